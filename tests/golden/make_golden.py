@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the UNMODIFIED reference scripts.
+
+Runs ONLY in the build container (needs /root/reference).  Nothing here travels
+to the GPU box except the .npz files this script writes next to itself.
+
+Method: the reference learner lives inside the
+``if __name__ == "__main__"`` block of e.g. cleanmarl/mappo_multienvs.py, so we
+execute the file with ``runpy.run_path(..., run_name="__main__")`` after
+injecting stub modules for the packages that are not installed here
+(tyro, tensorboard, env.* wrappers).  ``run_path`` returns the script's globals,
+from which we read the collated batch, the TD(lambda) returns / advantages and
+the per-epoch logged scalars; initial weights, per-step gradients and post-step
+weights are captured by subclassing the torch optimiser the script looks up with
+``getattr(optim, args.optimizer)``.
+
+The synthetic environment below is OURS (deterministic, numpy, implements the
+reference's CommonInterface surface: cleanmarl/env/common_interface.py:5-23).
+
+usage:  python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import dataclasses
+import os
+import runpy
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+REF = "/root/reference/cleanmarl"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# deterministic synthetic env (implements CommonInterface)
+# --------------------------------------------------------------------------
+class SynthEnv:
+    """Fixed-shape multi-agent env whose transitions are a pure function of
+    (env_id, episode, t).  Horizon differs per env instance when ``ragged``."""
+
+    counter = 0
+    spec = dict(A=3, obs_raw=6, K=5, horizon=16, ragged=False, avail_p=1.0,
+                state_dim=None, done_mode="truncate")
+
+    def __init__(self, agent_ids=True, **kw):
+        s = SynthEnv.spec
+        self.env_id = SynthEnv.counter
+        SynthEnv.counter += 1
+        self.n_agents = s["A"]
+        self.agent_ids = agent_ids
+        self.obs_raw = s["obs_raw"]
+        self.K = s["K"]
+        self.state_dim = s["state_dim"] or self.obs_raw * self.n_agents
+        h = s["horizon"]
+        if s["ragged"]:
+            h = h - (self.env_id * 5) % (h // 2 + 1)
+        self.horizon = max(2, h)
+        self.avail_p = s["avail_p"]
+        self.done_mode = s["done_mode"]
+        self.episode = -1
+        self.t = 0
+
+    # -- helpers ----------------------------------------------------------
+    def _rng(self, salt):
+        return np.random.default_rng([self.env_id, self.episode, self.t, salt])
+
+    def _observe(self):
+        raw = self._rng(0).standard_normal((self.n_agents, self.obs_raw))
+        if self.state_dim == self.obs_raw * self.n_agents:
+            self.state = raw.reshape(-1).copy()
+        else:
+            self.state = self._rng(1).standard_normal(self.state_dim)
+        if self.agent_ids:
+            raw = np.concatenate((raw, np.eye(self.n_agents)), axis=1)
+        return raw
+
+    # -- CommonInterface --------------------------------------------------
+    def reset(self, seed=None):
+        self.episode += 1
+        self.t = 0
+        return self._observe(), {}
+
+    def step(self, actions):
+        acts = np.asarray([int(a) for a in actions])
+        reward = float(self._rng(2).standard_normal() + 0.1 * np.mean(acts == (self.t % self.K)))
+        self.t += 1
+        end = self.t >= self.horizon
+        done = bool(end and self.done_mode == "done" and self.env_id % 2 == 0)
+        truncated = bool(end and not done)
+        return self._observe(), reward, done, truncated, {"battle_won": False}
+
+    def get_avail_actions(self):
+        if self.avail_p >= 1.0:
+            return np.ones((self.n_agents, self.K), dtype=np.int64)
+        av = (self._rng(3).random((self.n_agents, self.K)) < self.avail_p).astype(np.int64)
+        av[:, 0] = 1
+        return av
+
+    def get_state(self):
+        return self.state
+
+    def get_obs_size(self):
+        return self.obs_raw + self.agent_ids * self.n_agents
+
+    def get_state_size(self):
+        return self.state_dim
+
+    def get_action_size(self):
+        return self.K
+
+    def sample(self):
+        return [0] * self.n_agents
+
+    def close(self):
+        pass
+
+
+class _SW:
+    """stand-in for torch.utils.tensorboard.SummaryWriter"""
+    inst = None
+
+    def __init__(self, *a, **k):
+        self.log = []
+        _SW.inst = self
+
+    def add_scalar(self, tag, v, step):
+        self.log.append((tag, float(v), int(step)))
+
+    def add_text(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _install_stubs(overrides):
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = _SW
+    sys.modules["torch.utils.tensorboard"] = tb
+    ty = types.ModuleType("tyro")
+    ty.cli = lambda cls: dataclasses.replace(cls(), **overrides)
+    sys.modules["tyro"] = ty
+    pkg = types.ModuleType("env")
+    pkg.__path__ = []
+    sys.modules["env"] = pkg
+    for mod, cls in [("pettingzoo_wrapper", "PettingZooWrapper"),
+                     ("smaclite_wrapper", "SMACliteWrapper"), ("lbf", "LBFWrapper")]:
+        m = types.ModuleType("env." + mod)
+        setattr(m, cls, lambda family=None, env_name=None, map_name=None, agent_ids=True, **k: SynthEnv(agent_ids))
+        sys.modules["env." + mod] = m
+
+
+def run_reference(script, overrides, env_spec):
+    """Execute one reference script for exactly one training iteration."""
+    SynthEnv.counter = 0
+    SynthEnv.spec = dict(SynthEnv.spec, **env_spec)
+    ov = dict(env_type="pz", total_timesteps=1, eval_steps=10 ** 9, seed=1)
+    ov.update(overrides)
+    _install_stubs(ov)
+
+    snaps = []  # one dict per optimiser, in construction order (actor, critic)
+
+    def make(base):
+        class Snap(base):
+            def __init__(self, params, **k):
+                params = list(params)
+                self._snap = dict(init=[p.detach().clone().numpy() for p in params],
+                                  grads=[], after=[])
+                snaps.append(self._snap)
+                super().__init__(params, **k)
+
+            def step(self, *a, **k):
+                ps = [p for g in self.param_groups for p in g["params"]]
+                self._snap["grads"].append([p.grad.detach().clone().numpy() for p in ps])
+                r = super().step(*a, **k)
+                self._snap["after"].append([p.detach().clone().numpy() for p in ps])
+                return r
+        Snap.__name__ = base.__name__
+        return Snap
+
+    saved = {n: getattr(optim, n) for n in ("Adam", "AdamW")}
+    try:
+        for n, b in saved.items():
+            setattr(optim, n, make(b))
+        g = runpy.run_path(os.path.join(REF, script), run_name="__main__")
+    finally:
+        for n, b in saved.items():
+            setattr(optim, n, b)
+    return g, snaps, list(_SW.inst.log)
+
+
+def _flat(lst):
+    return np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in lst])
+
+
+def pack(g, snaps, log, extra=None):
+    a = g["args"]
+    out = {}
+    for k in ("b_obs", "b_actions", "b_log_probs", "b_reward", "b_states",
+              "b_avail_actions", "b_done", "b_mask", "return_lambda", "advantages"):
+        out[k] = g[k].detach().cpu().numpy()
+    for name, s in zip(("actor", "critic"), snaps):
+        out[f"{name}_shapes"] = np.array([len(p.shape) and p.shape[0] for p in s["init"]] , dtype=np.int64)
+        for i, p in enumerate(s["init"]):
+            out[f"{name}_init_{i}"] = p
+        out[f"{name}_nparam"] = np.int64(len(s["init"]))
+        out[f"{name}_grads"] = np.stack([_flat(x) for x in s["grads"]])
+        out[f"{name}_after"] = np.stack([_flat(x) for x in s["after"]])
+    for k in ("actor_losses", "critic_losses", "entropies_bonuses", "kl_divergences",
+              "actor_gradients", "critic_gradients", "clipped_ratios"):
+        out[k] = np.array([float(x) for x in g[k]], dtype=np.float64)
+    hp = {f.name: getattr(a, f.name) for f in dataclasses.fields(a)}
+    for k, v in hp.items():
+        if isinstance(v, (bool, int, float)):
+            out["hp_" + k] = np.float64(v)
+        else:
+            out["hp_" + k] = np.array(str(v))
+    out["log_tags"] = np.array([t for t, _, _ in log])
+    out["log_vals"] = np.array([v for _, v, _ in log], dtype=np.float64)
+    out["log_steps"] = np.array([s for _, _, s in log], dtype=np.int64)
+    if extra:
+        out.update(extra)
+    return out
+
+
+CASES = {
+    # name: (script, overrides, env_spec)
+    "mappo_dense": ("mappo_multienvs.py",
+                    dict(batch_size=8),
+                    dict(A=3, obs_raw=6, K=5, horizon=16, ragged=False, avail_p=1.0, state_dim=None, done_mode="truncate")),
+    "mappo_ragged_norm": ("mappo_multienvs.py",
+                          dict(batch_size=7, actor_hidden_dim=64, normalize_reward=True, normalize_advantage=True,
+                               normalize_return=True, clip_gradients=0.5),
+                          dict(A=3, obs_raw=6, K=5, horizon=18, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
+    "mappo_deep": ("mappo_multienvs.py",
+                   dict(batch_size=5, actor_hidden_dim=64, actor_num_layers=2, critic_hidden_dim=32,
+                        critic_num_layers=0, clip_gradients=10.0, optimizer="AdamW"),
+                   dict(A=2, obs_raw=35, K=4, horizon=12, ragged=True, avail_p=1.0, state_dim=None, done_mode="truncate")),
+    "ippo_dense": ("ippo_multienvs.py",
+                   dict(batch_size=8, critic_hidden_dim=64, actor_hidden_dim=64),
+                   dict(A=4, obs_raw=10, K=6, horizon=14, ragged=False, avail_p=1.0, state_dim=17, done_mode="truncate")),
+    "ippo_ragged_norm": ("ippo_multienvs.py",
+                         dict(batch_size=6, normalize_reward=True, normalize_advantage=True, normalize_return=True,
+                              clip_gradients=0.5),
+                         dict(A=3, obs_raw=11, K=7, horizon=20, ragged=True, avail_p=0.6, state_dim=19, done_mode="done")),
+    "mappo_lstm_ragged": ("mappo_lstm_multienvs.py",
+                          dict(batch_size=6, actor_hidden_dim=32, tbptt=4, epochs=2, clip_gradients=0.5),
+                          dict(A=3, obs_raw=6, K=5, horizon=21, ragged=True, avail_p=0.8, state_dim=None, done_mode="done")),
+    "mappo_lstm_dense": ("mappo_lstm_multienvs.py",
+                         dict(batch_size=4, actor_hidden_dim=64, tbptt=10, epochs=3),
+                         dict(A=4, obs_raw=10, K=5, horizon=24, ragged=False, avail_p=1.0, state_dim=None, done_mode="truncate")),
+    "ippo_lstm_ragged": ("ippo_lstm_multienvs.py",
+                         dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=32, epochs=2,
+                              normalize_advantage=True),
+                         dict(A=3, obs_raw=7, K=6, horizon=17, ragged=True, avail_p=0.7, state_dim=13, done_mode="done")),
+}
+
+
+def main(names=None):
+    torch.set_num_threads(1)  # deterministic summation order in the reference run
+    for name, (script, ov, spec) in CASES.items():
+        if names and name not in names:
+            continue
+        g, snaps, log = run_reference(script, ov, spec)
+        extra = {}
+        if ov.get("normalize_reward"):
+            # identical run without reward normalisation -> raw rewards (rollout is
+            # a pure function of the torch seed; normalisation happens after it)
+            ov2 = dict(ov, normalize_reward=False)
+            g2, _, _ = run_reference(script, ov2, spec)
+            assert np.array_equal(g2["b_actions"].numpy(), g["b_actions"].numpy())
+            extra["b_reward_raw"] = g2["b_reward"].numpy()
+        out = pack(g, snaps, log, extra)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) "
+              f"B,T,A={out['b_obs'].shape[:3]} actor_steps={len(out['actor_grads'])} critic_steps={len(out['critic_grads'])}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)

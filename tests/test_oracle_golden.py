@@ -1,0 +1,81 @@
+"""Pin the oracle (oracle/restatement.py) against golden vectors captured from the
+unmodified reference scripts (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"),
+             ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
+GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
+
+TOL = 2e-6  # oracle-vs-reference bar (product bar is 1e-4)
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.max(np.abs(a - b) / (1.0 + np.abs(b))) if a.size else 0.0
+    assert err <= tol, f"max rel-abs err {err:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("name,algo", MLP_CASES)
+def test_mlp_update_matches_reference(golden_dir, name, algo):
+    torch.set_num_threads(1)
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    if "b_reward_raw" in z.files:  # a2: reward normalisation
+        _close(R.normalize_reward(torch.from_numpy(z["b_reward_raw"]), batch["mask"]).numpy(), z["b_reward"])
+    ret, adv, recs = R.mlp_update(ap, cp, batch, hp, algo)
+    _close(ret.numpy(), z["return_lambda"])
+    _close(adv.numpy(), z["advantages"])
+    assert len(recs) == len(z["actor_losses"]) == int(hp["epochs"])
+    for e, r in enumerate(recs):
+        _close(r["actor_loss"], z["actor_losses"][e])
+        _close(r["critic_loss"], z["critic_losses"][e])
+        _close(r["entropy"], z["entropies_bonuses"][e])
+        _close(r["kl"], z["kl_divergences"][e], 5e-6)
+        _close(r["clipfrac"], z["clipped_ratios"][e])
+        _close(r["actor_gnorm"], z["actor_gradients"][e])
+        _close(r["critic_gnorm"], z["critic_gradients"][e])
+        _close(R.flat(r["actor_grads"]).numpy(), z["actor_grads"][e])
+        _close(R.flat(r["critic_grads"]).numpy(), z["critic_grads"][e])
+        _close(R.flat(r["actor_after"]).numpy(), z["actor_after"][e])
+        _close(R.flat(r["critic_after"]).numpy(), z["critic_after"][e])
+
+
+@pytest.mark.parametrize("name,algo", GRU_CASES)
+def test_gru_update_matches_reference(golden_dir, name, algo):
+    torch.set_num_threads(1)
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    ret, adv, recs = R.gru_update(ap, cp, batch, hp, algo)
+    _close(ret.numpy(), z["return_lambda"])
+    _close(adv.numpy(), z["advantages"])
+    k = 0
+    for e, r in enumerate(recs):
+        _close(r["actor_loss"], z["actor_losses"][e])
+        _close(r["critic_loss"], z["critic_losses"][e])
+        _close(r["entropy"], z["entropies_bonuses"][e])
+        _close(r["kl"], z["kl_divergences"][e], 5e-6)
+        _close(r["clipfrac"], z["clipped_ratios"][e])
+        _close(r["actor_gnorm"], z["actor_gradients"][e])
+        _close(r["critic_gnorm"], z["critic_gradients"][e])
+        for s in r["actor_steps"]:
+            _close(R.flat(s["grads"]).numpy(), z["actor_grads"][k])
+            _close(R.flat(s["after"]).numpy(), z["actor_after"][k])
+            k += 1
+        _close(R.flat(r["critic_grads"]).numpy(), z["critic_grads"][e])
+        _close(R.flat(r["critic_after"]).numpy(), z["critic_after"][e])
+    assert k == len(z["actor_grads"])
+
+
+def test_logged_scalars_are_epoch_means(golden_dir):
+    """train/* tags are means over epochs (mappo_multienvs.py:605-612)."""
+    z = np.load(os.path.join(golden_dir, "mappo_dense.npz"))
+    tags = list(z["log_tags"])
+    vals = z["log_vals"]
+    assert abs(vals[tags.index("train/actor_loss")] - z["actor_losses"].mean()) < 1e-9
+    assert abs(vals[tags.index("train/critic_loss")] - z["critic_losses"].mean()) < 1e-9
+    assert vals[tags.index("train/num_updates")] == 3
