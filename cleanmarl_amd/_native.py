@@ -1,0 +1,95 @@
+"""ctypes binding of libcleanmarl_hip.so (the C-ABI declared in include/cleanmarl_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails this raises.
+PyTorch is used only for device memory and streams; every pointer handed to the library is a raw
+``tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcleanmarl_hip.so")
+
+NUM_STATS = 8
+STAT_PG, STAT_ENT, STAT_KL, STAT_CLIP, STAT_VLOSS, STAT_COUNT = range(6)
+OPT_ADAM, OPT_ADAMW = 0, 1
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_d = C.c_double
+_f = C.c_float
+_u64 = C.c_uint64
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/cleanmarl_hip.h one to one
+SIGNATURES = {
+    "cm_last_error": (C.c_char_p, []),
+    "cm_version": (_i, []),
+    "cm_mlp_param_count": (_l, [_i, _i, _i, _i]),
+    "cm_gru_param_count": (_l, [_i, _i, _i]),
+    "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "cm_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_td_lambda_scan": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _p, _p, _p]),
+    "cm_masked_moments_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cm_masked_moments": (_i, [_p, _p, _i, _i, _i, _p, _p, _sz, _p]),
+    "cm_normalize": (_i, [_p, _p, _i, _i, _i, _p, _f, _i, _p]),
+    "cm_mlp_train_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cm_ppo_actor_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),
+    "cm_critic_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_grad_norm_clip_adam": (_i, [_p, _p, _p, _p, _l, _i, _d, _d, _d, _d, _d, _i, _d, _d, _p, _p]),
+    "cm_gru_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "cm_gru_actor_chunk_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _d, _d,
+                                        _p, _p, _sz, _p]),
+    "cm_gru_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_synth_env_reset": (_i, [_p, _i, _i, _i, _u64, _l, _l, _p, _p, _i, _p]),
+    "cm_synth_env_step": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or python cleanmarl_amd/build.py).  cleanmarl_amd has no CPU fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        except AttributeError:
+            if name.startswith("cm_gru_"):  # TEMP: GRU kernels land in a later commit
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cm_last_error()
+        raise NativeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

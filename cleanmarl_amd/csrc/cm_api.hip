@@ -1,0 +1,23 @@
+// cm_api.hip -- error plumbing + small C-ABI helpers of libcleanmarl_hip.so
+#include "cm_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void cm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cm_last_error(void) { return g_err; }
+extern "C" int cm_version(void) { return 100; }
+
+extern "C" int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout) {
+    return (int64_t)din * hidden + hidden + (int64_t)n_hidden_layers * ((int64_t)hidden * hidden + hidden) +
+           (int64_t)hidden * dout + dout;
+}
+extern "C" int64_t cm_gru_param_count(int din, int hidden, int dout) {
+    return (int64_t)din * hidden + hidden + 6LL * hidden * hidden + 6LL * hidden + (int64_t)hidden * dout + dout;
+}

@@ -1,0 +1,56 @@
+// cm_common.h -- shared device/host helpers for libcleanmarl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/cleanmarl_hip.h"
+
+#define CM_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing
+void cm_set_error(const char* fmt, ...);
+#define CM_FAIL(code, ...) do { cm_set_error(__VA_ARGS__); return (code); } while (0)
+#define CM_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) CM_FAIL(-2, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+#define CM_REQUIRE(cond, ...) do { if (!(cond)) CM_FAIL(-1, __VA_ARGS__); } while (0)
+
+// ---------------------------------------------------------------- Philox4x32-10 (counter RNG)
+// Keyed by the run seed, counted by (global row, time step, stream id): the draw for a given
+// (env, agent, t) is the same no matter how envs are sharded over GPUs.
+struct cm_u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline cm_u4 cm_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return cm_u4{c0, c1, c2, c3};
+}
+// uniform in [0,1) with 24 random bits (exactly representable in fp32)
+__host__ __device__ inline float cm_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+enum { CM_STREAM_ACT = 1, CM_STREAM_ENV_RESET = 2, CM_STREAM_ENV_STEP = 3 };
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float cm_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double cm_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,137 @@
+// cm_env.hip -- on-device synthetic MPE-like environment ("simple_spread" shapes and dynamics).
+//
+// Stands in for the per-env OS process + Pipe round trip of cleanmarl/mappo_multienvs.py:246-285, 393-453
+// in the synthetic benchmark configs.  Semantics follow the reference's CommonInterface
+// (cleanmarl/env/common_interface.py:5-23) as wrapped by cleanmarl/env/pettingzoo_wrapper.py:
+//   obs[a]  = [vel_a(2), pos_a(2), landmark_j - pos_a (2A), pos_j - pos_a for j != a (2(A-1)),
+//              comm zeros (2(A-1))]  (+ one-hot agent id when agent_ids)      -> Do = 6A (+A)   (:68-73, :93-98)
+//   state   = concat_a raw obs[a]                                             -> Ds = 6A*A      (:95)
+//   reward  = one team scalar per env step                                     (:66)
+//   actions = {0: no-op, 1: -x, 2: +x, 3: -y, 4: +y}; every action always available (:79-90)
+// Physics are our own re-statement of MPE-style point-mass dynamics (damping 0.25, dt 0.1, accel 5):
+// pettingzoo itself is not installed here, so this is "MPE-like", not a bit-copy of simple_spread_v3.
+// Randomness: Philox4x32-10 keyed by the run seed and counted by (global env index, episode, entity), so
+// the same env gets the same episode no matter which GPU owns it.
+// oracle/synth_env.py is the numpy twin used by the parity tests.
+#include "cm_common.h"
+
+namespace {
+
+constexpr float DAMP = 0.25f, DT = 0.1f, ACCEL = 5.0f, COLLIDE = 0.3f;
+
+__device__ __forceinline__ void write_obs(const float* pos, const float* vel, const float* lm, int A, int i,
+                                          int agent_ids, float* orow, float* srow) {
+    // pos/vel/lm: this env's [A][2] arrays (LDS).  orow: obs[e][i][t][:], srow: state[e][t][i*6A : (i+1)*6A]
+    const float px = pos[2 * i], py = pos[2 * i + 1];
+    int o = 0;
+    float v;
+#define PUT(val) do { v = (val); orow[o] = v; srow[o] = v; ++o; } while (0)
+    PUT(vel[2 * i]); PUT(vel[2 * i + 1]);
+    PUT(px); PUT(py);
+    for (int j = 0; j < A; ++j) { PUT(lm[2 * j] - px); PUT(lm[2 * j + 1] - py); }
+    for (int j = 0; j < A; ++j) if (j != i) { PUT(pos[2 * j] - px); PUT(pos[2 * j + 1] - py); }
+    for (int j = 0; j < 2 * (A - 1); ++j) PUT(0.0f);
+#undef PUT
+    if (agent_ids) for (int j = 0; j < A; ++j) orow[o + j] = (j == i) ? 1.0f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_env_reset(float* __restrict__ env_state, int E, int A, int agent_ids,
+                                                   unsigned long long seed, long env_offset, long episode,
+                                                   float* __restrict__ obs, float* __restrict__ state, int T) {
+    extern __shared__ float sm[];
+    const int epb = 256 / A;
+    const int el = threadIdx.x / A, i = threadIdx.x % A;
+    const long e = (long)blockIdx.x * epb + el;
+    const bool on = (el < epb) && (e < E);
+    float* pos = sm + el * 6 * A; float* vel = pos + 2 * A; float* lm = vel + 2 * A;
+    if (on) {
+        const unsigned long long ge = (unsigned long long)(env_offset + e);
+        const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                       (uint32_t)seed, (uint32_t)(seed >> 32));
+        pos[2 * i] = 2.0f * cm_u01(ra.x) - 1.0f; pos[2 * i + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+        lm[2 * i] = 2.0f * cm_u01(ra.z) - 1.0f; lm[2 * i + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+        vel[2 * i] = 0.0f; vel[2 * i + 1] = 0.0f;
+    }
+    __syncthreads();
+    if (on) {
+        float* es = env_state + e * 6 * A;
+        es[2 * i] = pos[2 * i]; es[2 * i + 1] = pos[2 * i + 1];
+        es[2 * A + 2 * i] = 0.0f; es[2 * A + 2 * i + 1] = 0.0f;
+        es[4 * A + 2 * i] = lm[2 * i]; es[4 * A + 2 * i + 1] = lm[2 * i + 1];
+        const int Do = 6 * A + (agent_ids ? A : 0);
+        write_obs(pos, vel, lm, A, i, agent_ids, obs + ((e * A + i) * (long)T + 0) * Do,
+                  state + (e * (long)T + 0) * (6L * A * A) + (long)i * 6 * A);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_env_step(float* __restrict__ env_state, const int* __restrict__ action,
+                                                  int E, int A, int agent_ids, int t, int T,
+                                                  float* __restrict__ reward, float* __restrict__ obs,
+                                                  float* __restrict__ state) {
+    extern __shared__ float sm[];
+    const int epb = 256 / A;
+    const int el = threadIdx.x / A, i = threadIdx.x % A;
+    const long e = (long)blockIdx.x * epb + el;
+    const bool on = (el < epb) && (e < E);
+    float* pos = sm + el * 6 * A; float* vel = pos + 2 * A; float* lm = vel + 2 * A;
+    if (on) {
+        float* es = env_state + e * 6 * A;
+        const int k = action[(e * A + i) * (long)T + t];
+        const float ux = (k == 1) ? -ACCEL : (k == 2 ? ACCEL : 0.0f);
+        const float uy = (k == 3) ? -ACCEL : (k == 4 ? ACCEL : 0.0f);
+        float vx = es[2 * A + 2 * i] * (1.0f - DAMP) + ux * DT;
+        float vy = es[2 * A + 2 * i + 1] * (1.0f - DAMP) + uy * DT;
+        float px = es[2 * i] + vx * DT;
+        float py = es[2 * i + 1] + vy * DT;
+        es[2 * i] = px; es[2 * i + 1] = py; es[2 * A + 2 * i] = vx; es[2 * A + 2 * i + 1] = vy;
+        pos[2 * i] = px; pos[2 * i + 1] = py; vel[2 * i] = vx; vel[2 * i + 1] = vy;
+        lm[2 * i] = es[4 * A + 2 * i]; lm[2 * i + 1] = es[4 * A + 2 * i + 1];
+    }
+    __syncthreads();
+    if (on) {
+        if (i == 0) {
+            float r = 0.0f;
+            for (int l = 0; l < A; ++l) {
+                float best = 3.0e38f;
+                for (int j = 0; j < A; ++j) {
+                    const float dx = pos[2 * j] - lm[2 * l], dy = pos[2 * j + 1] - lm[2 * l + 1];
+                    best = fminf(best, sqrtf(dx * dx + dy * dy));
+                }
+                r -= best;
+            }
+            for (int j = 0; j < A; ++j)
+                for (int q = j + 1; q < A; ++q) {
+                    const float dx = pos[2 * j] - pos[2 * q], dy = pos[2 * j + 1] - pos[2 * q + 1];
+                    if (sqrtf(dx * dx + dy * dy) < COLLIDE) r -= 1.0f;
+                }
+            reward[e * (long)T + t] = r;
+        }
+        if (t + 1 < T) {
+            const int Do = 6 * A + (agent_ids ? A : 0);
+            write_obs(pos, vel, lm, A, i, agent_ids, obs + ((e * A + i) * (long)T + (t + 1)) * Do,
+                      state + (e * (long)T + (t + 1)) * (6L * A * A) + (long)i * 6 * A);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cm_synth_env_reset(float* env_state, int E, int A, int agent_ids, uint64_t seed, int64_t env_offset,
+                                  int64_t episode, float* obs, float* state, int T, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && A > 0 && A <= 256 && T > 0, "cm_synth_env_reset: bad dims E=%d A=%d T=%d", E, A, T);
+    const int epb = 256 / A;
+    hipLaunchKernelGGL(k_env_reset, dim3((E + epb - 1) / epb), dim3(256), (size_t)epb * 6 * A * sizeof(float), (hipStream_t)stream,
+                       env_state, E, A, agent_ids, (unsigned long long)seed, (long)env_offset, (long)episode, obs, state, T);
+    CM_CHECK_LAUNCH("cm_synth_env_reset");
+    return 0;
+}
+
+extern "C" int cm_synth_env_step(float* env_state, const int32_t* action, int E, int A, int agent_ids, int t, int T,
+                                 float* reward, float* obs, float* state, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && A > 0 && A <= 256 && T > 0 && t >= 0 && t < T, "cm_synth_env_step: bad dims E=%d A=%d T=%d t=%d", E, A, T, t);
+    const int epb = 256 / A;
+    hipLaunchKernelGGL(k_env_step, dim3((E + epb - 1) / epb), dim3(256), (size_t)epb * 6 * A * sizeof(float), (hipStream_t)stream,
+                       env_state, action, E, A, agent_ids, t, T, reward, obs, state);
+    CM_CHECK_LAUNCH("cm_synth_env_step");
+    return 0;
+}

@@ -1,0 +1,70 @@
+// cm_optim.hip -- fused gradient scaling + norm_d + clip_grad_norm_ + Adam / AdamW step.
+//
+// Replaces cleanmarl/mappo_multienvs.py:572-594 after the backward pass:
+//   loss /= b_mask.sum()            -> gradient sums are scaled by grad_scale / N (N read from the stats tail)
+//   norm_d([p.grad ...], 2)         -> pre-clip global L2 norm, written to out_norm[0]
+//   clip_grad_norm_(max_norm)       -> g *= min(1, max_norm / (norm + 1e-6)) when max_norm > 0
+//   optimizer.step()                -> torch.optim.Adam / AdamW update rule
+// The parameter vectors are tiny (8k - 30k floats), so ONE workgroup of 1024 threads does all of it in a
+// single launch: pass 1 scales + accumulates the squared norm, a block reduction broadcasts the clip
+// coefficient, pass 2 applies the moment updates.  No host sync, no atomics, deterministic.
+#include "cm_common.h"
+
+#define OPT_THREADS 1024
+
+__global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam(
+    float* __restrict__ params, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+    float lr, float beta1, float beta2, float eps, float weight_decay, int opt_kind, float max_norm,
+    float grad_scale, float bc1, float bc2_sqrt, float* __restrict__ out_norm) {
+    __shared__ float sh[OPT_THREADS / 64];
+    __shared__ float s_coef;
+    const float N = g[n + CM_STAT_COUNT];
+    const float scale = (N > 0.0f) ? grad_scale / N : 0.0f;
+    float ss = 0.0f;
+    for (long i = threadIdx.x; i < n; i += OPT_THREADS) {
+        const float gi = g[i] * scale;
+        g[i] = gi;
+        ss = fmaf(gi, gi, ss);
+    }
+    ss = cm_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < OPT_THREADS / 64; ++w) tot += sh[w];
+        const float norm = sqrtf(tot);
+        out_norm[0] = norm;
+        float coef = 1.0f;
+        if (max_norm > 0.0f) coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+        s_coef = coef;
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    const float step_size = lr / bc1;
+    for (long i = threadIdx.x; i < n; i += OPT_THREADS) {
+        const float gi = g[i] * coef;
+        g[i] = gi;  // post-clip gradient stays readable (what optimizer.step() consumed)
+        float p = params[i];
+        if (opt_kind == CM_OPT_ADAMW) p *= (1.0f - lr * weight_decay);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        params[i] = p - step_size * (mi / denom);
+    }
+}
+
+extern "C" int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, float* exp_avg, float* exp_avg_sq,
+                                      int64_t n_params, int step, double lr, double beta1, double beta2, double eps,
+                                      double weight_decay, int opt_kind, double max_norm, double grad_scale,
+                                      float* out_norm, cm_stream_t stream) {
+    CM_REQUIRE(n_params > 0 && step >= 1, "cm_grad_norm_clip_adam: bad n_params=%ld step=%d", (long)n_params, step);
+    CM_REQUIRE(opt_kind == CM_OPT_ADAM || opt_kind == CM_OPT_ADAMW, "cm_grad_norm_clip_adam: unknown optimiser kind %d", opt_kind);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_grad_norm_clip_adam, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grad_and_stats,
+                       exp_avg, exp_avg_sq, (long)n_params, (float)lr, (float)beta1, (float)beta2, (float)eps,
+                       (float)weight_decay, opt_kind, (float)max_norm, (float)grad_scale, (float)bc1, (float)sqrt(bc2), out_norm);
+    CM_CHECK_LAUNCH("cm_grad_norm_clip_adam");
+    return 0;
+}

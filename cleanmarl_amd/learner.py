@@ -1,0 +1,277 @@
+"""Host side of the MAPPO / IPPO learner: owns device buffers and sequences the HIP kernels.
+
+Mirrors the inline learner of the reference script (cleanmarl/mappo_multienvs.py:481-612):
+    TD(lambda) targets (:484-504) -> optional normalisations (:505-512) -> `epochs` full-batch PPO
+    steps (:521-594) -> logged scalars (:597-612)
+but every numeric step is a call into libcleanmarl_hip.so on the current HIP stream.  PyTorch only
+provides device memory, streams and (for env-sharded multi-GPU runs) torch.distributed.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class NetSpec:
+    """Shape of one MLP (cleanmarl/mappo_multienvs.py:160-200) or GRU actor (mappo_lstm_multienvs.py:162-168)."""
+    din: int
+    hidden: int
+    n_layers: int
+    dout: int
+    kind: str = "mlp"
+
+    @property
+    def nparams(self):
+        lib = N.load()
+        if self.kind == "gru":
+            return int(lib.cm_gru_param_count(self.din, self.hidden, self.dout))
+        return int(lib.cm_mlp_param_count(self.din, self.hidden, self.n_layers, self.dout))
+
+    def shapes(self):
+        """Parameter tensor shapes in torch ``parameters()`` order."""
+        H, D, K = self.hidden, self.din, self.dout
+        if self.kind == "gru":
+            return [(H, D), (H,), (3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (K, H), (K,)]
+        s = [(H, D), (H,)]
+        for _ in range(self.n_layers):
+            s += [(H, H), (H,)]
+        return s + [(K, H), (K,)]
+
+
+def init_params_like_torch(spec, generator=None):
+    """nn.Linear / nn.GRUCell default init (U(+-1/sqrt(fan_in))), drawn on the CPU in the reference's
+    construction order so `torch.manual_seed(seed)` reproduces the reference's initial weights
+    (cleanmarl/mappo_multienvs.py:329-339)."""
+    import torch.nn as nn
+    mods = []
+    if spec.kind == "gru":
+        mods = [nn.Linear(spec.din, spec.hidden), nn.GRUCell(spec.hidden, spec.hidden), nn.Linear(spec.hidden, spec.dout)]
+    else:
+        mods = [nn.Linear(spec.din, spec.hidden)] + [nn.Linear(spec.hidden, spec.hidden) for _ in range(spec.n_layers)]
+        mods.append(nn.Linear(spec.hidden, spec.dout))
+    return [p.detach().clone() for m in mods for p in m.parameters()]
+
+
+def flatten_params(plist, device):
+    return torch.cat([p.reshape(-1).float() for p in plist]).contiguous().to(device)
+
+
+def unflatten_params(flat, spec):
+    out, o = [], 0
+    for shp in spec.shapes():
+        n = math.prod(shp)
+        out.append(flat[o:o + n].reshape(shp))
+        o += n
+    return out
+
+
+class DeviceBatch:
+    """Rollout storage in the device layout of include/cleanmarl_hip.h (the [E,A,T,F] permutation of the
+    reference's RolloutBuffer batch, cleanmarl/mappo_multienvs.py:109-157)."""
+
+    def __init__(self, E, A, T, Do, Ds, K, device):
+        self.E, self.A, self.T, self.Do, self.Ds, self.K = E, A, T, Do, Ds, K
+        self.device = device
+        f32 = dict(dtype=torch.float32, device=device)
+        self.obs = torch.zeros(E, A, T, Do, **f32)
+        self.state = torch.zeros(E, T, Ds, **f32)
+        self.avail = torch.zeros(E, A, T, K, dtype=torch.uint8, device=device)
+        self.action = torch.zeros(E, A, T, dtype=torch.int32, device=device)
+        self.logp = torch.zeros(E, A, T, **f32)
+        self.reward = torch.zeros(E, T, **f32)
+        self.ep_len = torch.zeros(E, dtype=torch.int32, device=device)
+        self.ret = torch.zeros(E, A, T, **f32)
+        self.adv = torch.zeros(E, A, T, **f32)
+
+    @classmethod
+    def from_reference_layout(cls, b_obs, b_actions, b_log_probs, b_reward, b_states, b_avail, b_mask, device):
+        """Build from tensors laid out like the reference batch ([B,T,A,F] etc.)."""
+        B, T, A, Do = b_obs.shape
+        self = cls(B, A, T, Do, b_states.shape[-1], b_avail.shape[-1], device)
+        self.obs.copy_(b_obs.permute(0, 2, 1, 3))
+        self.state.copy_(b_states)
+        self.avail.copy_(b_avail.permute(0, 2, 1, 3).to(torch.uint8))
+        self.action.copy_(b_actions.permute(0, 2, 1).to(torch.int32))
+        self.logp.copy_(b_log_probs.permute(0, 2, 1))
+        self.reward.copy_(b_reward)
+        self.ep_len.copy_(b_mask.sum(1).to(torch.int32))
+        return self
+
+
+@dataclass
+class HParams:
+    """The learner-relevant subset of the reference's Args (cleanmarl/mappo_multienvs.py:18-79)."""
+    gamma: float = 0.99
+    td_lambda: float = 0.95
+    normalize_reward: bool = False
+    normalize_advantage: bool = False
+    normalize_return: bool = False
+    epochs: int = 3
+    ppo_clip: float = 0.2
+    entropy_coef: float = 0.001
+    clip_gradients: float = -1
+    optimizer: str = "Adam"
+    learning_rate_actor: float = 0.0008
+    learning_rate_critic: float = 0.0008
+    tbptt: int = 10
+
+    @classmethod
+    def from_args(cls, args):
+        return cls(**{f: getattr(args, f) for f in cls.__dataclass_fields__ if hasattr(args, f)})
+
+
+class _Adam:
+    """Optimiser state for one flat parameter buffer (torch.optim.Adam / AdamW defaults)."""
+
+    def __init__(self, nparams, lr, kind, device):
+        if kind not in ("Adam", "AdamW"):
+            raise N.NativeError(f"optimizer={kind!r}: only Adam and AdamW have a HIP implementation")
+        self.kind = N.OPT_ADAMW if kind == "AdamW" else N.OPT_ADAM
+        self.wd = 0.01 if kind == "AdamW" else 0.0
+        self.lr = lr
+        self.m = torch.zeros(nparams, dtype=torch.float32, device=device)
+        self.v = torch.zeros(nparams, dtype=torch.float32, device=device)
+        self.step = 0
+
+
+class PPOLearner:
+    """algo = "mappo" (central critic on state) or "ippo" (per-agent critic on obs)."""
+
+    def __init__(self, algo, actor_spec, critic_spec, n_agents, hp, device, actor_params=None, critic_params=None,
+                 process_group=None, world_size=1):
+        assert algo in ("mappo", "ippo")
+        self.lib = N.load()
+        self.algo, self.A, self.hp, self.device = algo, n_agents, hp, device
+        self.actor_spec, self.critic_spec = actor_spec, critic_spec
+        self.pg, self.world = process_group, world_size
+        if actor_params is None:
+            actor_params = init_params_like_torch(actor_spec)
+        if critic_params is None:
+            critic_params = init_params_like_torch(critic_spec)
+        self.actor = flatten_params(actor_params, device)
+        self.critic = flatten_params(critic_params, device)
+        Pa, Pc = actor_spec.nparams, critic_spec.nparams
+        assert self.actor.numel() == Pa and self.critic.numel() == Pc, (self.actor.numel(), Pa, self.critic.numel(), Pc)
+        self.opt_a = _Adam(Pa, hp.learning_rate_actor, hp.optimizer, device)
+        self.opt_c = _Adam(Pc, hp.learning_rate_critic, hp.optimizer, device)
+        # one flat buffer [actor grads | 8 stats | critic grads | 8 stats] = ONE all-reduce per optimiser step
+        self.gbuf = torch.zeros(Pa + Pc + 2 * N.NUM_STATS, dtype=torch.float32, device=device)
+        self.g_actor = self.gbuf[:Pa + N.NUM_STATS]
+        self.g_critic = self.gbuf[Pa + N.NUM_STATS:]
+        self.norms = torch.zeros(2, dtype=torch.float32, device=device)
+        ws_a = self.lib.cm_mlp_train_workspace_bytes(actor_spec.din, actor_spec.hidden, actor_spec.n_layers, actor_spec.dout) \
+            if actor_spec.kind == "mlp" else 0
+        ws_c = self.lib.cm_mlp_train_workspace_bytes(critic_spec.din, critic_spec.hidden, critic_spec.n_layers, 1)
+        self.ws = torch.empty(max(ws_a, ws_c, 1024), dtype=torch.uint8, device=device)
+        self.moments = torch.zeros(3, dtype=torch.float64, device=device)
+        self.values = None
+        self.mom_ws = None
+
+    # ------------------------------------------------------------------ helpers
+    def _allreduce(self, t):
+        if self.world > 1:
+            torch.distributed.all_reduce(t, group=self.pg)
+
+    def _moments(self, x, ep_len, E, A, T, s):
+        """(count, mean, M2) of the agent-mean over valid steps; merged across ranks (Chan et al.)."""
+        need = self.lib.cm_masked_moments_workspace_bytes(E, A, T)
+        if self.mom_ws is None or self.mom_ws.numel() < need:
+            self.mom_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.mom_ws),
+                                           self.mom_ws.numel(), s), "cm_masked_moments")
+        if self.world > 1:
+            parts = [torch.zeros_like(self.moments) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, self.moments, group=self.pg)
+            n = sum(p[0] for p in parts)
+            mean = sum(p[0] * p[1] for p in parts) / n
+            m2 = sum(p[2] + p[0] * (p[1] - mean) ** 2 for p in parts)
+            self.moments.copy_(torch.stack([n, mean, m2]))
+
+    # ------------------------------------------------------------------ a6 / a7
+    def compute_targets(self, b):
+        """TD(lambda) returns + advantages into b.ret / b.adv (cleanmarl/mappo_multienvs.py:484-512)."""
+        lib, hp, s = self.lib, self.hp, N.stream_ptr()
+        E, A, T = b.E, b.A, b.T
+        cs = self.critic_spec
+        if hp.normalize_reward:  # RolloutBuffer.get_batch, :143-146
+            self._moments(b.reward, b.ep_len, E, 1, T, s)
+            N.check(lib.cm_normalize(N.ptr(b.reward), N.ptr(b.ep_len), E, 1, T, N.ptr(self.moments), 1e-6, 1, s), "cm_normalize")
+        Av = 1 if self.algo == "mappo" else A
+        if self.values is None or self.values.shape != (E, Av, T):
+            self.values = torch.empty(E, Av, T, dtype=torch.float32, device=self.device)
+        x = b.state if self.algo == "mappo" else b.obs
+        rows = E * T * Av
+        N.check(lib.cm_mlp_forward(N.ptr(x), rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
+                                   N.ptr(self.values), s), "cm_mlp_forward")
+        N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
+                                      hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
+        if hp.normalize_advantage:
+            self._moments(b.adv, b.ep_len, E, A, T, s)
+            N.check(lib.cm_normalize(N.ptr(b.adv), N.ptr(b.ep_len), E, A, T, N.ptr(self.moments), 0.0, 0, s), "cm_normalize")
+        if hp.normalize_return:
+            self._moments(b.ret, b.ep_len, E, A, T, s)
+            N.check(lib.cm_normalize(N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, N.ptr(self.moments), 0.0, 0, s), "cm_normalize")
+
+    # ------------------------------------------------------------------ a8 - a12
+    def _adam(self, params, g, opt, which, s, grad_scale=1.0):
+        opt.step += 1
+        hp = self.hp
+        N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
+                                                opt.lr, 0.9, 0.999, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
+                                                grad_scale, N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
+
+    def critic_pass(self, b, s):
+        cs = self.critic_spec
+        x = b.state if self.algo == "mappo" else b.obs
+        N.check(self.lib.cm_critic_fwd_bwd(N.ptr(x), N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
+                                           0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
+                                           N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws), self.ws.numel(), s),
+                "cm_critic_fwd_bwd")
+
+    def actor_pass(self, b, s):
+        a = self.actor_spec
+        N.check(self.lib.cm_ppo_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
+                                              N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
+                                              N.ptr(self.actor), self.hp.ppo_clip, self.hp.entropy_coef,
+                                              N.ptr(self.g_actor), N.ptr(self.ws), self.ws.numel(), s),
+                "cm_ppo_actor_fwd_bwd")
+
+    def update(self, b, keep_grads=False):
+        """`epochs` full-batch PPO steps (cleanmarl/mappo_multienvs.py:521-594).
+        Returns a list of per-epoch dicts (one host sync at the end)."""
+        hp, s = self.hp, N.stream_ptr()
+        Pa, Pc = self.actor.numel(), self.critic.numel()
+        rec = torch.zeros(int(hp.epochs), 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
+        kept = []
+        for ep in range(int(hp.epochs)):
+            self.actor_pass(b, s)
+            self.critic_pass(b, s)
+            self._allreduce(self.gbuf)  # the only data-path collective: grads + N + stat sums
+            self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
+            self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
+            rec[ep, :N.NUM_STATS] = self.g_actor[Pa:]
+            rec[ep, N.NUM_STATS:2 * N.NUM_STATS] = self.g_critic[Pc:]
+            rec[ep, 2 * N.NUM_STATS:] = self.norms
+            if keep_grads:
+                kept.append((self.g_actor[:Pa].clone(), self.g_critic[:Pc].clone(), self.actor.clone(), self.critic.clone()))
+        r = rec.cpu().double()  # single sync
+        out = []
+        for ep in range(int(hp.epochs)):
+            st_a, st_c = r[ep, :N.NUM_STATS], r[ep, N.NUM_STATS:2 * N.NUM_STATS]
+            n = float(st_a[N.STAT_COUNT])
+            d = dict(actor_loss=float(-st_a[N.STAT_PG] - hp.entropy_coef * st_a[N.STAT_ENT]) / n,
+                     critic_loss=float(st_c[N.STAT_VLOSS]) / float(st_c[N.STAT_COUNT]),
+                     entropy=float(st_a[N.STAT_ENT]) / n, kl=float(st_a[N.STAT_KL]) / n,
+                     clipfrac=float(st_a[N.STAT_CLIP]) / n,
+                     actor_gnorm=float(r[ep, 2 * N.NUM_STATS]), critic_gnorm=float(r[ep, 2 * N.NUM_STATS + 1]), n_valid=n)
+            if keep_grads:
+                d.update(actor_grads=kept[ep][0], critic_grads=kept[ep][1], actor_after=kept[ep][2], critic_after=kept[ep][3])
+            out.append(d)
+        return out
+
+    def train_iteration(self, b, keep_grads=False):
+        self.compute_targets(b)
+        return self.update(b, keep_grads=keep_grads)

@@ -1,0 +1,165 @@
+/* cleanmarl_hip.h -- C-ABI of libcleanmarl_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (AmineAndam04/cleanmarl) has NO operator / FFI interface: the whole learner is
+ * inline code inside `if __name__ == "__main__":` of cleanmarl/mappo_multienvs.py (and the
+ * ippo_ / *_lstm_ siblings).  Each entry point below replaces one inline program region of that
+ * script; the region is cited as file:line.  INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add at each of those program points.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; cm_last_error() gives a thread-local text.
+ *   - the CALLER owns all memory: arguments are raw DEVICE pointers (e.g. torch tensor.data_ptr()),
+ *     explicit dims, and the hipStream_t to launch on (torch.cuda.current_stream().cuda_stream).
+ *   - no hidden allocation, no global mutable state, no implicit host sync: functions that need
+ *     scratch take a caller-provided workspace sized by the matching *_workspace_bytes() query.
+ *   - all device arithmetic is fp32; scalar hyper-parameters cross the ABI as double so that expressions the
+ *     reference evaluates in Python float64 (e.g. 1 - td_lambda, 1 +- ppo_clip) are rounded to fp32 once.
+ *     Device data layout, E envs, A agents, T steps:
+ *       obs     float  [E][A][T][Do]      state  float [E][T][Ds]      reward float [E][T]
+ *       avail   uint8  [E][A][T][K]       action int32 [E][A][T]       logp   float [E][A][T]
+ *       values  float  [E][Av][T] (Av = 1 MAPPO / A IPPO)   ret, adv float [E][A][T]
+ *       ep_len  int32  [E]   (mask[e][t] = t < ep_len[e]; reference b_mask is always a prefix)
+ *     which is the axis permutation ref[b,t,a,f] == dev[e=b,a,t,f] of the reference batch
+ *     (cleanmarl/mappo_multienvs.py:113-132).
+ *   - network parameters are ONE flat fp32 buffer in torch `module.parameters()` order
+ *       MLP: W0[H][Din] b0[H] {Wl[H][H] bl[H]} x L  Wout[Dout][H] bout[Dout]
+ *            (cleanmarl/mappo_multienvs.py:160-170, 186-195)
+ *       GRU actor: fc1.W[H][Din] fc1.b[H] W_ih[3H][H] W_hh[3H][H] b_ih[3H] b_hh[3H] fc2.W[K][H] fc2.b[K]
+ *            (cleanmarl/mappo_lstm_multienvs.py:162-168)
+ *     gradients use the same flat layout.
+ */
+#ifndef CLEANMARL_HIP_H
+#define CLEANMARL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cm_stream_t; /* hipStream_t */
+
+/* statistics slots appended after the flat gradient by the *_fwd_bwd kernels (un-normalised sums) */
+enum {
+    CM_STAT_PG = 0,     /* sum_{e,t} mask * mean_a min(A*rho, A*clip(rho))      mappo_multienvs.py:538-546 */
+    CM_STAT_ENT = 1,    /* sum mask * mean_a H(pi)                              :549-550 */
+    CM_STAT_KL = 2,     /* sum mask * mean_a ((rho-1) - log rho)                :561-564 */
+    CM_STAT_CLIP = 3,   /* sum mask * mean_a [|rho-1| > eps]                    :565-570 */
+    CM_STAT_VLOSS = 4,  /* sum mask * mean_a (V - R)^2                          :554-558 */
+    CM_STAT_COUNT = 5,  /* number of valid (env,t) pairs seen = b_mask.sum()    :572 */
+    CM_NUM_STATS = 8
+};
+
+enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1 };
+
+const char* cm_last_error(void);
+int cm_version(void);
+/* number of floats in a flat MLP parameter buffer */
+int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout);
+int64_t cm_gru_param_count(int din, int hidden, int dout);
+
+/* ---- a3 / a5: Actor.logits / Critic.forward  (cleanmarl/mappo_multienvs.py:178-183, 197-200) ----
+ * y[rows][dout] = MLP(x[rows][din]).  If avail != NULL (uint8 [rows][dout]) entries with avail==0 are
+ * filled with -1e9 (masked_fill, :182).  Used for the value pass that feeds the TD(lambda) scan
+ * (replaces the 2*E*T single-row critic calls at :492-504). */
+int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                   const float* params, const uint8_t* avail, float* y, cm_stream_t stream);
+
+/* ---- a4: Actor.act  (cleanmarl/mappo_multienvs.py:172-176, called at :409-414) ----
+ * Fused actor MLP + masked_fill + Categorical sample + log_prob for `rows` (env,agent) pairs.
+ * x row r lives at x + r*x_row_stride floats (so the kernel can read obs[e][a][t][:] in place with
+ * stride T*Do); outputs are written at action + r*out_stride, logp + r*out_stride (stride T writes
+ * actions[e][a][t] in place).  Sampling: inverse-CDF with one Philox4x32-10 uniform keyed by
+ * (seed, global_row = row_offset + r, t) -- identical for any GPU count. */
+int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                  int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
+                  const float* params, uint64_t seed, int64_t row_offset, int t,
+                  int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
+
+/* ---- a6: TD(lambda) return + advantage  (cleanmarl/mappo_multienvs.py:484-504; ippo :483-503) ----
+ * R_t = r_t + gamma*(lam*R_{t+1} + (1-lam)*V_{t+1}),  R = V = 0 beyond the last valid step,
+ * A_t = R_t - V_t, zeros on padded steps.  Av = 1 broadcasts one value sequence to all A agents. */
+int cm_td_lambda_scan(const float* reward, const float* values, const int32_t* ep_len,
+                      int E, int A, int Av, int T, double gamma, double lam,
+                      float* ret, float* adv, cm_stream_t stream);
+
+/* ---- a2 / a7: masked moments + normalisation ----
+ * moments of the AGENT-MEAN of x[E][A][T] over valid (e,t):  out[0]=count, out[1]=sum, out[2]=sum of
+ * squares about the shard mean... see cm_masked_moments for the exact (count, mean, M2) triple so that
+ * shards can be merged Chan-style across GPUs.  (cleanmarl/mappo_multienvs.py:143-146, 505-512) */
+size_t cm_masked_moments_workspace_bytes(int E, int A, int T);
+int cm_masked_moments(const float* x, const int32_t* ep_len, int E, int A, int T,
+                      double* out_count_mean_m2 /* device, 3 doubles */, void* ws, size_t ws_bytes,
+                      cm_stream_t stream);
+/* x = (x - mean) / (std_unbiased + eps) applied to valid entries only (valid_only=1, reward path :146)
+ * or to every entry (valid_only=0, advantage / return path :508, :512).  count/mean/M2 are read from
+ * device memory so no host sync is needed. */
+int cm_normalize(float* x, const int32_t* ep_len, int E, int A, int T,
+                 const double* count_mean_m2, float eps, int valid_only, cm_stream_t stream);
+
+/* ---- a8 / a9: PPO actor loss forward + backward  (cleanmarl/mappo_multienvs.py:527-551, 561-582) ----
+ * One full-batch pass over rows = E*A*T.  Writes per-workgroup partial gradients + statistics into
+ * the workspace; cm_reduce_partials folds them into grad_and_stats[P + CM_NUM_STATS].
+ * Gradients / statistics are UN-NORMALISED masked sums of the agent-mean (i.e. already divided by A
+ * but not by N = b_mask.sum()); the division by the (global) N happens in cm_grad_norm_clip_adam so
+ * that env-sharded ranks can all-reduce the buffer first. */
+size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden_layers, int dout);
+int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
+                         const float* logp_old, const float* adv, const int32_t* ep_len,
+                         int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                         const float* params, double ppo_clip, double entropy_coef,
+                         float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+
+/* ---- a8 / a9: critic MSE forward + backward  (cleanmarl/mappo_multienvs.py:554-558, 582) ----
+ * per_agent = 0 (MAPPO): rows = E*T of x = state[E][T][din]; target mean over the A agents of ret.
+ * per_agent = 1 (IPPO):  rows = E*A*T of x = obs[E][A][T][din]  (cleanmarl/ippo_multienvs.py:554). */
+int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,
+                      int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                      const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                      cm_stream_t stream);
+
+/* ---- a10 / a11 / a12: norm_d + clip_grad_norm_ + Adam/AdamW step ----
+ * (cleanmarl/mappo_multienvs.py:221-224, 584-594).  grad_and_stats holds P un-normalised gradient sums
+ * followed by CM_NUM_STATS statistics; slot CM_STAT_COUNT is N.  The kernel scales the gradient by
+ * grad_scale / N  (grad_scale = 1 for the MLP scripts; 1/T_chunk for the TBPTT chunk loss of
+ * cleanmarl/mappo_lstm_multienvs.py:605-607), stores the pre-clip global L2 norm in out_norm[0],
+ * clips to max_norm if max_norm > 0 (coef = min(1, max_norm/(norm+1e-6))), then applies one
+ * Adam (weight_decay ignored) or AdamW (decoupled weight_decay) step with bias correction for `step`. */
+int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, float* exp_avg, float* exp_avg_sq,
+                           int64_t n_params, int step, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, int opt_kind, double max_norm, double grad_scale,
+                           float* out_norm, cm_stream_t stream);
+
+/* ---- a13 / a14: GRU actor, TBPTT chunk  (cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620) ----
+ * Forward + backward-through-time over steps [t0, t1) for all E*A sequences starting from the detached
+ * hidden state h_in[E*A][H]; writes h_out (= h at t1, to be used detached for the next chunk) and the
+ * flat gradient + statistics of the chunk loss  sum_{t in chunk} (-pg_t - c*ent_t)  (un-normalised). */
+size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int n_actions, int chunk_len);
+int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
+                               const float* logp_old, const float* adv, const int32_t* ep_len,
+                               int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                               const float* params, const float* h_in, float* h_out,
+                               double ppo_clip, double entropy_coef,
+                               float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* single rollout step of the GRU actor (mappo_lstm_multienvs.py:170-174, 421-425): h updated in place */
+int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                      int64_t rows, int din, int hidden, int n_actions, const float* params, float* h,
+                      uint64_t seed, int64_t row_offset, int t,
+                      int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
+
+/* ---- a15: on-device synthetic MPE-like environment (replaces the pipe round trips at
+ * cleanmarl/mappo_multienvs.py:393-453 for the synthetic configs; CommonInterface semantics of
+ * cleanmarl/env/common_interface.py:5-23 and the obs/state construction of
+ * cleanmarl/env/pettingzoo_wrapper.py:93-98 for MPE simple_spread: Do = 6A (+A ids), Ds = 6A*A). */
+/* env_state: float [E][6*A] = agent pos(2A) vel(2A) landmark pos(2A).  reset writes obs/state at t=0. */
+int cm_synth_env_reset(float* env_state, int E, int A, int agent_ids, uint64_t seed, int64_t env_offset,
+                       int64_t episode, float* obs, float* state, int T, cm_stream_t stream);
+/* consumes action[e][a][t], writes reward[e][t] and (if t+1 < T) obs/state at t+1. */
+int cm_synth_env_step(float* env_state, const int32_t* action, int E, int A, int agent_ids, int t, int T,
+                      float* reward, float* obs, float* state, cm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLEANMARL_HIP_H */

@@ -1,0 +1,174 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs golden vectors captured from the unmodified reference
+and vs the CPU oracle on seeded inputs.  Tolerance: north_star's 1e-4 (fp32), written per assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: returns / advantages / losses within 1e-4 fp32
+
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"),
+             ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
+
+
+def _err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+
+
+def _learner_from_golden(path, algo):
+    from oracle import restatement as R
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    batch, ap, cp, hp, z = R.load_golden(path)
+    dev = torch.device("cuda:0")
+    reward = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else batch["reward"]
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], reward,
+                                          batch["states"], batch["avail"], batch["mask"], dev)
+    A = batch["obs"].shape[2]
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"],
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = PPOLearner(algo, aspec, cspec, A, H, dev, actor_params=ap, critic_params=cp)
+    return L, b, z, batch
+
+
+@pytest.mark.parametrize("name,algo", MLP_CASES)
+def test_update_matches_reference_golden(golden_dir, name, algo):
+    L, b, z, batch = _learner_from_golden(os.path.join(golden_dir, name + ".npz"), algo)
+    recs = L.train_iteration(b, keep_grads=True)
+    if "b_reward_raw" in z.files:
+        assert _err(b.reward.cpu().numpy(), z["b_reward"]) <= TOL
+    ret = b.ret.permute(0, 2, 1).cpu().numpy()
+    adv = b.adv.permute(0, 2, 1).cpu().numpy()
+    assert _err(ret, z["return_lambda"]) <= TOL
+    assert _err(adv, z["advantages"]) <= TOL
+    for e, r in enumerate(recs):
+        assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL
+        assert _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+        assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
+        assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
+        assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
+        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
+        assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+        assert _err(r["actor_grads"].cpu().numpy(), z["actor_grads"][e]) <= TOL
+        assert _err(r["critic_grads"].cpu().numpy(), z["critic_grads"][e]) <= TOL
+        assert _err(r["actor_after"].cpu().numpy(), z["actor_after"][e]) <= TOL
+        assert _err(r["critic_after"].cpu().numpy(), z["critic_after"][e]) <= TOL
+
+
+def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(E, T, A, Do, generator=g)
+    states = torch.randn(E, T, Ds, generator=g)
+    avail = torch.rand(E, T, A, K, generator=g) < avail_p
+    avail[..., 0] = True
+    probs = avail.float() / avail.float().sum(-1, keepdim=True)
+    actions = torch.multinomial(probs.reshape(-1, K), 1, generator=g).reshape(E, T, A)
+    logp = -torch.rand(E, T, A, generator=g) * 2.0
+    reward = torch.randn(E, T, generator=g)
+    if ragged:
+        lens = torch.randint(max(1, T // 2), T + 1, (E,), generator=g)
+        lens[0] = T
+    else:
+        lens = torch.full((E,), T)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    m = mask[..., None]
+    obs = obs * m[..., None]; states = states * m; avail = avail & m[..., None]
+    actions = actions * mask[..., None]; logp = logp * m; reward = reward * mask
+    return dict(obs=obs, actions=actions, log_probs=logp, reward=reward, states=states, avail=avail, mask=mask)
+
+
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
+    ("mappo", 37, 3, 25, 21, 54, 5, 64, 1),     # config-1/2 shapes, ragged tile edge
+    ("mappo", 16, 8, 32, 56, 384, 5, 64, 1),    # config-3 shapes (6 input chunks for the critic)
+    ("ippo", 12, 10, 40, 115, 243, 17, 64, 1),  # config-4 shapes (2 chunks, 17 actions, avail masks)
+    ("mappo", 9, 2, 17, 70, 140, 6, 32, 2),     # H=32 padded to 64, 2 hidden layers, 2/3 chunks
+    ("ippo", 5, 3, 8, 7, 11, 3, 48, 0),         # no hidden->hidden layer, odd H
+])
+def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
+    from oracle import restatement as R
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+    torch.manual_seed(1)
+    batch = _random_case(123, E, A, T, Do, Ds, K)
+    aspec = NetSpec(Do, H, L, K)
+    cspec = NetSpec(Ds if algo == "mappo" else Do, H, L, 1)
+    ap = init_params_like_torch(aspec)
+    cp = init_params_like_torch(cspec)
+    hp = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=True, normalize_return=False, epochs=2, ppo_clip=0.2,
+              entropy_coef=0.01, clip_gradients=0.5, optimizer="Adam", learning_rate_actor=8e-4, learning_rate_critic=8e-4)
+    dev = torch.device("cuda:0")
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"],
+                                          batch["states"], batch["avail"], batch["mask"], dev)
+    Lr = PPOLearner(algo, aspec, cspec, A, HParams(**hp), dev, actor_params=[p.clone() for p in ap],
+                    critic_params=[p.clone() for p in cp])
+    recs = Lr.train_iteration(b, keep_grads=True)
+    ret, adv, orecs = R.mlp_update(ap, cp, batch, hp, algo)
+    assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL
+    assert _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
+    for r, o in zip(recs, orecs):
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
+            assert _err(r[k], o[k]) <= TOL, k
+        assert _err(r["actor_grads"].cpu().numpy(), R.flat(o["actor_grads"]).numpy()) <= TOL
+        assert _err(r["critic_grads"].cpu().numpy(), R.flat(o["critic_grads"]).numpy()) <= TOL
+        assert _err(r["actor_after"].cpu().numpy(), R.flat(o["actor_after"]).numpy()) <= TOL
+        assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
+
+
+def test_scan_long_sequences_and_edge_lengths():
+    """T not a multiple of 64, T > 64 lanes, ep_len in {0, 1, T}."""
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    for (E, A, Av, T) in [(7, 3, 1, 1), (5, 4, 4, 63), (9, 2, 1, 150), (6, 3, 3, 257)]:
+        g = torch.Generator().manual_seed(E * 1000 + T)
+        reward = torch.randn(E, T, generator=g)
+        values = torch.randn(E, Av, T, generator=g)
+        lens = torch.randint(0, T + 1, (E,), generator=g)
+        lens[0] = T
+        if E > 1:
+            lens[1] = 0
+        if E > 2:
+            lens[2] = 1
+        ret = torch.empty(E, A, T, device=dev); adv = torch.empty(E, A, T, device=dev)
+        N.check(lib.cm_td_lambda_scan(N.ptr(reward.to(dev)), N.ptr(values.to(dev)), N.ptr(lens.int().to(dev)), E, A, Av, T,
+                                      0.99, 0.95, N.ptr(ret), N.ptr(adv), N.stream_ptr()), "scan")
+        mask = torch.arange(T)[None, :] < lens[:, None]
+        v_ref = values.permute(0, 2, 1).expand(E, T, A)
+        r_ref, a_ref = R.td_lambda(reward * mask, v_ref, mask, 0.99, 0.95)
+        assert _err(ret.permute(0, 2, 1).cpu().numpy(), r_ref.numpy()) <= TOL
+        assert _err(adv.permute(0, 2, 1).cpu().numpy(), a_ref.numpy()) <= TOL
+
+
+def test_mlp_forward_matches_oracle():
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for (rows, din, H, L, dout) in [(1, 5, 64, 1, 1), (1000, 384, 64, 1, 1), (777, 115, 64, 1, 17), (130, 21, 32, 2, 5), (64, 200, 17, 0, 32)]:
+        spec = NetSpec(din, H, L, dout)
+        p = init_params_like_torch(spec)
+        x = torch.randn(rows, din)
+        avail = torch.rand(rows, dout) < 0.6
+        y = torch.empty(rows, dout, device=dev)
+        N.check(lib.cm_mlp_forward(N.ptr(x.to(dev)), rows, din, H, L, dout, N.ptr(flatten_params(p, dev)),
+                                   N.ptr(avail.to(torch.uint8).to(dev)), N.ptr(y), N.stream_ptr()), "fwd")
+        ref = R.actor_logits(p, x, avail)
+        assert _err(y.cpu().numpy(), ref.numpy()) <= TOL
+
+
+def test_unsupported_shapes_fail_loudly():
+    from cleanmarl_amd import _native as N
+    lib = N.load()
+    rc = lib.cm_mlp_forward(None, 10, 8, 4096, 1, 1, None, None, None, N.stream_ptr())
+    assert rc != 0 and b"hidden_dim" in lib.cm_last_error()
