@@ -169,6 +169,7 @@ class PPOLearner:
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
+        self.events = None  # bench.py sets this to a list to collect per-launch (kind, start, end) HIP events
 
     # ------------------------------------------------------------------ helpers
     def _allreduce(self, t):
@@ -223,6 +224,15 @@ class PPOLearner:
                                                 opt.lr, 0.9, 0.999, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
                                                 grad_scale, N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
 
+    def _timed(self, kind, fn, *a):
+        if self.events is None:
+            return fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*a)
+        e1.record()
+        self.events.append((kind, e0, e1))
+
     def critic_pass(self, b, s):
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
@@ -247,8 +257,8 @@ class PPOLearner:
         rec = torch.zeros(int(hp.epochs), 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
         kept = []
         for ep in range(int(hp.epochs)):
-            self.actor_pass(b, s)
-            self.critic_pass(b, s)
+            self._timed("actor", self.actor_pass, b, s)
+            self._timed("critic", self.critic_pass, b, s)
             self._allreduce(self.gbuf)  # the only data-path collective: grads + N + stat sums
             self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
             self._adam(self.critic, self.g_critic, self.opt_c, 1, s)

@@ -1,0 +1,51 @@
+"""Device-resident rollout: on-device synthetic env + fused act kernel write straight into the
+[E,A,T,F] rollout buffer (replaces cleanmarl/mappo_multienvs.py:393-453 + RolloutBuffer :82-157 for the
+synthetic configs: no pipes, no per-step host round trip, no collate copy)."""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from .learner import DeviceBatch
+
+_GOLD = 0x9E3779B97F4A7C15
+
+
+def _off(t, nbytes):
+    return C.c_void_p(t.data_ptr() + nbytes)
+
+
+class SyntheticSpreadRollout:
+    """E synthetic MPE-like envs (csrc/cm_env.hip), all truncated at exactly T steps."""
+
+    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0):
+        self.lib = N.load()
+        self.E, self.A, self.T, self.K = E, A, T, 5
+        self.agent_ids = bool(agent_ids)
+        self.Do = 6 * A + (A if agent_ids else 0)
+        self.Ds = 6 * A * A
+        self.seed, self.env_offset = int(seed), int(env_offset)
+        self.device = torch.device(device)
+        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
+        self.batch.avail.fill_(1)
+        self.batch.ep_len.fill_(T)
+        self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
+        self.episode = 0
+
+    def collect(self, actor_flat, actor_spec):
+        """One episode per env (reference outer loop body, :393-453).  Everything is enqueued on the
+        current stream; returns the filled DeviceBatch without synchronising."""
+        lib, b, s = self.lib, self.batch, N.stream_ptr()
+        E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,
+                                       self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
+        act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+        for t in range(T):
+            N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
+                                      actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat),
+                                      act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
+                    "cm_policy_act")
+            N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,
+                                          N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
+        self.episode += 1
+        return b

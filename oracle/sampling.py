@@ -1,0 +1,31 @@
+"""CPU twin of the on-device action sampler (csrc/cm_mlp.hip, mode M_ACT) -- TEST INFRASTRUCTURE.
+Restates Actor.act (cleanmarl/mappo_multienvs.py:172-176) with the build's counter-based RNG:
+inverse-CDF on softmax(logits) with one Philox4x32-10 uniform keyed by (seed, global row, t)."""
+import numpy as np
+
+from cleanmarl_amd.env.philox import STREAM_ACT, philox4x32, split_seed, u01
+
+
+def act(logits, avail, seed, row_offset, t):
+    """logits [R,K] float32 (already masked with -1e9), avail [R,K] bool -> (action[R], logp[R], u[R])"""
+    logits = np.asarray(logits, dtype=np.float32)
+    R, K = logits.shape
+    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row_offset))
+    k0, k1 = split_seed(seed)
+    x, _, _, _ = philox4x32((rows & np.uint64(0xFFFFFFFF)).astype(np.uint32), (rows >> np.uint64(32)).astype(np.uint32),
+                            np.uint32(t), np.uint32(STREAM_ACT), k0, k1)
+    u = u01(x)
+    m = logits.max(1, keepdims=True)
+    lse = m + np.log(np.exp(logits - m).sum(1, keepdims=True, dtype=np.float32))
+    p = np.exp(logits - lse).astype(np.float32)
+    action = np.zeros(R, np.int64)
+    for r in range(R):
+        cum, chosen, last = np.float32(0), -1, 0
+        for k in range(K):
+            if logits[r, k] > -5e8:
+                cum = np.float32(cum + p[r, k]); last = k
+                if chosen < 0 and u[r] < cum:
+                    chosen = k
+        action[r] = chosen if chosen >= 0 else last
+    logp = (logits - lse)[np.arange(R), action]
+    return action, logp.astype(np.float32), u

@@ -139,7 +139,8 @@ def test_scan_long_sequences_and_edge_lengths():
         if E > 2:
             lens[2] = 1
         ret = torch.empty(E, A, T, device=dev); adv = torch.empty(E, A, T, device=dev)
-        N.check(lib.cm_td_lambda_scan(N.ptr(reward.to(dev)), N.ptr(values.to(dev)), N.ptr(lens.int().to(dev)), E, A, Av, T,
+        d_r, d_v, d_l = reward.to(dev), values.to(dev), lens.int().to(dev)  # keep alive: raw pointers cross the ABI
+        N.check(lib.cm_td_lambda_scan(N.ptr(d_r), N.ptr(d_v), N.ptr(d_l), E, A, Av, T,
                                       0.99, 0.95, N.ptr(ret), N.ptr(adv), N.stream_ptr()), "scan")
         mask = torch.arange(T)[None, :] < lens[:, None]
         v_ref = values.permute(0, 2, 1).expand(E, T, A)
@@ -161,8 +162,8 @@ def test_mlp_forward_matches_oracle():
         x = torch.randn(rows, din)
         avail = torch.rand(rows, dout) < 0.6
         y = torch.empty(rows, dout, device=dev)
-        N.check(lib.cm_mlp_forward(N.ptr(x.to(dev)), rows, din, H, L, dout, N.ptr(flatten_params(p, dev)),
-                                   N.ptr(avail.to(torch.uint8).to(dev)), N.ptr(y), N.stream_ptr()), "fwd")
+        d_x, d_p, d_a = x.to(dev), flatten_params(p, dev), avail.to(torch.uint8).to(dev)
+        N.check(lib.cm_mlp_forward(N.ptr(d_x), rows, din, H, L, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.stream_ptr()), "fwd")
         ref = R.actor_logits(p, x, avail)
         assert _err(y.cpu().numpy(), ref.numpy()) <= TOL
 
@@ -172,3 +173,66 @@ def test_unsupported_shapes_fail_loudly():
     lib = N.load()
     rc = lib.cm_mlp_forward(None, 10, 8, 4096, 1, 1, None, None, None, N.stream_ptr())
     assert rc != 0 and b"hidden_dim" in lib.cm_last_error()
+
+
+def test_env_kernels_match_numpy_twin():
+    """cm_synth_env_reset / cm_synth_env_step vs cleanmarl_amd/env/synthetic.py on identical seeds + actions."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.env.synthetic import SyntheticSpreadEnv
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    for (E, A, T, ids, off) in [(5, 3, 6, 1, 0), (70, 8, 4, 1, 1000), (3, 2, 5, 0, 7)]:
+        Do, Ds = 6 * A + ids * A, 6 * A * A
+        g = torch.Generator().manual_seed(E)
+        action = torch.randint(0, 5, (E, A, T), generator=g, dtype=torch.int32).to(dev)
+        es = torch.zeros(E, 6 * A, device=dev)
+        obs = torch.zeros(E, A, T, Do, device=dev); state = torch.zeros(E, T, Ds, device=dev); rew = torch.zeros(E, T, device=dev)
+        s = N.stream_ptr()
+        N.check(lib.cm_synth_env_reset(N.ptr(es), E, A, ids, 42, off, 3, N.ptr(obs), N.ptr(state), T, s), "reset")
+        for t in range(T):
+            N.check(lib.cm_synth_env_step(N.ptr(es), N.ptr(action), E, A, ids, t, T, N.ptr(rew), N.ptr(obs), N.ptr(state), s), "step")
+        obs_c, state_c, rew_c, act_c = obs.cpu().numpy(), state.cpu().numpy(), rew.cpu().numpy(), action.cpu().numpy()
+        for e in range(E):
+            env = SyntheticSpreadEnv(A, bool(ids), max_cycles=T, seed=42, env_index=off + e)
+            env.episode = 2  # next reset() is episode 3
+            o, _ = env.reset()
+            for t in range(T):
+                assert np.abs(obs_c[e, :, t] - o).max() <= 1e-5
+                assert np.abs(state_c[e, t] - env.get_state()).max() <= 1e-5
+                o, r, done, trunc, _ = env.step(act_c[e, :, t])
+                assert abs(rew_c[e, t] - r) <= 1e-4
+            assert trunc and not done
+
+
+def test_policy_act_matches_cpu_sampler():
+    """cm_policy_act (strided, in-place rollout-buffer addressing) vs oracle/sampling.py."""
+    import ctypes as C
+    from oracle import restatement as R
+    from oracle import sampling
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    E, A, T, Do, K, t = 33, 5, 7, 40, 9, 3
+    spec = NetSpec(Do, 64, 1, K)
+    p = init_params_like_torch(spec)
+    obs = torch.randn(E, A, T, Do)
+    avail = torch.rand(E, A, T, K) < 0.5
+    avail[..., 2] = True
+    d_obs, d_av, d_p = obs.to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
+    action = torch.full((E, A, T), -7, dtype=torch.int32, device=dev)
+    logp = torch.full((E, A, T), 9.0, device=dev)
+    N.check(lib.cm_policy_act(C.c_void_p(d_obs.data_ptr() + 4 * t * Do), T * Do, C.c_void_p(d_av.data_ptr() + t * K), T * K,
+                              E * A, Do, 64, 1, K, N.ptr(d_p), 99, 1234, t,
+                              C.c_void_p(action.data_ptr() + 4 * t), C.c_void_p(logp.data_ptr() + 4 * t), T, N.stream_ptr()), "act")
+    logits = R.actor_logits(p, obs[:, :, t].reshape(E * A, Do), avail[:, :, t].reshape(E * A, K)).numpy()
+    a_ref, lp_ref, u = sampling.act(logits, avail[:, :, t].reshape(E * A, K).numpy(), 99, 1234, t)
+    a_gpu = action[:, :, t].reshape(-1).cpu().numpy()
+    lp_gpu = logp[:, :, t].reshape(-1).cpu().numpy()
+    same = a_gpu == a_ref
+    assert same.mean() >= 0.99  # a uniform within fp32 round-off of a CDF edge may flip a neighbour
+    assert np.abs(lp_gpu[same] - lp_ref[same]).max() <= TOL
+    assert avail[:, :, t].reshape(E * A, K).numpy()[np.arange(E * A), a_gpu].all()  # never an unavailable action
+    untouched = torch.ones(T, dtype=torch.bool); untouched[t] = False
+    assert (action[:, :, untouched] == -7).all() and (logp[:, :, untouched] == 9.0).all()
