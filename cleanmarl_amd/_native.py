@@ -62,6 +62,9 @@ def load():
         raise NativeError(
             f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
             "or python cleanmarl_amd/build.py).  cleanmarl_amd has no CPU fallback by design.")
+    # torch wheels bundle their own libamdhip64: import torch FIRST so that our library binds to the same HIP
+    # runtime instance that owns torch's streams and allocations (two runtimes in one process = "no device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
