@@ -1,0 +1,32 @@
+// cm_mlp_infer.hip -- C-ABI entry points of the forward-only MLP kernels (a3/a4/a5)
+#include "cm_mlp_kernel.h"
+
+extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                              const float* params, const uint8_t* avail, float* y, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_mlp_forward", din, hidden, n_hidden_layers, dout)) return rc;
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
+    a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
+    CM_CHECK_LAUNCH("cm_mlp_forward");
+    return 0;
+}
+
+extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                             int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
+                             const float* params, uint64_t seed, int64_t row_offset, int t,
+                             int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_policy_act", din, hidden, n_hidden_layers, n_actions)) return rc;
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = x_row_stride; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = params; a.avail = avail; a.avail_stride = avail_row_stride;
+    a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
+    CM_CHECK_LAUNCH("cm_policy_act");
+    return 0;
+}
+

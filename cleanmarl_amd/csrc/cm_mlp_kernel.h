@@ -1,0 +1,853 @@
+// cm_mlp_kernel.h -- fused actor / critic MLP kernel template for gfx950 (fp32 MFMA, weights LDS-stationary).
+//
+// One kernel template covers the four program regions of cleanmarl/mappo_multienvs.py that run an MLP:
+//   M_FWD    Actor.logits / Critic.forward         (:178-183, :197-200)   -> cm_mlp_forward
+//   M_ACT    Actor.act (sample + log_prob)         (:172-176, :409-414)   -> cm_policy_act
+//   M_ACTOR  PPO clipped-surrogate fwd + bwd       (:527-551, :561-582)   -> cm_ppo_actor_fwd_bwd
+//   M_CRITIC value MSE fwd + bwd                   (:554-558, :582)       -> cm_critic_fwd_bwd
+//
+// Design: a workgroup = 4 wavefronts (2 along rows x 2 along hidden columns) owns a tile of
+// TM = 64 rows and walks the whole network for that tile with every activation resident in LDS; rows
+// never round-trip to HBM between layers or between forward and backward.  All GEMMs run on
+// v_mfma_f32_32x32x2_f32 (exact fp32, == an fmaf chain), so results stay within fp32 round-off of the
+// reference's CPU PyTorch run.  Three MFMA forms are used, each wave owning one 32x32 output tile:
+//   rowpar_nt : Y[64 x 64]  = A[64 x K] * W[64 x K]^T        (forward layers)
+//   rowpar_tn : dX[64 x 64] = dZ[64 x 64] * W[64 x 64]       (backward data path)
+//   colred    : dW[64 x 64] += dZ[64 rows x 64]^T * X[64 rows x 64]  (weight gradients; the accumulators
+//               stay in registers across ALL row tiles of the persistent workgroup and are written once)
+// The tiny head (K <= 32 outputs) and all softmax / PPO / MSE math run on the VALU out of LDS.
+// Hidden widths H <= 64 are zero-padded to 64 in LDS (dead units have zero activations and zero
+// gradients), the input width is processed in chunks of 64 columns.
+#pragma once
+#include "cm_common.h"
+
+namespace {
+
+constexpr int HP = 64;    // padded hidden width
+constexpr int TM = 64;    // rows per tile
+constexpr int KC = 64;    // input chunk width
+constexpr int LDT = 68;   // LDS row stride in floats (4*17: conflict-free ds_read_b128 down a column of rows)
+constexpr int LMAX = 2;   // max hidden->hidden layers (kernels are compiled for LCAP = 1 or 2)
+constexpr int KMAX = 32;  // max head width
+constexpr int LSP = 36;   // row stride of the per-row head scratch (logits / dlogits), >= KMAX, zero padded
+constexpr int KJMAX = KMAX / 4;  // head outputs owned per lane (4 lanes per row); kernels compiled for KJ = 2 or 8
+constexpr int NTHREADS = 256;
+#ifndef CM_MLP_WAVES_PER_SIMD
+#define CM_MLP_WAVES_PER_SIMD 1
+#endif
+
+enum Mode { M_FWD = 0, M_ACT = 1, M_ACTOR = 2, M_CRITIC = 3 };
+
+struct MlpArgs {
+    const float* x; long x_stride; long rows;
+    int din, H, L, dout;
+    const float* params;
+    // M_FWD
+    const uint8_t* avail; long avail_stride; float* y;
+    // M_ACT
+    unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+    // training
+    const int* action; const float* logp_old; const float* adv; const float* ret; const int* ep_len;
+    int A, T, per_agent;
+    float clip_lo, clip_hi, clip_eps, ent_coef;
+    float* partial; int PS;  // per-workgroup partial gradients + stats, row stride PS floats
+    unsigned long long* prof;  // CM_PHASE_PROF builds only: [grid][16] cycle counters
+};
+
+struct Offsets {
+    int W0, b0, Wl0, lstep, Wout, bout, P;
+    __host__ __device__ int Wl(int l) const { return Wl0 + l * lstep; }            // hidden layer l (0-based) weight
+    __host__ __device__ int bl(int l) const { return Wl0 + l * lstep + lstep - hdim; }  // and bias
+    int hdim;
+};
+__host__ __device__ inline Offsets make_offsets(int din, int H, int L, int dout) {
+    Offsets o;
+    o.hdim = H;
+    o.W0 = 0; o.b0 = H * din;
+    o.Wl0 = o.b0 + H; o.lstep = H * H + H;
+    o.Wout = o.Wl0 + L * o.lstep; o.bout = o.Wout + dout * H; o.P = o.bout + dout;
+    return o;
+}
+
+// LDS carve (floats)
+struct Lds {
+    int Xs, W0s, Hs0, Ws, wout, b0, bl0, bout, ls, red, total;
+    __host__ __device__ int Hs(int l) const { return Hs0 + l * TM * LDT; }
+    __host__ __device__ int bl(int l) const { return bl0 + l * HP; }
+};
+__host__ __device__ inline Lds make_lds(int L, int dout) {
+    Lds s; int p = 0;
+    s.Xs = p; p += TM * LDT;
+    s.W0s = p; p += HP * LDT;
+    s.Hs0 = p; p += (L + 1) * TM * LDT;
+    s.Ws = p; if (L > 0) p += HP * LDT;
+    s.wout = p; p += ((dout + 3) & ~3) * HP;  // rows >= dout are zero
+    s.b0 = p; p += HP;
+    s.bl0 = p; p += L * HP;
+    s.bout = p; p += KMAX;
+    s.ls = p; p += TM * LSP;
+    p = (p + 3) & ~3;
+    s.red = p; p += 4 * HP;
+    s.total = p;
+    return s;
+}
+
+// 4-lane (quad) butterflies on the VALU via DPP quad_perm -- no LDS round trip like ds_bpermute
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) { v += quad_xor1(v); v += quad_xor2(v); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, quad_xor1(v)); v = fmaxf(v, quad_xor2(v)); return v; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// All three MFMA loops are software-pipelined by hand: the LDS operands of batch i+1 are requested before the
+// MFMAs of batch i issue, so the ~100-cycle ds_read latency hides under the 4 x 64-cycle MFMA batch instead of
+// stalling the matrix pipe once per loop iteration.
+//
+// acc[32x32] += A[32 rows][8*kb] * B[32 rows(n)][8*kb]^T ; A,B row-major in LDS with stride LDT.
+// k is consumed in the permuted order {8j+i, 8j+4+i}: lane half h reads floats [8j+4h, 8j+4h+4) as one b128.
+__device__ __forceinline__ void rowpar_nt(f32x16& acc, const float* As, const float* Bs, int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float4* ap = reinterpret_cast<const float4*>(As + r * LDT + 4 * h);
+    const float4* bp = reinterpret_cast<const float4*>(Bs + r * LDT + 4 * h);
+    float4 a = ap[0], b = bp[0];
+    for (int j = 0; j < kb; ++j) {
+        float4 an = a, bn = b;
+        if (j + 1 < kb) { an = ap[2 * (j + 1)]; bn = bp[2 * (j + 1)]; }
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+        a = an; b = bn;
+    }
+}
+
+// acc[32x32] += dZ[32 rows][64 (n)] * W[64 (n)][32 cols]  (W row-major [n][k] in LDS, read transposed)
+__device__ __forceinline__ void rowpar_tn(f32x16& acc, const float* As, const float* Ws_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float4* ap = reinterpret_cast<const float4*>(As + r * LDT + 4 * h);
+    const float* bp = Ws_c0 + (4 * h) * LDT + r;
+    float4 a = ap[0];
+    float b0 = bp[0], b1 = bp[LDT], b2 = bp[2 * LDT], b3 = bp[3 * LDT];
+#pragma unroll
+    for (int j = 0; j < HP / 8; ++j) {
+        float4 an = a;
+        float n0 = b0, n1 = b1, n2 = b2, n3 = b3;
+        if (j + 1 < HP / 8) {
+            an = ap[2 * (j + 1)];
+            n0 = bp[(8 * (j + 1) + 0) * LDT]; n1 = bp[(8 * (j + 1) + 1) * LDT];
+            n2 = bp[(8 * (j + 1) + 2) * LDT]; n3 = bp[(8 * (j + 1) + 3) * LDT];
+        }
+        acc = mfma32(a.x, b0, acc);
+        acc = mfma32(a.y, b1, acc);
+        acc = mfma32(a.z, b2, acc);
+        acc = mfma32(a.w, b3, acc);
+        a = an; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+    }
+}
+
+// acc[32 (n) x 32 (k)] += sum_rows dZ[row][n0 + i] * X[row][k0 + j]   over the TM rows of the tile
+__device__ __forceinline__ void colred(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = Zs_n0 + h * LDT + r;
+    const float* bp = Xs_k0 + h * LDT + r;
+    float a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = ap[2 * i * LDT]; b[i] = bp[2 * i * LDT]; }
+#pragma unroll
+    for (int kk = 0; kk < TM / 2; kk += 4) {
+        float an[4], bn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            an[i] = a[i]; bn[i] = b[i];
+            if (kk + 4 < TM / 2) { an[i] = ap[2 * (kk + 4 + i) * LDT]; bn[i] = bp[2 * (kk + 4 + i) * LDT]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = mfma32(a[i], b[i], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+    }
+}
+
+// acc[32 (k) x 32 (c)] += sum over 32 rows of dlogits[row][k] * H[row][c0 + c]   (head weight gradient)
+__device__ __forceinline__ void colred_head(f32x16& acc, const float* ls_r0, const float* Hs_r0_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = ls_r0 + h * LSP + r;
+    const float* bp = Hs_r0_c0 + h * LDT + r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = mfma32(ap[2 * kk * LSP], bp[2 * kk * LDT], acc);
+}
+
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long row0, long nrows, long stride,
+                                           int col0, int ncols) {
+    // dst[r][k] = src[(row0+r)*stride + col0 + k]  for r < TM, k < KC; zero outside [nrows) x [ncols)
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TM * KC; i += NTHREADS) {
+        const int r = i >> 6, k = i & 63;
+        const long row = row0 + r;
+        float v = 0.0f;
+        if (row < nrows && k < ncols) v = src[row * stride + col0 + k];
+        dst[r * LDT + k] = v;
+    }
+}
+
+// ---- register-staged tile prefetch (T14 "issue early / write late"): a 64x64 fp32 tile = 16 floats per thread.
+// The loads are issued one phase (or one whole tile) ahead of the ds_write that consumes them, so HBM latency
+// hides under the MFMA phases in between; plain global loads stay in flight across s_barrier.
+struct Tile16 { float4 v[4]; };
+
+template <bool VEC>
+__device__ __forceinline__ void tile_load(Tile16& t, const float* src, long row0, long nrows, long stride, int col0, int ncols) {
+    if (VEC) {  // 16-byte loads: rows 16-byte aligned, ncols % 4 == 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + NTHREADS * i;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            const long row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nrows && c4 < ncols) v = *reinterpret_cast<const float4*>(src + row * stride + col0 + c4);
+            t.v[i] = v;
+        }
+    } else {
+        float* f = reinterpret_cast<float*>(t.v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = threadIdx.x + NTHREADS * i;
+            const int r = idx >> 6, k = idx & 63;
+            const long row = row0 + r;
+            float v = 0.0f;
+            if (row < nrows && k < ncols) v = src[row * stride + col0 + k];
+            f[i] = v;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + NTHREADS * i;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<float4*>(dst + r * LDT + c4) = t.v[i];
+        }
+    } else {
+        const float* f = reinterpret_cast<const float*>(t.v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = threadIdx.x + NTHREADS * i;
+            dst[(idx >> 6) * LDT + (idx & 63)] = f[i];
+        }
+    }
+}
+
+#ifdef CM_PHASE_PROF
+#define PH_DECL unsigned long long ph_[16] = {0}; unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
+#define PH(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[i] += t_ - ph_t0; ph_t0 = t_; } while (0)
+#define PH_FLUSH do { if (a.prof && threadIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH
+#endif
+
+// per-row inputs of the loss heads, fetched at the top of a tile so their HBM latency hides under the MFMA phases
+template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
+
+template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
+__global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool TRAIN = (MODE == M_ACTOR || MODE == M_CRITIC);
+    constexpr int NC = (NCH > 0 ? NCH : 1);
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
+    const Lds lds = make_lds(a.L, a.dout);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int H = a.H, L = a.L, dout = a.dout, din = a.din;
+    const int nch = (din + KC - 1) / KC;
+    const bool w0_resident = (nch == 1);
+    const bool ws_resident = (L == 1);
+    float* Xs = smem + lds.Xs;
+    float* W0s = smem + lds.W0s;
+    float* Ws = smem + lds.Ws;
+    float* wouts = smem + lds.wout;
+    float* ls = smem + lds.ls;
+    float* red = smem + lds.red;
+    constexpr int lstride = LSP;
+
+    // ---- one-time staging of small tensors (+ resident weights)
+    for (int i = tid; i < ((dout + 3) & ~3) * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        wouts[i] = (c < H && k < dout) ? a.params[off.Wout + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) {
+        smem[lds.b0 + i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
+        for (int l = 0; l < LCAP; ++l)
+            if (l < L) smem[lds.bl(l) + i] = (i < H) ? a.params[off.bl(l) + i] : 0.0f;
+    }
+    for (int i = tid; i < KMAX; i += NTHREADS) smem[lds.bout + i] = (i < dout) ? a.params[off.bout + i] : 0.0f;
+    for (int i = tid; i < TM * LSP; i += NTHREADS) ls[i] = 0.0f;  // columns >= dout stay zero (MFMA operand padding)
+    if (w0_resident) stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
+    if (ws_resident) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+
+    // ---- persistent accumulators (training)
+    f32x16 accW0[NC];
+    f32x16 accWl[LCAP];
+    f32x16 accWo;  // dWout[k (32) x 32 hidden cols], rows of the tile split over the two wave-rows
+    float dbo = 0.0f;
+    float dbh[LCAP + 1];
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_vl = 0.f, st_cnt = 0.f;
+    if (TRAIN) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) accW0[c][g] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < LCAP; ++l)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) accWl[l][g] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) accWo[g] = 0.0f;
+#pragma unroll
+        for (int l = 0; l <= LCAP; ++l) dbh[l] = 0.0f;
+    }
+
+    const long ntiles = (a.rows + TM - 1) / TM;
+    PH_DECL
+    const int hrow = tid >> 2, hq = tid & 3;  // head mapping: 4 lanes per row, 16 hidden columns per lane
+    const int Aseq = (MODE == M_CRITIC && !a.per_agent) ? 1 : a.A;
+
+    // ---- software pipeline prologue: first X chunk (and W0 chunk when it is streamed) of the first tile
+    Tile16 px, pw;
+    if ((long)blockIdx.x < ntiles) {
+        tile_load<VEC>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
+        if (!w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
+    }
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * TM;
+        const long next_row0 = (tile + gridDim.x) * TM;  // >= rows when this is the last tile: loads predicate off
+        // ================= forward, layer 0 (input chunks) =================
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+        RowIn<KJ> ri;
+        ri.act = 0; ri.lpo = 0.f; ri.adv = 0.f; ri.ret = 0.f; ri.eplen = 0; ri.ag = 0; ri.e = 0; ri.t = 0;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) ri.avb[j] = 1;
+        const int grow = (int)row0 + hrow;  // this lane-group's global row (host guarantees rows < 2^31)
+        const bool rvalid = grow < (int)a.rows;
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();  // previous readers of Xs / W0s are done
+            tile_store<VEC>(Xs, px);
+            if (!w0_resident) tile_store<VEC>(W0s, pw);
+            // issue the next chunk's loads now; they land while the MFMAs below (and, for the last chunk,
+            // the whole rest of the tile) execute
+            {
+                const bool last = (c + 1 == nch);
+                const int cn = last ? 0 : c + 1;
+                const long r0n = last ? ((TRAIN && NCH > 1) ? row0 : next_row0) : row0;
+                const int wn_ = min(KC, din - cn * KC);
+                tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
+                if (!w0_resident && !(last && TRAIN && NCH > 1)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
+            }
+            if (c == 0) {
+                // per-row head inputs: issued here, consumed (raw) only in the head phases after the MFMA layers
+                const bool use_avail = (MODE == M_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr);
+                if (rvalid && use_avail) {
+                    const uint8_t* ap = a.avail + (long)grow * a.avail_stride;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j)
+                        if (4 * j + hq < dout) ri.avb[j] = ap[4 * j + hq];
+                }
+                if (TRAIN && rvalid) {
+                    const int seq = grow / a.T;
+                    ri.t = grow - seq * a.T;
+                    ri.e = seq / Aseq;
+                    ri.ag = seq - ri.e * Aseq;
+                    ri.eplen = a.ep_len[ri.e];
+                    if (MODE == M_ACTOR) { ri.act = a.action[grow]; ri.lpo = a.logp_old[grow]; ri.adv = a.adv[grow]; }
+                    else if (a.per_agent) ri.ret = a.ret[grow];
+                }
+            }
+            __syncthreads();
+            PH(0);
+            const int w = min(KC, din - c * KC);
+            rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
+        }
+        {
+            float* H0 = smem + lds.Hs(0);
+            const float bias = smem[lds.b0 + 32 * wn + lc];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                H0[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+            }
+        }
+        __syncthreads();
+        PH(1);
+        // ================= forward, hidden layers =================
+#pragma unroll
+        for (int l = 1; l <= LCAP; ++l) {
+            if (l <= L) {
+                if (!ws_resident) {
+                    stage_rows(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+                rowpar_nt(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                float* Hl = smem + lds.Hs(l);
+                const float bias = smem[lds.bl(l - 1) + 32 * wn + lc];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    Hl[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                }
+                __syncthreads();
+            }
+        }
+        PH(2);
+        // ================= head forward (VALU) =================
+        float* HL = smem + lds.Hs(L);
+        float hreg[16];
+        {
+            const float4* hp4 = reinterpret_cast<const float4*>(HL + hrow * LDT + 16 * hq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = hp4[i];
+                hreg[4 * i] = v.x; hreg[4 * i + 1] = v.y; hreg[4 * i + 2] = v.z; hreg[4 * i + 3] = v.w;
+            }
+        }
+        float zreg[KJ];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            zreg[j] = -1e9f;
+            if (4 * j < dout) {  // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 4 * j + q;
+                    if (k < dout) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + k * HP + 16 * hq);
+                        float p = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 w4 = wp4[i];
+                            p = fmaf(hreg[4 * i], w4.x, p); p = fmaf(hreg[4 * i + 1], w4.y, p);
+                            p = fmaf(hreg[4 * i + 2], w4.z, p); p = fmaf(hreg[4 * i + 3], w4.w, p);
+                        }
+                        p = quad_sum(p);
+                        if (hq == q) zreg[j] = ri.avb[j] ? p + smem[lds.bout + k] : -1e9f;  // masked_fill(~avail, -1e9)
+                    }
+                }
+            }
+        }
+        if (MODE == M_FWD) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j)
+                if (rvalid && 4 * j + hq < dout) a.y[(long)grow * dout + 4 * j + hq] = zreg[j];
+        }
+        if (MODE == M_ACT) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j)
+                if (4 * j + hq < dout) ls[hrow * lstride + 4 * j + hq] = zreg[j];
+        }
+        if (MODE == M_FWD) continue;  // next tile (the loop-top barrier protects LDS reuse)
+        if (MODE == M_ACT) __syncthreads();
+        PH(3);
+
+        // ================= per-row head math: lane hq == 0 of every row =================
+        if (MODE == M_ACT) {
+            if (hq == 0 && rvalid) {
+                float* z = ls + hrow * lstride;
+                float m = -INFINITY;
+                for (int k = 0; k < dout; ++k) m = fmaxf(m, z[k]);
+                float s = 0.0f;
+                for (int k = 0; k < dout; ++k) s += expf(z[k] - m);
+                const float lse = m + logf(s);
+                const unsigned long long gr = (unsigned long long)(a.row_offset + grow);
+                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)a.t, CM_STREAM_ACT,
+                                                (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                const float u = cm_u01(rnd.x);
+                float cum = 0.0f;
+                int chosen = -1, last = 0;
+                for (int k = 0; k < dout; ++k) {
+                    if (z[k] > -5e8f) {
+                        cum += expf(z[k] - lse);
+                        last = k;
+                        if (chosen < 0 && u < cum) chosen = k;
+                    }
+                }
+                if (chosen < 0) chosen = last;
+                a.action_out[(long)grow * a.out_stride] = chosen;
+                a.logp_out[(long)grow * a.out_stride] = z[chosen] - lse;
+            }
+            continue;
+        }
+
+        if (TRAIN) {
+            const bool valid = rvalid && (ri.t < ri.eplen);
+            const float invA = 1.0f / (float)a.A;
+            if (MODE == M_ACTOR) {
+                // Categorical(logits) statistics with the row's K logits spread over its 4 lanes (k = 4j + hq)
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < dout) m = fmaxf(m, zreg[j]);
+                m = quad_max(m);
+                float s = 0.0f;
+                float pj[KJ];
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    pj[j] = 0.0f;
+                    if (4 * j + hq < dout) { pj[j] = expf(zreg[j] - m); s += pj[j]; }
+                }
+                s = quad_sum(s);
+                const float lse = m + logf(s);
+                const float rs = 1.0f / s;
+                float ent = 0.0f, lpa = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    if (4 * j + hq < dout) {
+                        const float lp = zreg[j] - lse;
+                        const float p = pj[j] * rs;  // softmax probability (exp(z - m) / sum)
+                        pj[j] = p;
+                        ent -= p * lp;
+                        if (4 * j + hq == ri.act) lpa = lp;
+                    }
+                }
+                ent = quad_sum(ent);
+                lpa = quad_sum(lpa);
+                const float log_ratio = lpa - ri.lpo;
+                const float ratio = expf(log_ratio);
+                const float advv = ri.adv;
+                const float pg1 = advv * ratio;
+                const float pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                // d min(pg1,pg2)/d ratio with torch's tie rule (grad/2 to each operand)
+                float g;
+                if (pg1 < pg2) g = advv;
+                else if (pg1 > pg2) g = inr ? advv : 0.0f;
+                else g = 0.5f * advv + (inr ? 0.5f * advv : 0.0f);
+                if (valid && hq == 0) {
+                    st_pg += invA * fminf(pg1, pg2);
+                    st_ent += invA * ent;
+                    st_kl += invA * ((ratio - 1.0f) - log_ratio);
+                    st_clip += (fabsf(ratio - 1.0f) > a.clip_eps) ? invA : 0.0f;
+                    if (ri.ag == 0) st_cnt += 1.0f;
+                }
+                const float gr = g * ratio;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int k = 4 * j + hq;
+                    if (k < dout) {
+                        const float lp = zreg[j] - lse;
+                        float d = invA * (-gr * ((k == ri.act ? 1.0f : 0.0f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
+                        if (!valid || zreg[j] <= -5e8f) d = 0.0f;  // padded rows; masked_fill blocks the gradient
+                        ls[hrow * lstride + k] = d;
+                    }
+                }
+            } else if (hq == 0) {  // M_CRITIC: one output per row, owned by lane hq == 0
+                float d = 0.0f;
+                if (valid) {
+                    const float v = zreg[0];
+                    if (a.per_agent) {
+                        const float df = v - ri.ret;
+                        st_vl += invA * df * df;
+                        d = 2.0f * invA * df;
+                        if (ri.ag == 0) st_cnt += 1.0f;
+                    } else {
+                        float sd = 0.0f, sq = 0.0f;
+                        for (int q = 0; q < a.A; ++q) {
+                            const float df = v - a.ret[((long)ri.e * a.A + q) * a.T + ri.t];
+                            sd += df; sq += df * df;
+                        }
+                        st_vl += invA * sq;
+                        d = 2.0f * invA * sd;
+                        st_cnt += 1.0f;
+                    }
+                }
+                ls[hrow * lstride] = d;
+            }
+            __syncthreads();
+            PH(4);
+            // ---- dWout, dbout (contraction over the tile's rows; reads HL before it is overwritten)
+            // wave (wm, wn): rows 32wm..32wm+31 of the tile, hidden columns 32wn..32wn+31, all 32 (padded) head rows
+            colred_head(accWo, ls + 32 * wm * LSP, HL + 32 * wm * LDT + 32 * wn);
+            {
+                const int k = tid & 31, part = tid >> 5;
+                float sb = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) sb += ls[(part * 8 + r) * LSP + k];
+                dbo += sb;
+            }
+            __syncthreads();
+            PH(5);
+            // ---- dZ_L = (dlogits * Wout) .* relu'(H_L), in place (each lane owns its 16 columns)
+            {
+                float dz[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dz[i] = 0.0f;
+                for (int k0 = 0; k0 < dout; k0 += 4) {  // ls columns and wouts rows beyond dout are zero
+                    const float4 d4 = *reinterpret_cast<const float4*>(ls + hrow * lstride + k0);
+                    const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + (k0 + q) * HP + 16 * hq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 w4 = wp4[i];
+                            dz[4 * i] = fmaf(dk[q], w4.x, dz[4 * i]); dz[4 * i + 1] = fmaf(dk[q], w4.y, dz[4 * i + 1]);
+                            dz[4 * i + 2] = fmaf(dk[q], w4.z, dz[4 * i + 2]); dz[4 * i + 3] = fmaf(dk[q], w4.w, dz[4 * i + 3]);
+                        }
+                    }
+                }
+                float4* hp4 = reinterpret_cast<float4*>(HL + hrow * LDT + 16 * hq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 v;
+                    v.x = hreg[4 * i] > 0.0f ? dz[4 * i] : 0.0f;
+                    v.y = hreg[4 * i + 1] > 0.0f ? dz[4 * i + 1] : 0.0f;
+                    v.z = hreg[4 * i + 2] > 0.0f ? dz[4 * i + 2] : 0.0f;
+                    v.w = hreg[4 * i + 3] > 0.0f ? dz[4 * i + 3] : 0.0f;
+                    hp4[i] = v;
+                }
+            }
+            __syncthreads();
+            PH(6);
+            // ================= backward through hidden layers =================
+#pragma unroll
+            for (int l = LCAP; l >= 1; --l) {
+                if (l <= L) {
+                    float* Zl = smem + lds.Hs(l);       // holds dZ_l
+                    float* Hm = smem + lds.Hs(l - 1);   // holds H_{l-1}
+                    if (!ws_resident) {
+                        stage_rows(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
+                        __syncthreads();
+                    }
+                    {   // bias gradient: column sums
+                        const int c = tid & 63, part = tid >> 6;
+                        float s = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < TM / 4; ++r) s += Zl[(part * (TM / 4) + r) * LDT + c];
+                        dbh[l] += s;
+                    }
+                    colred(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+                    rowpar_tn(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
+                    __syncthreads();
+                    PH(7);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                        float* p = Hm + row * LDT + 32 * wn + lc;
+                        *p = (*p > 0.0f) ? acc[g] : 0.0f;
+                    }
+                    __syncthreads();
+                    PH(8);
+                }
+            }
+            // ================= layer 0 backward: bias + dW0 chunks =================
+            {
+                float* Z0 = smem + lds.Hs(0);
+                {
+                    const int c = tid & 63, part = tid >> 6;
+                    float s = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < TM / 4; ++r) s += Z0[(part * (TM / 4) + r) * LDT + c];
+                    dbh[0] += s;
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (NCH > 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
+                        __syncthreads();
+                        tile_store<VEC>(Xs, px);
+                        const bool last = (c + 1 == NCH);
+                        const int cn = last ? 0 : c + 1;
+                        tile_load<VEC>(px, a.x, last ? next_row0 : row0, a.rows, a.x_stride, cn * KC, min(KC, din - cn * KC));
+                        if (last && !w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
+                        __syncthreads();
+                    }
+                    colred(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
+                }
+            }
+            PH(9);
+        }
+    }
+    PH_FLUSH;
+
+    // ================= write this workgroup's partial gradient + stats =================
+    if (TRAIN) {
+        float* out = a.partial + (size_t)blockIdx.x * a.PS;
+        // dW0: wave (wm, wn) holds rows n = 32wm + i, cols k = 64c + 32wn + j
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                const int k = KC * c + 32 * wn + lc;
+                if (n < H && k < din) out[off.W0 + n * din + k] = accW0[c][g];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < LCAP; ++l) {
+            if (l < L) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int n = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    const int k = 32 * wn + lc;
+                    if (n < H && k < H) out[off.Wl(l) + n * H + k] = accWl[l][g];
+                }
+            }
+        }
+        {   // dWout: the two wave-rows hold partial sums of the same [32 x 32] tile -> combine through LDS
+            float* scr = smem + lds.Hs(0);  // activations are dead now: [2 (wn)][32 (k)][33] scratch
+            __syncthreads();
+            if (wm == 1) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    scr[(wn * 32 + k) * 33 + lc] = accWo[g];
+                }
+            }
+            __syncthreads();
+            if (wm == 0) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    const int c = 32 * wn + lc;
+                    if (k < dout && c < H) out[off.Wout + k * H + c] = accWo[g] + scr[(wn * 32 + k) * 33 + lc];
+                }
+            }
+            __syncthreads();
+            red[tid] = dbo;  // [8 parts][32 k]
+            __syncthreads();
+            if (tid < dout) {
+                float sb = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sb += red[q * 32 + tid];
+                out[off.bout + tid] = sb;
+            }
+        }
+        // bias grads: 4 row-parts per column -> LDS -> sum
+#pragma unroll
+        for (int l = 0; l <= LCAP; ++l) {
+            if (l <= L) {
+                __syncthreads();
+                red[(tid >> 6) * HP + (tid & 63)] = dbh[l];
+                __syncthreads();
+                if (tid < H) {
+                    const float s = red[tid] + red[HP + tid] + red[2 * HP + tid] + red[3 * HP + tid];
+                    out[(l == 0 ? off.b0 : off.bl(l - 1)) + tid] = s;
+                }
+            }
+        }
+        // stats
+        float sv[6] = {st_pg, st_ent, st_kl, st_clip, st_vl, st_cnt};
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const float v = cm_wave_sum(sv[s]);
+            if (lane == 0) red[s * 4 + wave] = v;
+        }
+        __syncthreads();
+        if (tid < CM_NUM_STATS) {
+            float v = 0.0f;
+            if (tid < 6) v = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+            out[off.P + tid] = v;
+        }
+    }
+}
+
+// sum per-workgroup partials: out[i] = sum_w partial[w][i]
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, int nparts, int PS, int n,
+                                                         float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < nparts; w += 4) {
+        s0 += partial[(size_t)w * PS + i];
+        s1 += partial[(size_t)(w + 1) * PS + i];
+        s2 += partial[(size_t)(w + 2) * PS + i];
+        s3 += partial[(size_t)(w + 3) * PS + i];
+    }
+    for (; w < nparts; ++w) s0 += partial[(size_t)w * PS + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+}
+
+constexpr int MAX_GRID = 256;  // one persistent workgroup per CU (LDS-limited)
+
+inline int check_shapes(const char* who, int din, int H, int L, int dout) {
+    CM_REQUIRE(din > 0 && H > 0 && L >= 0 && dout > 0, "%s: bad dims din=%d H=%d L=%d dout=%d", who, din, H, L, dout);
+    CM_REQUIRE(H <= HP, "%s: hidden_dim=%d > %d is not supported by this build", who, H, HP);
+    CM_REQUIRE(L <= LMAX, "%s: num_layers=%d > %d is not supported by this build", who, L, LMAX);
+    CM_REQUIRE(dout <= KMAX, "%s: output width %d > %d is not supported by this build", who, dout, KMAX);
+    return 0;
+}
+inline int check_rows(const char* who, long rows) {
+    CM_REQUIRE(rows < (1L << 31), "%s: %ld rows exceed the 2^31 row limit of one launch", who, rows);
+    return 0;
+}
+
+inline int grid_for(long rows) {
+    long nt = (rows + TM - 1) / TM;
+    return (int)(nt < MAX_GRID ? nt : MAX_GRID);
+}
+
+// 16-byte loads need 16-byte aligned rows of both the activations and W0 (row stride din)
+inline bool can_vec(const MlpArgs& a) {
+    return (a.din % 4 == 0) && (a.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(a.params) & 15) == 0);
+}
+
+template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
+inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
+}
+
+// runtime (vec, L <= 1, dout <= 8) -> compile-time (VEC, LCAP, KJ)
+template <int NCH, int MODE>
+inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+    const bool vec = can_vec(a), l1 = a.L <= 1, k8 = a.dout <= 8;
+    if (vec) {
+        if (l1) { if (k8) launch_one<NCH, MODE, true, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 1, 8>(a, grid, lds_bytes, s); }
+        else    { if (k8) launch_one<NCH, MODE, true, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 2, 8>(a, grid, lds_bytes, s); }
+    } else {
+        if (l1) { if (k8) launch_one<NCH, MODE, false, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, false, 1, 8>(a, grid, lds_bytes, s); }
+        else    { if (k8) launch_one<NCH, MODE, false, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, false, 2, 8>(a, grid, lds_bytes, s); }
+    }
+}
+
+template <int MODE>
+inline int launch_infer(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+    launch_variant<0, MODE>(a, grid, lds_bytes, s);
+    return 0;
+}
+
+template <int MODE>
+inline int launch_train(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+    const int nch = (a.din + KC - 1) / KC;
+    switch (nch) {
+        case 1: launch_variant<1, MODE>(a, grid, lds_bytes, s); break;
+        case 2: launch_variant<2, MODE>(a, grid, lds_bytes, s); break;
+        case 3: launch_variant<3, MODE>(a, grid, lds_bytes, s); break;
+        case 4: launch_variant<4, MODE>(a, grid, lds_bytes, s); break;
+        case 5: launch_variant<5, MODE>(a, grid, lds_bytes, s); break;
+        case 6: launch_variant<6, MODE>(a, grid, lds_bytes, s); break;
+        case 7: launch_variant<7, MODE>(a, grid, lds_bytes, s); break;
+        case 8: launch_variant<8, MODE>(a, grid, lds_bytes, s); break;
+        default: CM_FAIL(-1, "input width %d > %d is not supported by the fused training kernels", a.din, 8 * KC);
+    }
+    return 0;
+}
+
+}  // namespace

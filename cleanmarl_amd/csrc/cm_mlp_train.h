@@ -1,0 +1,22 @@
+// cm_mlp_train.h -- shared host helpers of the fused training entry points
+#pragma once
+#include "cm_mlp_kernel.h"
+
+#ifdef CM_PHASE_PROF
+extern unsigned long long* g_prof;
+#endif
+
+inline size_t train_ws_bytes(int din, int hidden, int n_hidden_layers, int dout) {
+    const int64_t P = cm_mlp_param_count(din, hidden, n_hidden_layers, dout);
+    const size_t PS = (size_t)((P + CM_NUM_STATS + 63) / 64 * 64);
+    return (size_t)MAX_GRID * PS * sizeof(float);
+}
+
+inline int finish_train(const MlpArgs& a, int grid, int64_t P, float* grad_and_stats, hipStream_t s, const char* who) {
+    const int n = (int)(P + CM_NUM_STATS);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, grid, a.PS, n, grad_and_stats);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) CM_FAIL(-2, "%s: reduce launch failed: %s", who, hipGetErrorString(e));
+    return 0;
+}
+

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the fused MLP training kernels (needs the -DCM_PHASE_PROF build).
+    hipcc ... -DCM_PHASE_PROF -o cleanmarl_amd/libcleanmarl_hip_prof.so ; python tools/phase_prof.py [actor|critic]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cleanmarl_amd import _native as N  # noqa: E402
+
+N.LIB_PATH = os.path.join(ROOT, "cleanmarl_amd", "libcleanmarl_hip_prof.so")
+lib = N.load()
+lib.cm_prof_set_buffer.argtypes = [C.c_void_p]
+which = sys.argv[1] if len(sys.argv) > 1 else "actor"
+E, A, T, K = 4096, 8, 128, 5
+Do, Ds = 7 * A, 6 * A * A
+dev = torch.device("cuda:0")
+from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch  # noqa: E402
+torch.manual_seed(0)
+prof = torch.zeros(256, 16, dtype=torch.int64, device=dev)
+lib.cm_prof_set_buffer(C.c_void_p(prof.data_ptr()))
+ep_len = torch.full((E,), T, dtype=torch.int32, device=dev)
+s = N.stream_ptr()
+if which == "actor":
+    spec = NetSpec(Do, 64, 1, K)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    obs = torch.randn(E, A, T, Do, device=dev); avail = torch.ones(E, A, T, K, dtype=torch.uint8, device=dev)
+    act = torch.randint(0, K, (E, A, T), dtype=torch.int32, device=dev); lp = -torch.rand(E, A, T, device=dev) - 1.0
+    adv = torch.randn(E, A, T, device=dev)
+    g = torch.zeros(spec.nparams + 8, device=dev)
+    ws = torch.empty(lib.cm_mlp_train_workspace_bytes(Do, 64, 1, K), dtype=torch.uint8, device=dev)
+    run = lambda: N.check(lib.cm_ppo_actor_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lp), N.ptr(adv), N.ptr(ep_len),
+                                                  E, A, T, Do, 64, 1, K, N.ptr(p), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "actor")
+else:
+    spec = NetSpec(Ds, 64, 1, 1)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    st = torch.randn(E, T, Ds, device=dev); ret = torch.randn(E, A, T, device=dev)
+    g = torch.zeros(spec.nparams + 8, device=dev)
+    ws = torch.empty(lib.cm_mlp_train_workspace_bytes(Ds, 64, 1, 1), dtype=torch.uint8, device=dev)
+    run = lambda: N.check(lib.cm_critic_fwd_bwd(N.ptr(st), N.ptr(ret), N.ptr(ep_len), E, A, T, 0, Ds, 64, 1, N.ptr(p),
+                                                N.ptr(g), N.ptr(ws), ws.numel(), s), "critic")
+for _ in range(2):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+ph = prof.double().mean(0).cpu()
+tot = float(ph.sum())
+names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
+rows = (E * A * T) if which == "actor" else E * T
+tiles_per_wg = rows / 64 / 256
+print(f"{which}: {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks (100 MHz const clock?) per tile:")
+for i, n in enumerate(names):
+    print(f"  {n:24s} {float(ph[i]) / tiles_per_wg:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
