@@ -1,0 +1,281 @@
+// cm_rollout.hip -- fused, persistent rollout kernel for the on-device synthetic MPE-like env.
+//
+// Replaces the whole inner rollout loop of cleanmarl/mappo_multienvs.py:393-453 (reset, then per step:
+// Actor.act :409-414 -> env.step over the pipes :415-424 -> append to the episode lists :425-434) and the
+// collate copy of RolloutBuffer.get_batch (:109-157) by ONE launch: environments are independent, so a
+// workgroup keeps a tile of floor(64/A) envs (<= 64 (env,agent) rows) resident in LDS and walks all T steps
+//     obs from env state -> [write obs/state to the rollout buffer] -> actor MLP on the MFMA units ->
+//     Categorical sample (Philox keyed by seed, global row, t) -> [write action/logp] -> point-mass physics
+//     -> team reward -> next step
+// with the actor weights LDS-stationary for the whole episode.  No inter-workgroup dependency, no host round
+// trip, no per-step launch.  The per-step kernels (cm_policy_act + cm_synth_env_step) remain the C-ABI for
+// real / host-side environments and are the parity reference for this kernel (tests/test_hip_parity.py).
+#include "cm_mlp_kernel.h"
+
+namespace {
+
+constexpr float DAMP = 0.25f, DT = 0.1f, ACCEL = 5.0f, COLLIDE = 0.3f;
+
+struct RolloutArgs {
+    float* env_state;  // [E][6A]: pos(2A) vel(2A) landmarks(2A) -- written at the end (state after step T-1)
+    int E, A, T, agent_ids;
+    unsigned long long seed, act_seed;
+    long env_offset, episode;
+    const float* params; int din, H, L, K;
+    float* obs; float* state; int* action; float* logp; float* reward;
+};
+
+// feature f of agent i's observation (cm_env.hip write_obs order)
+__device__ __forceinline__ float obs_feature(int f, int i, int A, const float* pos, const float* vel, const float* lm,
+                                             int agent_ids) {
+    const float px = pos[2 * i], py = pos[2 * i + 1];
+    if (f < 2) return vel[2 * i + f];
+    if (f < 4) return f == 2 ? px : py;
+    f -= 4;
+    if (f < 2 * A) return lm[f] - ((f & 1) ? py : px);
+    f -= 2 * A;
+    if (f < 2 * (A - 1)) {
+        int j = f >> 1;
+        if (j >= i) ++j;
+        return pos[2 * j + (f & 1)] - ((f & 1) ? py : px);
+    }
+    f -= 2 * (A - 1);
+    if (f < 2 * (A - 1)) return 0.0f;
+    f -= 2 * (A - 1);
+    if (agent_ids && f < A) return f == i ? 1.0f : 0.0f;
+    return 0.0f;  // zero padding up to the 64-column MFMA chunk
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    const int EPT = TM / A, RT = EPT * A;  // envs / valid rows per tile
+    const int Ds = 6 * A * A;
+    // LDS carve
+    float* Xs = smem;                    // obs tile; aliased by H1 once layer 0 has consumed it
+    float* W0s = Xs + TM * LDT;
+    float* H0 = W0s + HP * LDT;
+    float* Ws = H0 + TM * LDT;
+    float* wouts = Ws + HP * LDT;        // [8][HP]
+    float* b0s = wouts + 8 * HP;
+    float* b1s = b0s + HP;
+    float* bos = b1s + HP;               // [8]
+    float* ls = bos + 8;                 // [TM][8] logits
+    float* epos = ls + TM * 8;           // [TM][2] per row (env-local agent)
+    float* evel = epos + TM * 2;
+    float* elm = evel + TM * 2;          // [EPT*A][2] landmarks of env el at elm + el*2A
+    int* eact = reinterpret_cast<int*>(elm + TM * 2);  // [TM]
+
+    for (int i = tid; i < 8 * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        wouts[i] = (c < H && k < K) ? a.params[off.Wout + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) {
+        b0s[i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
+        b1s[i] = (i < H && L > 0) ? a.params[off.bl(0) + i] : 0.0f;
+    }
+    if (tid < 8) bos[tid] = (tid < K) ? a.params[off.bout + tid] : 0.0f;
+    stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
+    if (L > 0) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const int hrow = tid >> 2, hq = tid & 3;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();
+        // ---------------- reset (cm_env.hip k_env_reset): thread per (env, agent) row
+        if (tid < RT) {
+            const int el = tid / A, i = tid - el * A;
+            const int e = e0 + el;
+            if (e < a.E) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            // ---------------- observations of step t -> Xs (4 lanes per row, features f = hq, hq+4, ...)
+            {
+                const int el = hrow / A, i = hrow - el * A;
+                const bool live = hrow < RT && (e0 + el) < a.E;
+#pragma unroll
+                for (int j = 0; j < KC / 4; ++j) {
+                    const int f = 4 * j + hq;
+                    Xs[hrow * LDT + f] = live ? obs_feature(f, i, A, epos + el * 2 * A, evel + el * 2 * A, elm + el * 2 * A, a.agent_ids) : 0.0f;
+                }
+            }
+            __syncthreads();
+            // ---------------- rollout-buffer writes (coalesced along the feature axis)
+#pragma unroll 4
+            for (int idx = tid; idx < TM * KC; idx += NTHREADS) {
+                const int r = idx >> 6, c = idx & 63;
+                const int el = r / A, i = r - el * A;
+                const long e = e0 + el;
+                if (r < RT && e < a.E) {
+                    const float v = Xs[r * LDT + c];
+                    if (c < din) a.obs[((e * A + i) * (long)T + t) * din + c] = v;
+                    if (c < 6 * A) a.state[(e * (long)T + t) * Ds + i * 6 * A + c] = v;
+                }
+            }
+            // ---------------- actor forward, layer 0
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+            rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (din + 7) >> 3);
+            {
+                const float bias = b0s[32 * wn + lc];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    H0[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                }
+            }
+            __syncthreads();
+            float* HL = H0;
+            if (L > 0) {  // hidden layer; H1 aliases Xs (every wave is past its layer-0 reads)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+                rowpar_nt(acc, H0 + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                const float bias = b1s[32 * wn + lc];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    Xs[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                }
+                HL = Xs;
+                __syncthreads();
+            }
+            // ---------------- head: logits (4 lanes per row x 16 hidden columns), all K actions available
+            {
+                float hreg[16];
+                const float4* hp4 = reinterpret_cast<const float4*>(HL + hrow * LDT + 16 * hq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = hp4[i];
+                    hreg[4 * i] = v.x; hreg[4 * i + 1] = v.y; hreg[4 * i + 2] = v.z; hreg[4 * i + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k < K) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + k * HP + 16 * hq);
+                        float p = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 w4 = wp4[i];
+                            p = fmaf(hreg[4 * i], w4.x, p); p = fmaf(hreg[4 * i + 1], w4.y, p);
+                            p = fmaf(hreg[4 * i + 2], w4.z, p); p = fmaf(hreg[4 * i + 3], w4.w, p);
+                        }
+                        p = quad_sum(p);
+                        if (hq == (k & 3)) ls[hrow * 8 + k] = p + bos[k];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---------------- Categorical sample + log_prob (same arithmetic as k_mlp<M_ACT>), then physics
+            if (tid < RT) {
+                const int el = tid / A, i = tid - el * A;
+                const long e = e0 + el;
+                if (e < a.E) {
+                    const float* z = ls + tid * 8;
+                    float m = -INFINITY;
+                    for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
+                    float s = 0.0f;
+                    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+                    const float lse = m + logf(s);
+                    const unsigned long long gr = (unsigned long long)((a.env_offset + e) * A + i);
+                    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
+                                                    (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                    const float u = cm_u01(rnd.x);
+                    float cum = 0.0f;
+                    int chosen = -1;
+                    for (int k = 0; k < K; ++k) {
+                        cum += expf(z[k] - lse);
+                        if (chosen < 0 && u < cum) chosen = k;
+                    }
+                    if (chosen < 0) chosen = K - 1;
+                    const long o = (e * A + i) * (long)T + t;
+                    a.action[o] = chosen;
+                    a.logp[o] = z[chosen] - lse;
+                    // point-mass physics (cm_env.hip k_env_step)
+                    const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
+                    const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);
+                    const float vx = evel[2 * tid] * (1.0f - DAMP) + ux * DT;
+                    const float vy = evel[2 * tid + 1] * (1.0f - DAMP) + uy * DT;
+                    evel[2 * tid] = vx; evel[2 * tid + 1] = vy;
+                    epos[2 * tid] += vx * DT; epos[2 * tid + 1] += vy * DT;
+                }
+            }
+            __syncthreads();
+            // ---------------- team reward of step t: one thread per env
+            if (tid < EPT && e0 + tid < a.E) {
+                const float* pos = epos + tid * 2 * A;
+                const float* lm = elm + tid * 2 * A;
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) {
+                    float best = 3.0e38f;
+                    for (int j = 0; j < A; ++j) {
+                        const float dx = pos[2 * j] - lm[2 * l], dy = pos[2 * j + 1] - lm[2 * l + 1];
+                        best = fminf(best, sqrtf(dx * dx + dy * dy));
+                    }
+                    r -= best;
+                }
+                for (int j = 0; j < A; ++j)
+                    for (int q = j + 1; q < A; ++q) {
+                        const float dx = pos[2 * j] - pos[2 * q], dy = pos[2 * j + 1] - pos[2 * q + 1];
+                        if (sqrtf(dx * dx + dy * dy) < COLLIDE) r -= 1.0f;
+                    }
+                a.reward[(long)(e0 + tid) * T + t] = r;
+            }
+        }
+        __syncthreads();
+        // ---------------- final env state back to global (pos | vel | landmarks)
+        if (tid < RT) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            if (e < a.E) {
+                float* es = a.env_state + e * 6 * A;
+                es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int n_hidden_layers) {
+    const int din = 6 * A + (agent_ids ? A : 0);
+    return (A >= 1 && din <= KC && hidden <= HP && n_hidden_layers <= 1) ? 1 : 0;
+}
+
+extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                 int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
+                                 float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && T > 0, "cm_rollout_spread: bad dims E=%d T=%d", E, T);
+    CM_REQUIRE(cm_rollout_spread_supported(A, agent_ids, hidden, n_hidden_layers),
+               "cm_rollout_spread: unsupported shape A=%d hidden=%d layers=%d (use cm_policy_act + cm_synth_env_step)", A, hidden, n_hidden_layers);
+    RolloutArgs a = {};
+    a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed;
+    a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0);
+    a.H = hidden; a.L = n_hidden_layers; a.K = 5;
+    a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+    const int EPT = TM / A;
+    const int ntiles = (E + EPT - 1) / EPT;
+    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 8 * HP + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM;
+    const size_t lds_bytes = lds_floats * sizeof(float);
+    const int grid = ntiles < 512 ? ntiles : 512;  // <= 80 KB of LDS: two workgroups per CU overlap each other's latencies
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_rollout_spread, dim3(grid), dim3(NTHREADS), lds_bytes, (hipStream_t)stream, a);
+    CM_CHECK_LAUNCH("cm_rollout_spread");
+    return 0;
+}

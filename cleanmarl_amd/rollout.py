@@ -32,11 +32,27 @@ class SyntheticSpreadRollout:
         self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
         self.episode = 0
 
-    def collect(self, actor_flat, actor_spec):
+    def collect(self, actor_flat, actor_spec, fused=None):
         """One episode per env (reference outer loop body, :393-453).  Everything is enqueued on the
-        current stream; returns the filled DeviceBatch without synchronising."""
+        current stream; returns the filled DeviceBatch without synchronising.
+        fused=None picks the single-launch persistent kernel (cm_rollout_spread) whenever the shape allows,
+        else T x (cm_policy_act + cm_synth_env_step); both produce the same rollout for the same seeds."""
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        can_fuse = actor_spec.kind == "mlp" and bool(lib.cm_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden,
+                                                                                 actor_spec.n_layers))
+        if fused is None:
+            fused = can_fuse
+        if fused:
+            if not can_fuse:
+                raise N.NativeError("fused rollout requested for an unsupported shape")
+            act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+            N.check(lib.cm_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
+                                          self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
+                                          actor_spec.n_layers, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action), N.ptr(b.logp),
+                                          N.ptr(b.reward), s), "cm_rollout_spread")
+            self.episode += 1
+            return b
         N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,
                                        self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF

@@ -159,6 +159,17 @@ int cm_synth_env_reset(float* env_state, int E, int A, int agent_ids, uint64_t s
 int cm_synth_env_step(float* env_state, const int32_t* action, int E, int A, int agent_ids, int t, int T,
                       float* reward, float* obs, float* state, cm_stream_t stream);
 
+/* ---- a15 (fused): the WHOLE rollout of the synthetic env in one persistent launch ----
+ * Equivalent to cm_synth_env_reset followed by T x (cm_policy_act; cm_synth_env_step) with the same seeds
+ * (replaces cleanmarl/mappo_multienvs.py:393-453 + the collate of :109-157): each workgroup keeps floor(64/A)
+ * envs in LDS for all T steps, actor weights LDS-stationary.  Supported when 6A(+A) <= 64, hidden <= 64 and
+ * n_hidden_layers <= 1 (query with cm_rollout_spread_supported); other shapes use the per-step entry points.
+ * act_seed keys the action sampler (the per-step path passes the same value as `seed` of cm_policy_act). */
+int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int n_hidden_layers);
+int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                      int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
+                      float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
