@@ -69,12 +69,7 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        try:
-            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
-        except AttributeError:
-            if name.startswith("cm_gru_"):  # TEMP: GRU kernels land in a later commit
-                continue
-            raise
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
     _lib = lib

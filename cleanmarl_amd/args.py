@@ -1,0 +1,124 @@
+"""Command-line surface of the four hot-path scripts.
+
+Every field, default and help string mirrors the reference's ``@dataclass Args`` parsed by ``tyro.cli``
+(cleanmarl/mappo_multienvs.py:18-79, cleanmarl/ippo_multienvs.py:18-79, cleanmarl/mappo_lstm_multienvs.py:18-80,
+cleanmarl/ippo_lstm_multienvs.py:18-80); tyro is not a dependency here, so an argparse front-end reproduces its
+spelling rules: ``--a_b=v``, ``--a_b v``, ``--a-b v`` and ``--flag / --no-flag`` (also ``--flag=True|False``).
+Build-only additions never change an existing default: ``--env_type=synthetic`` (on-device MPE-like env) /
+``synthetic_cpu`` (same env on the host behind the pipe protocol) with ``--synthetic_agents`` and
+``--synthetic_steps``; ``--device`` defaults to ``cuda`` because this build has no CPU compute path.
+"""
+import argparse
+from dataclasses import dataclass, fields
+
+
+@dataclass
+class Args:
+    env_type: str = "smaclite"
+    """ Pettingzoo, SMAClite ... (build adds: synthetic, synthetic_cpu) """
+    env_name: str = "3m"
+    """ Name of the environment"""
+    env_family: str = "mpe"
+    """ Env family when using pz"""
+    agent_ids: bool = True
+    """ Include id (one-hot vector) at the agent of the observations"""
+    batch_size: int = 3
+    """ Number of episodes to collect in each rollout"""
+    actor_hidden_dim: int = 32
+    """ Hidden dimension of actor network"""
+    actor_num_layers: int = 1
+    """ Number of hidden layers of actor network"""
+    critic_hidden_dim: int = 64
+    """ Hidden dimension of critic network"""
+    critic_num_layers: int = 1
+    """ Number of hidden layers of critic network"""
+    optimizer: str = "Adam"
+    """ The optimizer"""
+    learning_rate_actor: float = 0.0008
+    """ Learning rate for the actor"""
+    learning_rate_critic: float = 0.0008
+    """ Learning rate for the critic"""
+    total_timesteps: int = 1000000
+    """ Total steps in the environment during training"""
+    gamma: float = 0.99
+    """ Discount factor"""
+    td_lambda: float = 0.95
+    """ TD(lambda) discount factor"""
+    normalize_reward: bool = False
+    """ Normalize the rewards if True"""
+    normalize_advantage: bool = False
+    """ Normalize the advantage if True"""
+    normalize_return: bool = False
+    """ Normalize the returns if True"""
+    epochs: int = 3
+    """ Number of training epochs"""
+    ppo_clip: float = 0.2
+    """ PPO clipping factor """
+    entropy_coef: float = 0.001
+    """ Entropy coefficient """
+    clip_gradients: float = -1
+    """ 0< for no clipping and 0> if clipping at clip_gradients"""
+    tbptt: int = 10
+    """ Chunck size for Truncated Backpropagation Through Time tbptt (recurrent scripts only)"""
+    log_every: int = 10
+    """ Logging steps """
+    eval_steps: int = 50
+    """ Evaluate the policy each eval_steps training steps"""
+    num_eval_ep: int = 10
+    """ Number of evaluation episodes"""
+    use_wnb: bool = False
+    """ Logging to Weights & Biases if True"""
+    wnb_project: str = ""
+    """ Weights & Biases project name"""
+    wnb_entity: str = ""
+    """ Weights & Biases entity name"""
+    device: str = "cuda"
+    """ Device (this build: cuda only; the reference defaults to cpu)"""
+    seed: int = 1
+    """ Random seed"""
+    # ---- build-only flags
+    synthetic_agents: int = 3
+    """ [build] number of agents of the synthetic MPE-like env"""
+    synthetic_steps: int = 25
+    """ [build] fixed episode length (max_cycles) of the synthetic env"""
+
+
+# per-script default overrides
+SCRIPT_DEFAULTS = {
+    "mappo_multienvs": dict(),
+    "ippo_multienvs": dict(critic_hidden_dim=32),
+    "mappo_lstm_multienvs": dict(num_eval_ep=5, tbptt=10),
+    "ippo_lstm_multienvs": dict(critic_hidden_dim=32, optimizer="AdamW", tbptt=5),
+}
+
+
+def _str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("1", "true", "t", "yes", "y"):
+        return True
+    if v.lower() in ("0", "false", "f", "no", "n"):
+        return False
+    raise argparse.ArgumentTypeError(f"boolean expected, got {v!r}")
+
+
+def build_parser(script):
+    defaults = dict(SCRIPT_DEFAULTS[script])
+    p = argparse.ArgumentParser(prog=script + ".py", description=f"MI355X-native {script} (cleanmarl CLI surface)")
+    for f in fields(Args):
+        default = defaults.get(f.name, f.default)
+        names = ["--" + f.name]
+        if "_" in f.name:
+            names.append("--" + f.name.replace("_", "-"))
+        if f.type is bool or isinstance(f.default, bool):
+            p.add_argument(*names, dest=f.name, nargs="?", const=True, default=default, type=_str2bool)
+            no = ["--no-" + f.name] + (["--no-" + f.name.replace("_", "-")] if "_" in f.name else [])
+            p.add_argument(*no, dest=f.name, action="store_false", help=argparse.SUPPRESS)
+        else:
+            p.add_argument(*names, dest=f.name, type=f.type if isinstance(f.type, type) else type(f.default), default=default)
+    return p
+
+
+def parse_args(script, argv=None):
+    ns = build_parser(script).parse_args(argv)
+    return Args(**vars(ns))

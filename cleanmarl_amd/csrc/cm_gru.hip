@@ -1,0 +1,639 @@
+// cm_gru.hip -- GRU actor: rollout step and fused TBPTT chunk forward + backward-through-time.
+//
+// Reference: Actor of cleanmarl/mappo_lstm_multienvs.py:162-184
+//     x1 = relu(fc1(obs));  h' = GRUCell(x1, h);  logits = Linear(relu(h'));  masked_fill(~avail, -1e9)
+// and the truncated-BPTT actor update of :562-620: for every chunk of `tbptt` steps the loss
+//     sum_{t in chunk} (-pg_t - c_ent * ent_t) / (N_chunk * T_chunk)
+// is back-propagated through the chunk only (h detached at the chunk boundary) and followed by an optimiser step.
+//
+// One workgroup owns a tile of 64 (env,agent) sequences and walks the chunk twice: forward t0..t1-1 (saving
+// x1, r, z, n, W_hn h + b_hn and h' per step to a workspace in HBM and the per-step dlogits of the PPO head),
+// then backward t1-1..t0 with dh carried in LDS.  Every GEMM is a 64x64x64 block on v_mfma_f32_32x32x2_f32
+// (same three forms as cm_mlp_kernel.h); gate weight blocks are streamed through LDS, weight-gradient
+// accumulators (W_ih, W_hh: 6 blocks, fc1, fc2) stay in registers for the whole chunk and are written once
+// per workgroup, then folded by k_reduce_partials.  Time is inherently sequential here; parallelism is over
+// sequences only (SURVEY.md §7 "hard parts" (e)).
+#include "cm_mlp_train.h"
+
+namespace {
+
+struct GruOff { int W1, b1, Wih, Whh, bih, bhh, W2, b2, P; };
+__host__ __device__ inline GruOff gru_offsets(int din, int H, int K) {
+    GruOff o;
+    o.W1 = 0; o.b1 = H * din; o.Wih = o.b1 + H; o.Whh = o.Wih + 3 * H * H; o.bih = o.Whh + 3 * H * H;
+    o.bhh = o.bih + 3 * H; o.W2 = o.bhh + 3 * H; o.b2 = o.W2 + K * H; o.P = o.b2 + K;
+    return o;
+}
+
+constexpr int WS_ACT = 6 * HP;  // per (step,row): x1 | r | z | n | ghn | hnew, each padded to HP floats
+constexpr int WS_DL = KMAX;     // per (step,row): dlogits padded to KMAX
+
+struct GruArgs {
+    const float* obs; const uint8_t* avail; const int* action; const float* logp_old; const float* adv; const int* ep_len;
+    int E, A, T, t0, t1, din, H, K;
+    const float* params; const float* h_in; float* h_out;
+    float clip_lo, clip_hi, clip_eps, ent_coef;
+    float* ws_act; float* ws_dl; float* partial; int PS;
+    // act mode
+    const float* x; long x_stride; const uint8_t* av; long av_stride; long rows; float* h;
+    unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// LDS carve: 8 activation/weight buffers + head weights + per-row scratch + biases
+struct GruLds { float *b[8], *wouts, *ls, *b1, *bih, *bhh, *b2, *red; };
+__device__ __forceinline__ GruLds gru_lds(float* smem, int KP) {
+    GruLds s; float* p = smem;
+    for (int i = 0; i < 8; ++i) { s.b[i] = p; p += TM * LDT; }
+    s.wouts = p; p += KP * HP;
+    s.ls = p; p += TM * LSP;
+    s.b1 = p; p += HP; s.bih = p; p += 3 * HP; s.bhh = p; p += 3 * HP; s.b2 = p; p += KMAX;
+    s.red = p;
+    return s;
+}
+inline size_t gru_lds_bytes(int K) {
+    const int KP = (K <= 8) ? 8 : KMAX;
+    return (size_t)(8 * TM * LDT + KP * HP + TM * LSP + HP + 6 * HP + KMAX + 4 * HP) * sizeof(float);
+}
+
+__device__ __forceinline__ void gru_stage_consts(const GruLds& L, const GruArgs& a, const GruOff& off, int KP) {
+    const int tid = threadIdx.x, H = a.H, K = a.K;
+    for (int i = tid; i < KP * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) L.b1[i] = (i < H) ? a.params[off.b1 + i] : 0.0f;
+    for (int i = tid; i < 3 * HP; i += NTHREADS) {
+        const int g = i / HP, c = i % HP;
+        L.bih[i] = (c < H) ? a.params[off.bih + g * H + c] : 0.0f;
+        L.bhh[i] = (c < H) ? a.params[off.bhh + g * H + c] : 0.0f;
+    }
+    for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+    for (int i = tid; i < TM * LSP; i += NTHREADS) L.ls[i] = 0.0f;
+}
+
+// One GRU forward step for the tile whose obs rows are already addressable through (xbase, xstride).
+// X=b0 W=b1 A1=b2 HP=hp HN=hn GR=b5 GZ=b6 W2=b7.  SAVE: also write the activations the backward pass needs.
+template <bool SAVE>
+__device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, const GruOff& off, const float* xbase,
+                                             long xstride, long row0, long nrows, float* hp, float* hn, float* wsrow /* ws_act + (s*R + row0)*WS_ACT */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int H = a.H, din = a.din;
+    float *X = L.b[0], *W = L.b[1], *A1 = L.b[2], *GR = L.b[5], *GZ = L.b[6], *W2 = L.b[7];
+    const int col = 32 * wn + lc;
+    f32x16 acc;
+    // ---- F1: x1 = relu(fc1(obs))
+    __syncthreads();
+    stage_rows(X, xbase, row0, nrows, xstride, 0, din);
+    stage_rows(W, a.params + off.W1, 0, H, din, 0, din);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+    rowpar_nt(acc, X + 32 * wm * LDT, W + 32 * wn * LDT, (din + 7) >> 3);
+    {
+        const float bias = L.b1[col];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const float v = fmaxf(acc[g] + bias, 0.0f);
+            A1[row * LDT + col] = v;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 0 * HP + col] = v;
+        }
+    }
+    // ---- F2: r, z gates
+#pragma unroll
+    for (int gate = 0; gate < 2; ++gate) {
+        __syncthreads();  // A1 complete / previous readers of W, W2 done
+        stage_rows(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
+        stage_rows(W2, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+        rowpar_nt(acc, A1 + 32 * wm * LDT, W + 32 * wn * LDT, HP / 8);
+        rowpar_nt(acc, hp + 32 * wm * LDT, W2 + 32 * wn * LDT, HP / 8);
+        float* G = gate == 0 ? GR : GZ;
+        const float bias = L.bih[gate * HP + col] + L.bhh[gate * HP + col];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const float v = sigmoidf_(acc[g] + bias);
+            G[row * LDT + col] = v;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + (1 + gate) * HP + col] = v;
+        }
+    }
+    // ---- F3: candidate n and the new hidden state
+    __syncthreads();
+    stage_rows(W, a.params + off.Wih + 2 * H * H, 0, H, H, 0, H);
+    stage_rows(W2, a.params + off.Whh + 2 * H * H, 0, H, H, 0, H);
+    __syncthreads();
+    f32x16 acch;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { acc[g] = 0.0f; acch[g] = 0.0f; }
+    rowpar_nt(acc, A1 + 32 * wm * LDT, W + 32 * wn * LDT, HP / 8);
+    rowpar_nt(acch, hp + 32 * wm * LDT, W2 + 32 * wn * LDT, HP / 8);
+    {
+        const float bi = L.bih[2 * HP + col], bh = L.bhh[2 * HP + col];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const float ghn = acch[g] + bh;
+            const float r = GR[row * LDT + col], z = GZ[row * LDT + col], hprev = hp[row * LDT + col];
+            const float n = tanhf(acc[g] + bi + r * ghn);
+            const float hv = (col < H) ? (1.0f - z) * n + z * hprev : 0.0f;
+            hn[row * LDT + col] = hv;
+            if (SAVE && row0 + row < nrows) {
+                float* w = wsrow + (long)row * WS_ACT;
+                w[3 * HP + col] = n; w[4 * HP + col] = ghn; w[5 * HP + col] = hv;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// logits of the head for this lane's row (4 lanes per row): zreg[j] holds k = 4j + hq
+template <int KJ>
+__device__ __forceinline__ void gru_head_logits(const GruLds& L, const float* hn, int K, const unsigned char* avb, float (&zreg)[KJ]) {
+    const int tid = threadIdx.x, hrow = tid >> 2, hq = tid & 3;
+    float hreg[16];
+    const float4* hp4 = reinterpret_cast<const float4*>(hn + hrow * LDT + 16 * hq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = hp4[i];
+        hreg[4 * i] = fmaxf(v.x, 0.f); hreg[4 * i + 1] = fmaxf(v.y, 0.f); hreg[4 * i + 2] = fmaxf(v.z, 0.f); hreg[4 * i + 3] = fmaxf(v.w, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        zreg[j] = -1e9f;
+        if (4 * j < K) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * j + q;
+                if (k < K) {
+                    const float4* wp4 = reinterpret_cast<const float4*>(L.wouts + k * HP + 16 * hq);
+                    float p = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 w4 = wp4[i];
+                        p = fmaf(hreg[4 * i], w4.x, p); p = fmaf(hreg[4 * i + 1], w4.y, p);
+                        p = fmaf(hreg[4 * i + 2], w4.z, p); p = fmaf(hreg[4 * i + 3], w4.w, p);
+                    }
+                    p = quad_sum(p);
+                    if (hq == q) zreg[j] = avb[j] ? p + L.b2[k] : -1e9f;
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================ chunk fwd + bwd
+template <int KJ>
+__global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = KJ * 4;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    const GruLds L = gru_lds(smem, KP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int hrow = tid >> 2, hq = tid & 3;
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const int col = 32 * wn + lc;
+    gru_stage_consts(L, a, off, KP);
+
+    f32x16 accW1, accWih[3], accWhh[3], accWo;
+    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbo = 0.f;
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        accW1[g] = 0.f; accWo[g] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
+    }
+    const long ntiles = (R + TM - 1) / TM;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * TM;
+        const int grow = (int)row0 + hrow;
+        const bool rvalid = grow < R;
+        const int e_row = rvalid ? grow / a.A : 0;
+        const int ag = grow - e_row * a.A;
+        const int eplen = rvalid ? a.ep_len[e_row] : 0;
+        float* hp = L.b[3];
+        float* hn = L.b[4];
+        // h_in -> hp
+        __syncthreads();
+        for (int i = tid; i < TM * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+        }
+        // ================================ forward over the chunk
+        for (int s = 0; s < CL; ++s) {
+            const int t = a.t0 + s;
+            gru_fwd_step<true>(L, a, off, a.obs + (long)t * din, (long)T * din, row0, R, hp, hn, a.ws_act + (s * R + row0) * WS_ACT);
+            // ---- PPO head on relu(h'): statistics + dlogits (saved for the backward sweep)
+            unsigned char avb[KJ];
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                avb[j] = 1;
+                if (rvalid && 4 * j + hq < K) avb[j] = a.avail[((long)grow * T + t) * K + 4 * j + hq];
+            }
+            float zreg[KJ];
+            gru_head_logits<KJ>(L, hn, K, avb, zreg);
+            {
+                const bool valid = rvalid && t < eplen;
+                const float invA = 1.0f / (float)a.A;
+                const long o = (long)grow * T + t;
+                const int act = rvalid ? a.action[o] : 0;
+                const float lpo = rvalid ? a.logp_old[o] : 0.f, advv = rvalid ? a.adv[o] : 0.f;
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
+                m = quad_max(m);
+                float ssum = 0.0f, pj[KJ];
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
+                ssum = quad_sum(ssum);
+                const float lse = m + logf(ssum), rs = 1.0f / ssum;
+                float ent = 0.f, lpa = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) {
+                    const float lp = zreg[j] - lse;
+                    pj[j] *= rs; ent -= pj[j] * lp;
+                    if (4 * j + hq == act) lpa = lp;
+                }
+                ent = quad_sum(ent); lpa = quad_sum(lpa);
+                const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
+                const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                float gsel;
+                if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
+                if (valid && hq == 0) {
+                    st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
+                    st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
+                    if (ag == 0) st_cnt += 1.f;
+                }
+                const float gr = gsel * ratio;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int k = 4 * j + hq;
+                    if (k < K && rvalid) {
+                        const float lp = zreg[j] - lse;
+                        float d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
+                        if (!valid || zreg[j] <= -5e8f) d = 0.f;
+                        a.ws_dl[(s * R + grow) * WS_DL + k] = d;
+                    }
+                }
+            }
+            float* tmp = hp; hp = hn; hn = tmp;
+        }
+        // h at the end of the chunk (detached carry for the next chunk)
+        __syncthreads();
+        if (a.h_out)
+            for (int i = tid; i < TM * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+            }
+        // ================================ backward through the chunk
+        float *DH = L.b[0], *W = L.b[1], *A1 = L.b[2], *HPV = L.b[3], *G0 = L.b[4], *G1 = L.b[5], *G2 = L.b[6], *G3 = L.b[7];
+        __syncthreads();
+        for (int i = tid; i < TM * LDT; i += NTHREADS) DH[i] = 0.0f;
+        for (int s = CL - 1; s >= 0; --s) {
+            const int t = a.t0 + s;
+            const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
+            // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
+            __syncthreads();
+            for (int i = tid; i < TM * KP; i += NTHREADS) {
+                const int r = i / KP, k = i - r * KP;
+                L.ls[r * LSP + k] = (row0 + r < R && k < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + k] : 0.0f;
+            }
+            for (int i = tid; i < TM * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                G3[r * LDT + c] = (row0 + r < R) ? fmaxf(wsS[(long)r * WS_ACT + 5 * HP + c], 0.0f) : 0.0f;
+            }
+            __syncthreads();
+            colred_head(accWo, L.ls + 32 * wm * LSP, G3 + 32 * wm * LDT + 32 * wn);
+            {
+                const int k = tid & 31, part = tid >> 5;
+                float sb = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) sb += L.ls[(part * 8 + r) * LSP + k];
+                dbo += sb;
+            }
+            {   // DH += (dlogits * W2) .* (h' > 0)
+                float dz[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dz[i] = 0.f;
+                for (int k0 = 0; k0 < K; k0 += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(L.ls + hrow * LSP + k0);
+                    const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(L.wouts + (k0 + q) * HP + 16 * hq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 w4 = wp4[i];
+                            dz[4 * i] = fmaf(dk[q], w4.x, dz[4 * i]); dz[4 * i + 1] = fmaf(dk[q], w4.y, dz[4 * i + 1]);
+                            dz[4 * i + 2] = fmaf(dk[q], w4.z, dz[4 * i + 2]); dz[4 * i + 3] = fmaf(dk[q], w4.w, dz[4 * i + 3]);
+                        }
+                    }
+                }
+                float* dp = DH + hrow * LDT + 16 * hq;
+                const float* gp = G3 + hrow * LDT + 16 * hq;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (gp[i] > 0.0f) dp[i] += dz[i];
+            }
+            __syncthreads();
+            // ---- B2: gate derivatives (elementwise, flat mapping), h_prev -> HPV, x1 -> A1
+            for (int i = tid; i < TM * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                float rr = 0.f, zz = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, x1 = 0.f;
+                if (row0 + r < R && c < H) {
+                    const float* w = wsS + (long)r * WS_ACT;
+                    x1 = w[c]; rr = w[HP + c]; zz = w[2 * HP + c]; nn = w[3 * HP + c]; ghn = w[4 * HP + c];
+                    if (s > 0) hprev = a.ws_act[((s - 1) * R + row0 + r) * WS_ACT + 5 * HP + c];
+                    else if (a.h_in) hprev = a.h_in[(row0 + r) * H + c];
+                }
+                const float dh = DH[r * LDT + c];
+                const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
+                const float dn_pre = dn * (1.0f - nn * nn);
+                const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+                const float dz_pre = dzg * zz * (1.0f - zz);
+                G0[r * LDT + c] = dr_pre; G1[r * LDT + c] = dz_pre; G2[r * LDT + c] = dn_pre; G3[r * LDT + c] = dn_pre * rr;
+                HPV[r * LDT + c] = hprev; A1[r * LDT + c] = x1;
+                DH[r * LDT + c] = dh * zz;
+            }
+            __syncthreads();
+            // ---- B3: weight gradients of the gates
+            colred(accWih[0], G0 + 32 * wm, A1 + 32 * wn);
+            colred(accWih[1], G1 + 32 * wm, A1 + 32 * wn);
+            colred(accWih[2], G2 + 32 * wm, A1 + 32 * wn);
+            colred(accWhh[0], G0 + 32 * wm, HPV + 32 * wn);
+            colred(accWhh[1], G1 + 32 * wm, HPV + 32 * wn);
+            colred(accWhh[2], G3 + 32 * wm, HPV + 32 * wn);
+            {
+                const int c = tid & 63, part = tid >> 6;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int r = 0; r < TM / 4; ++r) {
+                    const int o = (part * (TM / 4) + r) * LDT + c;
+                    s0 += G0[o]; s1 += G1[o]; s2 += G2[o]; s3 += G3[o];
+                }
+                dbg[0] += s0; dbg[1] += s1; dbg[2] += s2; dbg[3] += s3;
+            }
+            // ---- B4: dx1 = sum_g dgi_g * W_ih[g]   (.* relu'(x1), in place over A1)
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) {
+                __syncthreads();
+                stage_rows(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
+                __syncthreads();
+                rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G2) + 32 * wm * LDT, W + 32 * wn);
+            }
+            // ---- B5: dh_prev += sum_g dgh_g * W_hh[g]
+            f32x16 acch;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acch[g] = 0.f;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) {
+                __syncthreads();
+                stage_rows(W, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+                __syncthreads();
+                rowpar_tn(acch, (gate == 0 ? G0 : gate == 1 ? G1 : G3) + 32 * wm * LDT, W + 32 * wn);
+            }
+            __syncthreads();  // every wave is done with A1 (B3) and G* (B4/B5)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                float* p = A1 + row * LDT + col;
+                *p = (*p > 0.0f) ? acc[g] : 0.0f;
+                DH[row * LDT + col] += acch[g];
+            }
+            // ---- B6: fc1 weight gradient: obs tile -> G0
+            stage_rows(G0, a.obs + (long)t * din, row0, R, (long)T * din, 0, din);
+            __syncthreads();
+            colred(accW1, A1 + 32 * wm, G0 + 32 * wn);
+            {
+                const int c = tid & 63, part = tid >> 6;
+                float s0 = 0.f;
+#pragma unroll
+                for (int r = 0; r < TM / 4; ++r) s0 += A1[(part * (TM / 4) + r) * LDT + c];
+                db1 += s0;
+            }
+        }
+    }
+    // ================================ partial gradient + stats of this workgroup
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int n = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (n < H && col < din) out[off.W1 + n * din + col] = accW1[g];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (n < H && col < H) {
+                out[off.Wih + (q * H + n) * H + col] = accWih[q][g];
+                out[off.Whh + (q * H + n) * H + col] = accWhh[q][g];
+            }
+        }
+    }
+    {   // fc2 weight: combine the two wave-rows through LDS (activations are dead)
+        float* scr = L.b[0];
+        __syncthreads();
+        if (wm == 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) scr[(wn * 32 + (g & 3) + 8 * (g >> 2) + 4 * h) * 33 + lc] = accWo[g];
+        }
+        __syncthreads();
+        if (wm == 0) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (k < K && col < H) out[off.W2 + k * H + col] = accWo[g] + scr[(wn * 32 + k) * 33 + lc];
+            }
+        }
+        __syncthreads();
+        L.red[tid] = dbo;
+        __syncthreads();
+        if (tid < K) {
+            float sb = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sb += L.red[q * 32 + tid];
+            out[off.b2 + tid] = sb;
+        }
+    }
+    {   // column-sum biases: 4 row parts per column
+        float vals[5] = {db1, dbg[0], dbg[1], dbg[2], dbg[3]};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            __syncthreads();
+            L.red[(tid >> 6) * HP + (tid & 63)] = vals[q];
+            __syncthreads();
+            if (tid < H) {
+                const float sv = L.red[tid] + L.red[HP + tid] + L.red[2 * HP + tid] + L.red[3 * HP + tid];
+                if (q == 0) out[off.b1 + tid] = sv;
+                else if (q == 1) { out[off.bih + tid] = sv; out[off.bhh + tid] = sv; }                // r gate: d b_ir == d b_hr
+                else if (q == 2) { out[off.bih + H + tid] = sv; out[off.bhh + H + tid] = sv; }        // z gate
+                else if (q == 3) out[off.bih + 2 * H + tid] = sv;                                      // b_in
+                else out[off.bhh + 2 * H + tid] = sv;                                                  // b_hn (scaled by r)
+            }
+        }
+    }
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = cm_wave_sum(sv6[q]);
+        if (lane == 0) L.red[q * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < CM_NUM_STATS) {
+        float v = 0.f;
+        if (tid < 6) v = L.red[tid * 4] + L.red[tid * 4 + 1] + L.red[tid * 4 + 2] + L.red[tid * 4 + 3];
+        out[off.P + tid] = v;
+    }
+}
+
+// ============================================================================================ rollout step
+template <int KJ>
+__global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = KJ * 4;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    const GruLds L = gru_lds(smem, KP);
+    const int tid = threadIdx.x, hrow = tid >> 2, hq = tid & 3;
+    const int H = a.H, K = a.K;
+    gru_stage_consts(L, a, off, KP);
+    const long ntiles = (a.rows + TM - 1) / TM;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * TM;
+        float* hp = L.b[3];
+        float* hn = L.b[4];
+        __syncthreads();
+        for (int i = tid; i < TM * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            hp[r * LDT + c] = (row0 + r < a.rows && c < H) ? a.h[(row0 + r) * H + c] : 0.0f;
+        }
+        gru_fwd_step<false>(L, a, off, a.x, a.x_stride, row0, a.rows, hp, hn, nullptr);
+        for (int i = tid; i < TM * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            if (row0 + r < a.rows && c < H) a.h[(row0 + r) * H + c] = hn[r * LDT + c];
+        }
+        const long grow = row0 + hrow;
+        const bool rvalid = grow < a.rows;
+        unsigned char avb[KJ];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            avb[j] = 1;
+            if (rvalid && a.av && 4 * j + hq < K) avb[j] = a.av[grow * a.av_stride + 4 * j + hq];
+        }
+        float zreg[KJ];
+        gru_head_logits<KJ>(L, hn, K, avb, zreg);
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+            if (4 * j + hq < K) L.ls[hrow * LSP + 4 * j + hq] = zreg[j];
+        __syncthreads();
+        if (hq == 0 && rvalid) {  // same sampler as k_mlp<M_ACT>
+            const float* z = L.ls + hrow * LSP;
+            float m = -INFINITY;
+            for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
+            float s = 0.0f;
+            for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+            const float lse = m + logf(s);
+            const unsigned long long gr = (unsigned long long)(a.row_offset + grow);
+            const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)a.t, CM_STREAM_ACT,
+                                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const float u = cm_u01(rnd.x);
+            float cum = 0.0f;
+            int chosen = -1, last = 0;
+            for (int k = 0; k < K; ++k) {
+                if (z[k] > -5e8f) {
+                    cum += expf(z[k] - lse);
+                    last = k;
+                    if (chosen < 0 && u < cum) chosen = k;
+                }
+            }
+            if (chosen < 0) chosen = last;
+            a.action_out[grow * a.out_stride] = chosen;
+            a.logp_out[grow * a.out_stride] = z[chosen] - lse;
+        }
+    }
+}
+
+int gru_check(const char* who, int din, int H, int K) {
+    CM_REQUIRE(din > 0 && H > 0 && K > 0, "%s: bad dims din=%d H=%d K=%d", who, din, H, K);
+    CM_REQUIRE(H <= HP, "%s: hidden_dim=%d > %d is not supported by this build", who, H, HP);
+    CM_REQUIRE(din <= KC, "%s: obs width %d > %d is not supported by the GRU kernels of this build", who, din, KC);
+    CM_REQUIRE(K <= KMAX, "%s: n_actions=%d > %d is not supported by this build", who, K, KMAX);
+    return 0;
+}
+
+}  // namespace
+
+static size_t gru_ps(int din, int hidden, int K) {
+    return (size_t)((cm_gru_param_count(din, hidden, K) + CM_NUM_STATS + 63) / 64 * 64);
+}
+
+extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int n_actions, int chunk_len) {
+    const size_t R = (size_t)E * A;
+    return ((size_t)chunk_len * R * (WS_ACT + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
+}
+
+extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
+                                          const float* logp_old, const float* adv, const int32_t* ep_len,
+                                          int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                                          const float* params, const float* h_in, float* h_out,
+                                          double ppo_clip, double entropy_coef,
+                                          float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    if (int rc = gru_check("cm_gru_actor_chunk_fwd_bwd", din, hidden, n_actions)) return rc;
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T, "cm_gru_actor_chunk_fwd_bwd: bad dims E=%d A=%d T=%d t0=%d t1=%d", E, A, T, t0, t1);
+    const size_t need = cm_gru_workspace_bytes(E, A, din, hidden, n_actions, t1 - t0);
+    CM_REQUIRE(ws && ws_bytes >= need, "cm_gru_actor_chunk_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    const size_t R = (size_t)E * A;
+    const int CL = t1 - t0;
+    GruArgs a = {};
+    a.obs = obs; a.avail = avail; a.action = action; a.logp_old = logp_old; a.adv = adv; a.ep_len = ep_len;
+    a.E = E; a.A = A; a.T = T; a.t0 = t0; a.t1 = t1; a.din = din; a.H = hidden; a.K = n_actions;
+    a.params = params; a.h_in = h_in; a.h_out = h_out;
+    a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip; a.ent_coef = (float)entropy_coef;
+    a.ws_act = (float*)ws; a.ws_dl = a.ws_act + (size_t)CL * R * WS_ACT; a.partial = a.ws_dl + (size_t)CL * R * WS_DL;
+    a.PS = (int)gru_ps(din, hidden, n_actions);
+    const int grid = grid_for((long)R);
+    const size_t lds = gru_lds_bytes(n_actions);
+    if (n_actions <= 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_chunk<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_chunk<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    }
+    CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
+    MlpArgs m = {};
+    m.partial = a.partial; m.PS = a.PS;
+    return finish_train(m, grid, cm_gru_param_count(din, hidden, n_actions), grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
+}
+
+extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                                 int64_t rows, int din, int hidden, int n_actions, const float* params, float* h,
+                                 uint64_t seed, int64_t row_offset, int t,
+                                 int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream) {
+    if (int rc = gru_check("cm_gru_policy_act", din, hidden, n_actions)) return rc;
+    if (rows <= 0) return 0;
+    CM_REQUIRE(h != nullptr, "cm_gru_policy_act: hidden state pointer is NULL");
+    GruArgs a = {};
+    a.x = x; a.x_stride = x_row_stride; a.av = avail; a.av_stride = avail_row_stride; a.rows = rows; a.din = din; a.H = hidden;
+    a.K = n_actions; a.params = params; a.h = h; a.seed = seed; a.row_offset = row_offset; a.t = t;
+    a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
+    const size_t lds = gru_lds_bytes(n_actions);
+    const int grid = grid_for(rows);
+    if (n_actions <= 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_act<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_act<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_act<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_act<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    }
+    CM_CHECK_LAUNCH("cm_gru_policy_act");
+    return 0;
+}

@@ -1,0 +1,236 @@
+"""Training driver behind the four single-file scripts (mappo_multienvs.py, ippo_multienvs.py and the
+*_lstm_* pair).  Control flow follows the reference's ``__main__`` block (cleanmarl/mappo_multienvs.py:288-659):
+seed -> envs -> networks/optimisers -> writer -> while step < total_timesteps: rollout, TD(lambda), epochs of
+PPO, logging, periodic eval -> shutdown.  All numerics run in libcleanmarl_hip.so on the GPU.
+
+Multi-GPU: launched one process per GPU (torchrun); ``--batch_size`` environments are sharded over ranks and
+the only data-path collective is the per-optimiser-step all-reduce of the flat gradient buffer (learner.py).
+"""
+import datetime
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .args import parse_args
+from .env.vector import PipeVectorEnv, environment
+from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+from .logger import ScalarWriter
+from .rollout import SyntheticSpreadRollout
+
+RUN_PREFIX = {  # run-name strings of the four scripts (sic)
+    "mappo_multienvs": "MAPPO-multienvs", "ippo_multienvs": "IPPO-multienvs",
+    "mappo_lstm_multienvs": "MAPPO-lstm-multienv", "ippo_lstm_multienvs": "IPPO-lstm-multienvs",
+}
+
+
+class HostActor:
+    """Actor.act for observations that live on the host (real envs, eval): stage -> cm_policy_act -> fetch."""
+
+    def __init__(self, learner, n_agents, recurrent, device):
+        self.L, self.A, self.recurrent, self.dev = learner, n_agents, recurrent, device
+        self.lib = N.load()
+        self.calls = 0
+
+    def act(self, obs, avail, h=None, seed=0):
+        spec = self.L.actor_spec
+        x = torch.as_tensor(np.ascontiguousarray(obs), dtype=torch.float32).reshape(-1, spec.din).to(self.dev)
+        av = torch.as_tensor(np.ascontiguousarray(avail)).reshape(-1, spec.dout).to(torch.uint8).to(self.dev)
+        rows = x.shape[0]
+        action = torch.empty(rows, dtype=torch.int32, device=self.dev)
+        logp = torch.empty(rows, dtype=torch.float32, device=self.dev)
+        self.calls += 1
+        if self.recurrent:
+            if h is None:
+                h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
+            N.check(self.lib.cm_gru_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
+                                               N.ptr(self.L.actor), N.ptr(h), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                               N.stream_ptr()), "cm_gru_policy_act")
+        else:
+            N.check(self.lib.cm_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
+                                           spec.dout, N.ptr(self.L.actor), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                           N.stream_ptr()), "cm_policy_act")
+        return action.cpu().numpy(), logp.cpu().numpy(), h
+
+
+def host_rollout(venv, actor, E, A, seed, recurrent, device):
+    """One episode per env over the pipe protocol (cleanmarl/mappo_multienvs.py:393-453; GRU: hidden state
+    carried for alive envs only, cleanmarl/mappo_lstm_multienvs.py:406-433).  Returns (DeviceBatch, stats)."""
+    cont = venv.reset_all()
+    obs = np.stack([c["obs"] for c in cont]); avail = np.stack([c["avail_actions"] for c in cont])
+    state = np.stack([c["state"] for c in cont])
+    eps = [dict(obs=[], actions=[], logp=[], reward=[], state=[], avail=[]) for _ in range(E)]
+    alive = list(range(E))
+    ep_reward, ep_len, ep_info = [0.0] * E, [0] * E, [None] * E
+    h_all = None
+    while alive:
+        h_in = None
+        if recurrent and h_all is not None:
+            idx = torch.as_tensor(alive, device=device)
+            h_in = h_all.reshape(E, A, -1)[idx].reshape(len(alive) * A, -1).contiguous()
+        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed)
+        if recurrent:
+            if h_all is None:
+                h_all = h_out
+            else:
+                h_all.reshape(E, A, -1)[torch.as_tensor(alive, device=device)] = h_out.reshape(len(alive), A, -1)
+        act = act.reshape(len(alive), A); logp = logp.reshape(len(alive), A)
+        cont = venv.step(alive, [list(map(int, a)) for a in act])
+        nobs, nstate, navail, still = [], [], [], []
+        for i, j in enumerate(alive):
+            e, c = eps[j], cont[i]
+            e["obs"].append(obs[i]); e["actions"].append(act[i]); e["logp"].append(logp[i]); e["reward"].append(c["reward"])
+            e["state"].append(state[i]); e["avail"].append(avail[i])
+            ep_reward[j] += c["reward"]; ep_len[j] += 1
+            if c["done"] or c["truncated"]:
+                ep_info[j] = c.get("infos")
+            else:
+                still.append(j); nobs.append(c["next_obs"]); nstate.append(c["next_state"]); navail.append(c["avail_actions"])
+        alive = still
+        if alive:
+            obs, state, avail = np.stack(nobs), np.stack(nstate), np.stack(navail)
+    T = max(ep_len)
+    Do, Ds, K = eps[0]["obs"][0].shape[-1], eps[0]["state"][0].shape[-1], eps[0]["avail"][0].shape[-1]
+    b_obs = np.zeros((E, T, A, Do), np.float32); b_av = np.zeros((E, T, A, K), bool); b_act = np.zeros((E, T, A), np.int64)
+    b_lp = np.zeros((E, T, A), np.float32); b_rew = np.zeros((E, T), np.float32); b_st = np.zeros((E, T, Ds), np.float32)
+    b_mask = np.zeros((E, T), bool)
+    for j, e in enumerate(eps):  # zero-pad + mask: RolloutBuffer.get_batch, :109-142
+        n = ep_len[j]
+        b_obs[j, :n] = np.stack(e["obs"]); b_av[j, :n] = np.stack(e["avail"]).astype(bool); b_act[j, :n] = np.stack(e["actions"])
+        b_lp[j, :n] = np.stack(e["logp"]); b_rew[j, :n] = np.asarray(e["reward"], np.float32); b_st[j, :n] = np.stack(e["state"])
+        b_mask[j, :n] = True
+    t = torch.from_numpy
+    b = DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device)
+    return b, dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
+
+
+def run(script, argv=None):
+    args = parse_args(script, argv)
+    algo = "mappo" if script.startswith("mappo") else "ippo"
+    recurrent = "lstm" in script
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not str(args.device).startswith("cuda"):
+        raise N.NativeError(f"--device={args.device}: this build computes on MI355X only (cuda / cuda:N); there is no CPU path")
+    random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)  # :291-294
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        pg = torch.distributed.group.WORLD
+    E_glob = args.batch_size
+    E = E_glob // world + (1 if rank < E_glob % world else 0)  # env shard of this rank
+    env_offset = rank * (E_glob // world) + min(rank, E_glob % world)
+    synth = dict(agents=args.synthetic_agents, steps=args.synthetic_steps)
+    fac = dict(env_type=args.env_type, env_name=args.env_name, env_family=args.env_family, agent_ids=args.agent_ids,
+               kwargs={}, seed=args.seed, synthetic=synth)
+    eval_env = environment(**dict(fac, index=10 ** 6))
+    A, Do, Ds, K = eval_env.n_agents, eval_env.get_obs_size(), eval_env.get_state_size(), eval_env.get_action_size()
+
+    # networks in the reference's construction order actor -> critic (:329-339) so torch.manual_seed reproduces them
+    actor_spec = NetSpec(Do, args.actor_hidden_dim, 0 if recurrent else args.actor_num_layers, K, "gru" if recurrent else "mlp")
+    critic_spec = NetSpec(Ds if algo == "mappo" else Do, args.critic_hidden_dim, args.critic_num_layers, 1)
+    a_init, c_init = init_params_like_torch(actor_spec), init_params_like_torch(critic_spec)
+    hp = HParams.from_args(args)
+    if recurrent:
+        from .gru import GRUPPOLearner
+        learner = GRUPPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
+    else:
+        learner = PPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
+
+    device_env = args.env_type == "synthetic"
+    venv = roll = None
+    if device_env:
+        if recurrent:
+            from .gru import GRUSyntheticRollout
+            roll = GRUSyntheticRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
+                                       env_offset=env_offset)
+        else:
+            roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
+                                          env_offset=env_offset)
+    else:
+        venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
+    host_actor = HostActor(learner, A, recurrent, device)
+
+    time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+    run_name = f"{RUN_PREFIX[script]}-{args.env_type}__{args.env_name}__{time_token}"
+    writer = None
+    if rank == 0:
+        if args.use_wnb:
+            import wandb
+            wandb.init(project=args.wnb_project, entity=args.wnb_entity, sync_tensorboard=True, config=vars(args), name=run_name)
+        writer = ScalarWriter(f"runs/{run_name}")
+        writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % "\n".join(f"|{k}|{v}|" for k, v in vars(args).items()))
+
+    ep_rewards, ep_lengths, ep_stats = [], [], []
+    training_step = num_episodes = step = 0
+    while step < args.total_timesteps:
+        if device_env:
+            b = roll.collect(learner.actor, actor_spec)
+            rew = b.reward.sum(1).cpu().tolist()
+            stats = dict(ep_reward=rew, ep_len=[b.T] * E, infos=[None] * E)
+        else:
+            b, stats = host_rollout(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
+        n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
+        if world > 1:
+            torch.distributed.all_reduce(n_steps, group=pg)
+        step += int(n_steps.item())  # counts ENV steps, like the reference (:435)
+        ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
+        if args.env_type == "smaclite":
+            ep_stats.extend([i["battle_won"] for i in stats["infos"]])
+        num_episodes += E_glob
+        log_now = (training_step % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
+        if log_now:
+            if writer:
+                writer.add_scalar("rollout/ep_reward", np.mean(ep_rewards), step)
+                writer.add_scalar("rollout/ep_length", np.mean(ep_lengths), step)
+                writer.add_scalar("rollout/num_episodes", num_episodes, step)
+                if args.env_type == "smaclite":
+                    writer.add_scalar("rollout/battle_won", np.mean(ep_stats), step)
+            ep_rewards, ep_lengths, ep_stats = [], [], []
+
+        recs = learner.train_iteration(b)
+        training_step += len(recs)
+        if writer:  # train/* are means over epochs (:605-612)
+            m = lambda k: float(np.mean([r[k] for r in recs]))
+            writer.add_scalar("train/critic_loss", m("critic_loss"), step)
+            writer.add_scalar("train/actor_loss", m("actor_loss"), step)
+            writer.add_scalar("train/entropy", m("entropy"), step)
+            writer.add_scalar("train/kl_divergence", m("kl"), step)
+            writer.add_scalar("train/clipped_ratios", m("clipfrac"), step)
+            writer.add_scalar("train/actor_gradients", m("actor_gnorm"), step)
+            writer.add_scalar("train/critic_gradients", m("critic_gnorm"), step)
+            writer.add_scalar("train/num_updates", training_step, step)
+
+        if rank == 0 and (training_step / args.epochs) % args.eval_steps == 0:  # :614-650 (actions are SAMPLED)
+            eval_obs, _ = eval_env.reset()
+            rets, lens, infos_l, cur_r, cur_l, h_eval = [], [], [], 0.0, 0, None
+            while len(rets) < args.num_eval_ep:
+                act, _, h_eval = host_actor.act(eval_obs[None], np.asarray(eval_env.get_avail_actions())[None], h=h_eval,
+                                                seed=args.seed + 7919)
+                eval_obs, r, done, trunc, info = eval_env.step(act.reshape(-1))
+                cur_r += r; cur_l += 1
+                if done or trunc:
+                    eval_obs, _ = eval_env.reset()
+                    rets.append(cur_r); lens.append(cur_l); infos_l.append(info); cur_r, cur_l, h_eval = 0.0, 0, None
+            writer.add_scalar("eval/ep_reward", np.mean(rets), step)
+            writer.add_scalar("eval/std_ep_reward", np.std(rets), step)
+            writer.add_scalar("eval/ep_length", np.mean(lens), step)
+            if args.env_type == "smaclite":
+                writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
+
+    if writer:
+        writer.close()
+    if args.use_wnb and rank == 0:
+        import wandb
+        wandb.finish()
+    eval_env.close()
+    if venv:
+        venv.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return dict(step=step, training_step=training_step, history=writer.history if writer else [], learner=learner)

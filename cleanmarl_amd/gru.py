@@ -1,0 +1,118 @@
+"""GRU-actor variants (reference: cleanmarl/mappo_lstm_multienvs.py, cleanmarl/ippo_lstm_multienvs.py).
+
+GRUPPOLearner keeps the critic path of PPOLearner and replaces the actor update by the truncated-BPTT
+schedule of cleanmarl/mappo_lstm_multienvs.py:551-664: per epoch, h = None; for every chunk of `tbptt` steps
+one fused forward + backward-through-time launch (cm_gru_actor_chunk_fwd_bwd), one all-reduce (N > 1) and one
+Adam step with the chunk loss normalised by N_chunk * T_chunk (:605-607); h is carried detached (:620); the
+critic takes one step per epoch (:646-655).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from .learner import DeviceBatch, PPOLearner
+
+_GOLD = 0x9E3779B97F4A7C15
+
+
+class GRUPPOLearner(PPOLearner):
+    def __init__(self, algo, actor_spec, critic_spec, n_agents, hp, device, actor_params=None, critic_params=None,
+                 process_group=None, world_size=1):
+        assert actor_spec.kind == "gru"
+        super().__init__(algo, actor_spec, critic_spec, n_agents, hp, device, actor_params, critic_params, process_group, world_size)
+        self.gru_ws = None
+        self.h = [None, None]
+
+    def _ensure(self, b):
+        a = self.actor_spec
+        need = self.lib.cm_gru_workspace_bytes(b.E, b.A, a.din, a.hidden, a.dout, int(self.hp.tbptt))
+        if self.gru_ws is None or self.gru_ws.numel() < need:
+            self.gru_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.h[0] is None or self.h[0].shape[0] != b.E * b.A:
+            self.h = [torch.zeros(b.E * b.A, a.hidden, dtype=torch.float32, device=self.device) for _ in range(2)]
+
+    def update(self, b, keep_grads=False):
+        hp, s, a = self.hp, N.stream_ptr(), self.actor_spec
+        self._ensure(b)
+        Pa, Pc = self.actor.numel(), self.critic.numel()
+        T, tb = b.T, int(hp.tbptt)
+        chunks = [(t0, min(t0 + tb, T)) for t0 in range(0, T, tb)]
+        nE = int(hp.epochs)
+        rec_a = torch.zeros(nE, len(chunks), N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
+        rec_c = torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
+        kept = []
+        for ep in range(nE):
+            steps = []
+            h_in = None
+            for ci, (t0, t1) in enumerate(chunks):
+                h_out = self.h[ci & 1]
+                N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
+                    N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
+                    b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(self.actor), N.ptr(h_in), N.ptr(h_out),
+                    hp.ppo_clip, hp.entropy_coef, N.ptr(self.g_actor), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
+                    "cm_gru_actor_chunk_fwd_bwd")
+                self._allreduce(self.g_actor)
+                self._adam(self.actor, self.g_actor, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0))
+                rec_a[ep, ci, :N.NUM_STATS] = self.g_actor[Pa:]
+                rec_a[ep, ci, N.NUM_STATS] = self.norms[0]
+                if keep_grads:
+                    steps.append((self.g_actor[:Pa].clone(), self.actor.clone()))
+                h_in = h_out
+            self._timed("critic", self.critic_pass, b, s)
+            self._allreduce(self.g_critic)
+            self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
+            rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
+            rec_c[ep, N.NUM_STATS] = self.norms[1]
+            if keep_grads:
+                kept.append((steps, self.g_critic[:Pc].clone(), self.critic.clone()))
+        ra, rc = rec_a.cpu().double(), rec_c.cpu().double()  # single sync
+        out = []
+        for ep in range(nE):
+            tot = ra[ep, :, :N.NUM_STATS].sum(0)
+            n = float(tot[N.STAT_COUNT])
+            d = dict(actor_loss=float(-tot[N.STAT_PG] - hp.entropy_coef * tot[N.STAT_ENT]) / n,
+                     critic_loss=float(rc[ep, N.STAT_VLOSS]) / float(rc[ep, N.STAT_COUNT]),
+                     entropy=float(tot[N.STAT_ENT]) / n, kl=float(tot[N.STAT_KL]) / n, clipfrac=float(tot[N.STAT_CLIP]) / n,
+                     actor_gnorm=float(ra[ep, :, N.NUM_STATS].mean()), critic_gnorm=float(rc[ep, N.NUM_STATS]), n_valid=n)
+            if keep_grads:
+                d.update(actor_steps=kept[ep][0], critic_grads=kept[ep][1], critic_after=kept[ep][2])
+            out.append(d)
+        return out
+
+
+class GRUSyntheticRollout:
+    """Synthetic MPE-like env with the GRU actor: T x (cm_gru_policy_act, cm_synth_env_step), hidden state on
+    device (reference rollout: cleanmarl/mappo_lstm_multienvs.py:392-479, h = None at the start of each episode)."""
+
+    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0):
+        self.lib = N.load()
+        self.E, self.A, self.T, self.K = E, A, T, 5
+        self.agent_ids = bool(agent_ids)
+        self.Do, self.Ds = 6 * A + (A if agent_ids else 0), 6 * A * A
+        self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
+        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
+        self.batch.avail.fill_(1)
+        self.batch.ep_len.fill_(T)
+        self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
+        self.h = None
+        self.episode = 0
+
+    def collect(self, actor_flat, actor_spec, fused=None):
+        lib, b, s = self.lib, self.batch, N.stream_ptr()
+        E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        if self.h is None:
+            self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)
+        self.h.zero_()
+        N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,
+                                       self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
+        act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+        off = lambda t, nbytes: C.c_void_p(t.data_ptr() + nbytes)
+        for t in range(T):
+            N.check(lib.cm_gru_policy_act(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                          actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
+                                          off(b.action, 4 * t), off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
+            N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,
+                                          N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
+        self.episode += 1
+        return b

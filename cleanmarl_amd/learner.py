@@ -12,6 +12,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _native as N
+from . import dist
 
 
 @dataclass
@@ -173,8 +174,7 @@ class PPOLearner:
 
     # ------------------------------------------------------------------ helpers
     def _allreduce(self, t):
-        if self.world > 1:
-            torch.distributed.all_reduce(t, group=self.pg)
+        dist.allreduce_sum_(t, self.pg, self.world)
 
     def _moments(self, x, ep_len, E, A, T, s):
         """(count, mean, M2) of the agent-mean over valid steps; merged across ranks (Chan et al.)."""
@@ -183,13 +183,7 @@ class PPOLearner:
             self.mom_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.mom_ws),
                                            self.mom_ws.numel(), s), "cm_masked_moments")
-        if self.world > 1:
-            parts = [torch.zeros_like(self.moments) for _ in range(self.world)]
-            torch.distributed.all_gather(parts, self.moments, group=self.pg)
-            n = sum(p[0] for p in parts)
-            mean = sum(p[0] * p[1] for p in parts) / n
-            m2 = sum(p[2] + p[0] * (p[1] - mean) ** 2 for p in parts)
-            self.moments.copy_(torch.stack([n, mean, m2]))
+        dist.merge_moments_(self.moments, self.pg, self.world)
 
     # ------------------------------------------------------------------ a6 / a7
     def compute_targets(self, b):

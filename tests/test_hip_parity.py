@@ -266,3 +266,72 @@ def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L):
     assert (ba.reward[env_ok] - bb.reward[env_ok]).abs().max().item() <= 1e-4
     assert (ba.logp[env_ok] - bb.logp[env_ok]).abs().max().item() <= 1e-4
     assert (ra.env_state[env_ok] - rb.env_state[env_ok]).abs().max().item() <= 1e-5
+
+
+GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
+
+
+@pytest.mark.parametrize("name,algo", GRU_CASES)
+def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo):
+    """cm_gru_actor_chunk_fwd_bwd + TBPTT schedule vs the unmodified reference's mappo/ippo_lstm_multienvs.py."""
+    from oracle import restatement as R
+    from cleanmarl_amd.gru import GRUPPOLearner
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    dev = torch.device("cuda:0")
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"],
+                                          batch["states"], batch["avail"], batch["mask"], dev)
+    A = batch["obs"].shape[2]
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], tbptt=int(hp["tbptt"]),
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], 0, ap[-1].shape[0], "gru")
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = GRUPPOLearner(algo, aspec, cspec, A, H, dev, actor_params=ap, critic_params=cp)
+    recs = L.train_iteration(b, keep_grads=True)
+    assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), z["return_lambda"]) <= TOL
+    assert _err(b.adv.permute(0, 2, 1).cpu().numpy(), z["advantages"]) <= TOL
+    k = 0
+    for e, r in enumerate(recs):
+        assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL
+        assert _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+        assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
+        assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
+        assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
+        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
+        assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+        for g, after in r["actor_steps"]:
+            assert _err(g.cpu().numpy(), z["actor_grads"][k]) <= TOL, f"actor grad step {k}"
+            assert _err(after.cpu().numpy(), z["actor_after"][k]) <= TOL, f"actor params step {k}"
+            k += 1
+        assert _err(r["critic_grads"].cpu().numpy(), z["critic_grads"][e]) <= TOL
+        assert _err(r["critic_after"].cpu().numpy(), z["critic_after"][e]) <= TOL
+    assert k == len(z["actor_grads"])
+
+
+def test_gru_policy_act_matches_oracle():
+    from oracle import restatement as R
+    from oracle import sampling
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    rows, Do, Hd, K = 150, 35, 64, 5
+    spec = NetSpec(Do, Hd, 0, K, "gru")
+    p = init_params_like_torch(spec)
+    x = torch.randn(rows, Do); h0 = torch.randn(rows, Hd) * 0.5
+    avail = torch.rand(rows, K) < 0.6
+    avail[:, 1] = True
+    d_x, d_h, d_av, d_p = x.to(dev), h0.clone().to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
+    act = torch.empty(rows, dtype=torch.int32, device=dev); lp = torch.empty(rows, device=dev)
+    N.check(lib.cm_gru_policy_act(N.ptr(d_x), Do, N.ptr(d_av), K, rows, Do, Hd, K, N.ptr(d_p), N.ptr(d_h), 5, 77, 3,
+                                  N.ptr(act), N.ptr(lp), 1, N.stream_ptr()), "gru act")
+    logits, h1 = R.gru_actor_logits(p, x, h0, avail)
+    assert _err(d_h.cpu().numpy(), h1.numpy()) <= TOL
+    a_ref, lp_ref, _ = sampling.act(logits.numpy(), avail.numpy(), 5, 77, 3)
+    same = act.cpu().numpy() == a_ref
+    assert same.mean() >= 0.99
+    assert np.abs(lp.cpu().numpy()[same] - lp_ref[same]).max() <= TOL

@@ -1,0 +1,87 @@
+"""CPU tests of the host-side mirror of the reference interface: CLI defaults, pipe-protocol vector env,
+rollout collation into the device layout, the C-ABI library's exported symbols (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_defaults_match_reference_scripts():
+    from cleanmarl_amd.args import parse_args
+    a = parse_args("mappo_multienvs", [])
+    # cleanmarl/mappo_multienvs.py:18-79 (device differs on purpose: this build is GPU-only)
+    exp = dict(env_type="smaclite", env_name="3m", env_family="mpe", agent_ids=True, batch_size=3, actor_hidden_dim=32,
+               actor_num_layers=1, critic_hidden_dim=64, critic_num_layers=1, optimizer="Adam", learning_rate_actor=0.0008,
+               learning_rate_critic=0.0008, total_timesteps=1000000, gamma=0.99, td_lambda=0.95, normalize_reward=False,
+               normalize_advantage=False, normalize_return=False, epochs=3, ppo_clip=0.2, entropy_coef=0.001, clip_gradients=-1,
+               log_every=10, eval_steps=50, num_eval_ep=10, use_wnb=False, wnb_project="", wnb_entity="", seed=1)
+    for k, v in exp.items():
+        assert getattr(a, k) == v, k
+    assert parse_args("ippo_multienvs", []).critic_hidden_dim == 32            # cleanmarl/ippo_multienvs.py:34
+    m = parse_args("mappo_lstm_multienvs", [])
+    assert (m.tbptt, m.num_eval_ep, m.optimizer) == (10, 5, "Adam")            # cleanmarl/mappo_lstm_multienvs.py:64,70
+    i = parse_args("ippo_lstm_multienvs", [])
+    assert (i.tbptt, i.num_eval_ep, i.optimizer, i.critic_hidden_dim) == (5, 10, "AdamW", 32)  # ippo_lstm :38,66
+    b = parse_args("mappo_multienvs", ["--env_type=pz", "--env-name", "simple_spread_v3", "--batch_size", "4",
+                                       "--normalize_reward", "--no-agent_ids", "--clip_gradients=0.5", "--use_wnb=False"])
+    assert (b.env_type, b.env_name, b.batch_size, b.normalize_reward, b.agent_ids, b.clip_gradients) == \
+        ("pz", "simple_spread_v3", 4, True, False, 0.5)
+
+
+def test_pipe_vector_env_and_collation():
+    from cleanmarl_amd.driver import host_rollout
+    from cleanmarl_amd.env.synthetic import SyntheticSpreadEnv
+    from cleanmarl_amd.env.vector import PipeVectorEnv
+    E, A, T = 3, 2, 5
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=3,
+               synthetic=dict(agents=A, steps=T))
+    venv = PipeVectorEnv(E, fac)
+    assert venv.info() == {"obs_size": 7 * A, "action_size": 5, "n_agents": A, "state_size": 6 * A * A}
+    rng = np.random.default_rng(0)
+    script = rng.integers(0, 5, size=(T, E * A))
+
+    class Stub:  # stands in for the on-device actor: deterministic scripted actions
+        t = 0
+
+        def act(self, obs, avail, h=None, seed=0):
+            a = script[self.t][:obs.shape[0] * A]
+            self.t += 1
+            return a.astype(np.int32), np.full(a.shape, -1.5, np.float32), None
+
+    b, stats = host_rollout(venv, Stub(), E, A, 0, False, torch.device("cpu"))
+    venv.close()
+    assert b.obs.shape == (E, A, T, 7 * A) and b.ep_len.tolist() == [T] * E and stats["ep_len"] == [T] * E
+    for e in range(E):
+        env = SyntheticSpreadEnv(A, True, max_cycles=T, seed=3, env_index=e)
+        o, _ = env.reset()
+        tot = 0.0
+        for t in range(T):
+            assert np.allclose(b.obs[e, :, t].numpy(), o) and np.allclose(b.state[e, t].numpy(), env.get_state())
+            acts = script[t][e * A:(e + 1) * A]
+            assert b.action[e, :, t].tolist() == list(acts)
+            o, r, d, tr, _ = env.step(acts)
+            assert abs(b.reward[e, t].item() - r) < 1e-6
+            tot += r
+        assert abs(stats["ep_reward"][e] - tot) < 1e-5
+    assert b.avail.all() and (b.logp == -1.5).all()
+
+
+def test_library_exports_every_declared_symbol():
+    """include/cleanmarl_hip.h <-> libcleanmarl_hip.so <-> ctypes table stay in sync (no GPU needed)."""
+    from cleanmarl_amd import _native
+    from cleanmarl_amd.build import build_native
+    build_native()  # no-op when up to date; hipcc cross-compiles for gfx950 without a GPU
+    hdr = open(os.path.join(ROOT, "include", "cleanmarl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _native.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _native.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_native.SIGNATURES) == declared
+    assert lib.cm_version() >= 100
+    assert lib.cm_mlp_param_count(56, 64, 1, 5) == 56 * 64 + 64 + 64 * 64 + 64 + 5 * 64 + 5
