@@ -140,6 +140,15 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "flop_per_launch": flop_actor},
         }
+        # HBM bytes of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read
+        # live here); tools/pmc_summary.py writes them to profiles/pmc_dominant_kernel.json
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+        if os.path.exists(pmc_path) and args.workload == "cfg3" and not args.envs:
+            pmc = json.load(open(pmc_path))
+            out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = pmc["source"]
+            out["roofline"]["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
+            out["roofline"]["algorithmic_bytes_per_launch"] = rows_a * (4 * aspec.din + roll.K + 12)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import reference_loop  # checker / baseline only -- never part of the measured path
             Ec = args.cpu_envs
