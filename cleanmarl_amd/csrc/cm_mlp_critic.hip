@@ -18,7 +18,7 @@ extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
-    const int grid = grid_for(a.rows);
+    const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
     if (int rc = launch_train<M_CRITIC>(a, grid, lds_bytes, (hipStream_t)stream)) return rc;
     CM_CHECK_LAUNCH("cm_critic_fwd_bwd");

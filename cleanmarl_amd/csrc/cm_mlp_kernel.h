@@ -29,12 +29,12 @@ constexpr int KC = 64;    // input chunk width
 constexpr int LDT = 68;   // LDS row stride in floats (4*17: conflict-free ds_read_b128 down a column of rows)
 constexpr int LMAX = 2;   // max hidden->hidden layers (kernels are compiled for LCAP = 1 or 2)
 constexpr int KMAX = 32;  // max head width
-constexpr int LSP = 36;   // row stride of the per-row head scratch (logits / dlogits), >= KMAX, zero padded
+constexpr int LSP = 32;   // row stride of the per-row head scratch (logits / dlogits) = KMAX, zero padded
 constexpr int KJMAX = KMAX / 4;  // head outputs owned per lane (4 lanes per row); kernels compiled for KJ = 2 or 8
 constexpr int NTHREADS = 256;
-#ifndef CM_MLP_WAVES_PER_SIMD
-#define CM_MLP_WAVES_PER_SIMD 1
-#endif
+// Workgroups per CU: two independent workgroups overlap each other's VALU and MFMA phases (needs <= 80 KB of LDS
+// and <= 256 registers); kernels with many layer-0 gradient chunks keep one workgroup per CU and 512 registers.
+constexpr int wgs_per_cu(int nch) { return nch <= 2 ? 2 : 1; }
 
 enum Mode { M_FWD = 0, M_ACT = 1, M_ACTOR = 2, M_CRITIC = 3 };
 
@@ -72,14 +72,16 @@ __host__ __device__ inline Offsets make_offsets(int din, int H, int L, int dout)
 // LDS carve (floats)
 struct Lds {
     int Xs, W0s, Hs0, Ws, wout, b0, bl0, bout, ls, red, total;
-    __host__ __device__ int Hs(int l) const { return Hs0 + l * TM * LDT; }
+    // hidden layer 1's activations live in the X buffer: X is dead once layer 0 has consumed it and is
+    // re-streamed (L2 hit) for the layer-0 weight gradient -- this is what gets the footprint under 80 KB
+    __host__ __device__ int Hs(int l) const { return l == 0 ? Hs0 : (l == 1 ? Xs : Hs0 + (l - 1) * TM * LDT); }
     __host__ __device__ int bl(int l) const { return bl0 + l * HP; }
 };
 __host__ __device__ inline Lds make_lds(int L, int dout) {
     Lds s; int p = 0;
     s.Xs = p; p += TM * LDT;
     s.W0s = p; p += HP * LDT;
-    s.Hs0 = p; p += (L + 1) * TM * LDT;
+    s.Hs0 = p; p += (L >= 1 ? L : 1) * TM * LDT;
     s.Ws = p; if (L > 0) p += HP * LDT;
     s.wout = p; p += ((dout + 3) & ~3) * HP;  // rows >= dout are zero
     s.b0 = p; p += HP;
@@ -87,7 +89,7 @@ __host__ __device__ inline Lds make_lds(int L, int dout) {
     s.bout = p; p += KMAX;
     s.ls = p; p += TM * LSP;
     p = (p + 3) & ~3;
-    s.red = p; p += 4 * HP;
+    s.red = p; p += 4 * HP;  // 256 floats
     s.total = p;
     return s;
 }
@@ -261,7 +263,7 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
 template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
 
 template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
-__global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const MlpArgs a) {
+__global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool TRAIN = (MODE == M_ACTOR || MODE == M_CRITIC);
     constexpr int NC = (NCH > 0 ? NCH : 1);
@@ -271,8 +273,9 @@ __global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const M
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
     const int H = a.H, L = a.L, dout = a.dout, din = a.din;
     const int nch = (din + KC - 1) / KC;
-    const bool w0_resident = (nch == 1);
-    const bool ws_resident = (L == 1);
+    // compile-time for the training instantiations so the streaming paths (and their registers) vanish
+    const bool w0_resident = (NCH > 0) ? (NCH == 1) : (nch == 1);
+    const bool ws_resident = (LCAP == 1) || (L == 1);
     float* Xs = smem + lds.Xs;
     float* W0s = smem + lds.W0s;
     float* Ws = smem + lds.Ws;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const M
     for (int i = tid; i < KMAX; i += NTHREADS) smem[lds.bout + i] = (i < dout) ? a.params[off.bout + i] : 0.0f;
     for (int i = tid; i < TM * LSP; i += NTHREADS) ls[i] = 0.0f;  // columns >= dout stay zero (MFMA operand padding)
     if (w0_resident) stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
-    if (ws_resident) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+    if (ws_resident && L >= 1) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
 
     // ---- persistent accumulators (training)
     f32x16 accW0[NC];
@@ -352,10 +355,11 @@ __global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const M
             {
                 const bool last = (c + 1 == nch);
                 const int cn = last ? 0 : c + 1;
-                const long r0n = last ? ((TRAIN && NCH > 1) ? row0 : next_row0) : row0;
+                const bool again = TRAIN && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
+                const long r0n = last ? (again ? row0 : next_row0) : row0;
                 const int wn_ = min(KC, din - cn * KC);
                 tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
-                if (!w0_resident && !(last && TRAIN && NCH > 1)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
+                if (!w0_resident && !(last && TRAIN)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
             }
             if (c == 0) {
                 // per-row head inputs: issued here, consumed (raw) only in the head phases after the MFMA layers
@@ -610,11 +614,12 @@ __global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const M
                 float4* hp4 = reinterpret_cast<float4*>(HL + hrow * LDT + 16 * hq);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    const float4 hv = hp4[i];  // relu mask re-read from LDS (cheaper than 16 live registers)
                     float4 v;
-                    v.x = hreg[4 * i] > 0.0f ? dz[4 * i] : 0.0f;
-                    v.y = hreg[4 * i + 1] > 0.0f ? dz[4 * i + 1] : 0.0f;
-                    v.z = hreg[4 * i + 2] > 0.0f ? dz[4 * i + 2] : 0.0f;
-                    v.w = hreg[4 * i + 3] > 0.0f ? dz[4 * i + 3] : 0.0f;
+                    v.x = hv.x > 0.0f ? dz[4 * i] : 0.0f;
+                    v.y = hv.y > 0.0f ? dz[4 * i + 1] : 0.0f;
+                    v.z = hv.z > 0.0f ? dz[4 * i + 2] : 0.0f;
+                    v.w = hv.w > 0.0f ? dz[4 * i + 3] : 0.0f;
                     hp4[i] = v;
                 }
             }
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(NTHREADS, CM_MLP_WAVES_PER_SIMD) void k_mlp(const M
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    if (NCH > 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
+                    if (NCH > 1 || L >= 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
                         __syncthreads();
                         tile_store<VEC>(Xs, px);
                         const bool last = (c + 1 == NCH);
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     out[i] = (s0 + s1) + (s2 + s3);
 }
 
-constexpr int MAX_GRID = 256;  // one persistent workgroup per CU (LDS-limited)
+constexpr int MAX_GRID = 512;  // persistent workgroups: up to two per CU
 
 inline int check_shapes(const char* who, int din, int H, int L, int dout) {
     CM_REQUIRE(din > 0 && H > 0 && L >= 0 && dout > 0, "%s: bad dims din=%d H=%d L=%d dout=%d", who, din, H, L, dout);
@@ -796,9 +801,10 @@ inline int check_rows(const char* who, long rows) {
     return 0;
 }
 
-inline int grid_for(long rows) {
-    long nt = (rows + TM - 1) / TM;
-    return (int)(nt < MAX_GRID ? nt : MAX_GRID);
+inline int grid_for(long rows, int nch = 0) {
+    const long nt = (rows + TM - 1) / TM;
+    const long cap = 256L * wgs_per_cu(nch);
+    return (int)(nt < cap ? nt : cap);
 }
 
 // 16-byte loads need 16-byte aligned rows of both the activations and W0 (row stride din)
