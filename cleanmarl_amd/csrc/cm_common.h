@@ -40,6 +40,30 @@ __host__ __device__ inline float cm_u01(uint32_t x) { return (float)(x >> 8) * (
 
 enum { CM_STREAM_ACT = 1, CM_STREAM_ENV_RESET = 2, CM_STREAM_ENV_STEP = 3 };
 
+// Categorical(logits).sample() + log_prob (cleanmarl/mappo_multienvs.py:172-176) by inverse CDF on one uniform u.
+// z: K logits already masked with -1e9 (entries <= -5e8 count as unavailable).  One exp per action:
+// e_k = exp(z_k - max), s = sum e_k, pick the first available k with u*s < e_0 + ... + e_k.  Shared by every
+// act kernel (and mirrored by oracle/sampling.py) so the fused rollout and the per-step path agree.
+__device__ __forceinline__ void cm_categorical_sample(const float* z, int K, float u, int* action, float* logp) {
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+    const float thr = u * s;
+    float cum = 0.0f;
+    int chosen = -1, last = 0;
+    for (int k = 0; k < K; ++k) {
+        if (z[k] > -5e8f) {
+            cum += expf(z[k] - m);
+            last = k;
+            if (chosen < 0 && thr < cum) chosen = k;
+        }
+    }
+    if (chosen < 0) chosen = last;
+    *action = chosen;
+    *logp = z[chosen] - (m + logf(s));
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float cm_wave_sum(float v) {
 #pragma unroll

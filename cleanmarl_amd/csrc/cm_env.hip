@@ -95,14 +95,14 @@ __global__ __launch_bounds__(256) void k_env_step(float* __restrict__ env_state,
                 float best = 3.0e38f;
                 for (int j = 0; j < A; ++j) {
                     const float dx = pos[2 * j] - lm[2 * l], dy = pos[2 * j + 1] - lm[2 * l + 1];
-                    best = fminf(best, sqrtf(dx * dx + dy * dy));
+                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
                 }
                 r -= best;
             }
             for (int j = 0; j < A; ++j)
                 for (int q = j + 1; q < A; ++q) {
                     const float dx = pos[2 * j] - pos[2 * q], dy = pos[2 * j + 1] - pos[2 * q + 1];
-                    if (sqrtf(dx * dx + dy * dy) < COLLIDE) r -= 1.0f;
+                    if (__builtin_amdgcn_sqrtf(dx * dx + dy * dy) < COLLIDE) r -= 1.0f;
                 }
             reward[e * (long)T + t] = r;
         }

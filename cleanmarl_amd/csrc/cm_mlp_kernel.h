@@ -469,28 +469,13 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         // ================= per-row head math: lane hq == 0 of every row =================
         if (MODE == M_ACT) {
             if (hq == 0 && rvalid) {
-                float* z = ls + hrow * lstride;
-                float m = -INFINITY;
-                for (int k = 0; k < dout; ++k) m = fmaxf(m, z[k]);
-                float s = 0.0f;
-                for (int k = 0; k < dout; ++k) s += expf(z[k] - m);
-                const float lse = m + logf(s);
                 const unsigned long long gr = (unsigned long long)(a.row_offset + grow);
                 const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)a.t, CM_STREAM_ACT,
                                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-                const float u = cm_u01(rnd.x);
-                float cum = 0.0f;
-                int chosen = -1, last = 0;
-                for (int k = 0; k < dout; ++k) {
-                    if (z[k] > -5e8f) {
-                        cum += expf(z[k] - lse);
-                        last = k;
-                        if (chosen < 0 && u < cum) chosen = k;
-                    }
-                }
-                if (chosen < 0) chosen = last;
+                int chosen; float lp;
+                cm_categorical_sample(ls + hrow * lstride, dout, cm_u01(rnd.x), &chosen, &lp);
                 a.action_out[(long)grow * a.out_stride] = chosen;
-                a.logp_out[(long)grow * a.out_stride] = z[chosen] - lse;
+                a.logp_out[(long)grow * a.out_stride] = lp;
             }
             continue;
         }

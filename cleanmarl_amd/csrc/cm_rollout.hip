@@ -11,6 +11,9 @@
 // trip, no per-step launch.  The per-step kernels (cm_policy_act + cm_synth_env_step) remain the C-ABI for
 // real / host-side environments and are the parity reference for this kernel (tests/test_hip_parity.py).
 #include "cm_mlp_kernel.h"
+#ifdef CM_PHASE_PROF
+extern unsigned long long* g_prof;
+#endif
 
 namespace {
 
@@ -23,6 +26,7 @@ struct RolloutArgs {
     long env_offset, episode;
     const float* params; int din, H, L, K;
     float* obs; float* state; int* action; float* logp; float* reward;
+    unsigned long long* prof;
 };
 
 // feature f of agent i's observation (cm_env.hip write_obs order)
@@ -68,6 +72,9 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     float* evel = epos + TM * 2;
     float* elm = evel + TM * 2;          // [EPT*A][2] landmarks of env el at elm + el*2A
     int* eact = reinterpret_cast<int*>(elm + TM * 2);  // [TM]
+    long* obase = reinterpret_cast<long*>(eact + TM);  // [TM] obs row base (elements), -1 = dead row
+    long* sbase = obase + TM;                          // [TM] state row base
+    float* rscr = reinterpret_cast<float*>(sbase + TM);  // [2][TM] reward partials
 
     for (int i = tid; i < 8 * HP; i += NTHREADS) {
         const int k = i / HP, c = i % HP;
@@ -83,10 +90,18 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
 
     const int ntiles = (a.E + EPT - 1) / EPT;
     const int hrow = tid >> 2, hq = tid & 3;
+    PH_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * EPT;
         __syncthreads();
         // ---------------- reset (cm_env.hip k_env_reset): thread per (env, agent) row
+        if (tid < TM) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
+            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+        }
         if (tid < RT) {
             const int el = tid / A, i = tid - el * A;
             const int e = e0 + el;
@@ -103,28 +118,53 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
         }
         for (int t = 0; t < T; ++t) {
             __syncthreads();
+            PH(0);
             // ---------------- observations of step t -> Xs (4 lanes per row, features f = hq, hq+4, ...)
-            {
+            {   // 4 lanes per row: lane hq handles entities j = hq, hq+4, ... (landmark j, other agent j, id j)
                 const int el = hrow / A, i = hrow - el * A;
                 const bool live = hrow < RT && (e0 + el) < a.E;
+                float* xr = Xs + hrow * LDT;
+                if (live) {
+                    const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
+                    const float px = pos[2 * i], py = pos[2 * i + 1];
+                    if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
+                    for (int j = hq; j < A; j += 4) {
+                        xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                        if (j != i) {
+                            const int jj = j < i ? j : j - 1;
+                            xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
+                            xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                        }
+                        if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
+                    }
+                    for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;  // MFMA chunk padding (H1 recycles this buffer)
+                } else {
 #pragma unroll
-                for (int j = 0; j < KC / 4; ++j) {
-                    const int f = 4 * j + hq;
-                    Xs[hrow * LDT + f] = live ? obs_feature(f, i, A, epos + el * 2 * A, evel + el * 2 * A, elm + el * 2 * A, a.agent_ids) : 0.0f;
+                    for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
                 }
             }
             __syncthreads();
+            PH(1);
             // ---------------- rollout-buffer writes (coalesced along the feature axis)
 #pragma unroll 4
-            for (int idx = tid; idx < TM * KC; idx += NTHREADS) {
-                const int r = idx >> 6, c = idx & 63;
-                const int el = r / A, i = r - el * A;
-                const long e = e0 + el;
-                if (r < RT && e < a.E) {
-                    const float v = Xs[r * LDT + c];
-                    if (c < din) a.obs[((e * A + i) * (long)T + t) * din + c] = v;
-                    if (c < 6 * A) a.state[(e * (long)T + t) * Ds + i * 6 * A + c] = v;
+            for (int r = wave; r < TM; r += 4) {  // wave-uniform row; lane = feature column
+                const long ob = obase[r];
+                if (ob >= 0) {
+                    const float v = Xs[r * LDT + lane];
+                    if (lane < din) a.obs[ob + (long)t * din + lane] = v;
+                    if (lane < 6 * A) a.state[sbase[r] + (long)t * Ds + lane] = v;
                 }
+            }
+            PH(2);
+            // the step's uniform does not depend on the logits: issue the Philox rounds here so they interleave with
+            // the MFMA chain below instead of extending the serial sampling phase
+            float u_row = 0.0f;
+            if (tid < RT) {
+                const int el = tid / A, i = tid - el * A;
+                const unsigned long long gr = (unsigned long long)((a.env_offset + e0 + el) * A + i);
+                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
+                                                (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                u_row = cm_u01(rnd.x);
             }
             // ---------------- actor forward, layer 0
             f32x16 acc;
@@ -154,6 +194,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 HL = Xs;
                 __syncthreads();
             }
+            PH(3);
             // ---------------- head: logits (4 lanes per row x 16 hidden columns), all K actions available
             {
                 float hreg[16];
@@ -180,31 +221,17 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 }
             }
             __syncthreads();
+            PH(4);
             // ---------------- Categorical sample + log_prob (same arithmetic as k_mlp<M_ACT>), then physics
             if (tid < RT) {
                 const int el = tid / A, i = tid - el * A;
                 const long e = e0 + el;
                 if (e < a.E) {
-                    const float* z = ls + tid * 8;
-                    float m = -INFINITY;
-                    for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
-                    float s = 0.0f;
-                    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
-                    const float lse = m + logf(s);
-                    const unsigned long long gr = (unsigned long long)((a.env_offset + e) * A + i);
-                    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
-                                                    (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
-                    const float u = cm_u01(rnd.x);
-                    float cum = 0.0f;
-                    int chosen = -1;
-                    for (int k = 0; k < K; ++k) {
-                        cum += expf(z[k] - lse);
-                        if (chosen < 0 && u < cum) chosen = k;
-                    }
-                    if (chosen < 0) chosen = K - 1;
+                    int chosen; float lpv;
+                    cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
                     const long o = (e * A + i) * (long)T + t;
                     a.action[o] = chosen;
-                    a.logp[o] = z[chosen] - lse;
+                    a.logp[o] = lpv;
                     // point-mass physics (cm_env.hip k_env_step)
                     const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
                     const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);
@@ -215,26 +242,32 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 }
             }
             __syncthreads();
+            PH(5);
             // ---------------- team reward of step t: one thread per env
-            if (tid < EPT && e0 + tid < a.E) {
-                const float* pos = epos + tid * 2 * A;
-                const float* lm = elm + tid * 2 * A;
-                float r = 0.0f;
-                for (int l = 0; l < A; ++l) {
-                    float best = 3.0e38f;
-                    for (int j = 0; j < A; ++j) {
-                        const float dx = pos[2 * j] - lm[2 * l], dy = pos[2 * j + 1] - lm[2 * l + 1];
-                        best = fminf(best, sqrtf(dx * dx + dy * dy));
+            if (tid < RT) {  // thread (env el, index l): nearest agent to landmark l, and collisions of agent l with q > l
+                const int el = tid / A, l = tid - el * A;
+                const float* pos = epos + el * 2 * A;
+                const float lx = elm[2 * tid], ly = elm[2 * tid + 1];
+                const float qx = pos[2 * l], qy = pos[2 * l + 1];
+                float best = 3.0e38f, col = 0.0f;
+                for (int j = 0; j < A; ++j) {
+                    const float dx = pos[2 * j] - lx, dy = pos[2 * j + 1] - ly;
+                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
+                    if (j > l) {
+                        const float cx = qx - pos[2 * j], cy = qy - pos[2 * j + 1];
+                        if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < COLLIDE) col += 1.0f;
                     }
-                    r -= best;
                 }
-                for (int j = 0; j < A; ++j)
-                    for (int q = j + 1; q < A; ++q) {
-                        const float dx = pos[2 * j] - pos[2 * q], dy = pos[2 * j + 1] - pos[2 * q + 1];
-                        if (sqrtf(dx * dx + dy * dy) < COLLIDE) r -= 1.0f;
-                    }
+                rscr[tid] = best; rscr[TM + tid] = col;
+            }
+            __syncthreads();
+            if (tid < EPT && e0 + tid < a.E) {
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+                for (int l = 0; l < A; ++l) r -= rscr[TM + tid * A + l];
                 a.reward[(long)(e0 + tid) * T + t] = r;
             }
+            PH(6);
         }
         __syncthreads();
         // ---------------- final env state back to global (pos | vel | landmarks)
@@ -249,6 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             }
         }
     }
+    PH_FLUSH;
 }
 
 }  // namespace
@@ -269,9 +303,12 @@ extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agen
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0);
     a.H = hidden; a.L = n_hidden_layers; a.K = 5;
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+#ifdef CM_PHASE_PROF
+    a.prof = g_prof;
+#endif
     const int EPT = TM / A;
     const int ntiles = (E + EPT - 1) / EPT;
-    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 8 * HP + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM;
+    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 8 * HP + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM + 4 * TM + 2 * TM;
     const size_t lds_bytes = lds_floats * sizeof(float);
     const int grid = ntiles < 512 ? ntiles : 512;  // <= 80 KB of LDS: two workgroups per CU overlap each other's latencies
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

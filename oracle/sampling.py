@@ -16,16 +16,20 @@ def act(logits, avail, seed, row_offset, t):
                             np.uint32(t), np.uint32(STREAM_ACT), k0, k1)
     u = u01(x)
     m = logits.max(1, keepdims=True)
-    lse = m + np.log(np.exp(logits - m).sum(1, keepdims=True, dtype=np.float32))
-    p = np.exp(logits - lse).astype(np.float32)
+    e = np.exp(logits - m).astype(np.float32)
+    ssum = np.zeros(R, np.float32)
+    for k in range(K):  # serial fp32 sum, like the kernel
+        ssum = (ssum + e[:, k]).astype(np.float32)
+    thr = (u * ssum).astype(np.float32)
     action = np.zeros(R, np.int64)
     for r in range(R):
         cum, chosen, last = np.float32(0), -1, 0
         for k in range(K):
             if logits[r, k] > -5e8:
-                cum = np.float32(cum + p[r, k]); last = k
-                if chosen < 0 and u[r] < cum:
+                cum = np.float32(cum + e[r, k]); last = k
+                if chosen < 0 and thr[r] < cum:
                     chosen = k
         action[r] = chosen if chosen >= 0 else last
-    logp = (logits - lse)[np.arange(R), action]
+    lse = (m[:, 0] + np.log(ssum)).astype(np.float32)
+    logp = logits[np.arange(R), action] - lse
     return action, logp.astype(np.float32), u

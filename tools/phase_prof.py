@@ -34,6 +34,14 @@ if which == "actor":
     ws = torch.empty(lib.cm_mlp_train_workspace_bytes(Do, 64, 1, K), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_ppo_actor_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lp), N.ptr(adv), N.ptr(ep_len),
                                                   E, A, T, Do, 64, 1, K, N.ptr(p), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "actor")
+elif which == "rollout":
+    from cleanmarl_amd.rollout import SyntheticSpreadRollout
+    prof = torch.zeros(512, 16, dtype=torch.int64, device=dev)
+    lib.cm_prof_set_buffer(C.c_void_p(prof.data_ptr()))
+    spec = NetSpec(Do, 64, 1, K)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    roll = SyntheticSpreadRollout(E, A, T, seed=1, device=dev)
+    run = lambda: roll.collect(p, spec, fused=True)
 else:
     spec = NetSpec(Ds, 64, 1, 1)
     p = flatten_params(init_params_like_torch(spec), dev)
@@ -50,6 +58,13 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 ph = prof.double().mean(0).cpu()
 tot = float(ph.sum())
+if which == "rollout":
+    ph = prof.double().mean(0).cpu(); tot = float(ph.sum())
+    print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase (512 WGs, 1 tile each):")
+    for i, n in enumerate(["barrier_top", "obs_features", "buffer_writes", "fwd_mlp", "head_logits", "sample+physics", "reward"]):
+        print(f"  {n:24s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+    print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
+    sys.exit(0)
 names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
 rows = (E * A * T) if which == "actor" else E * T
 tiles_per_wg = rows / 64 / 256
