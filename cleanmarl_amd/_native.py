@@ -36,6 +36,7 @@ SIGNATURES = {
     "cm_normalize": (_i, [_p, _p, _i, _i, _i, _p, _f, _i, _p]),
     "cm_mlp_train_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "cm_ppo_actor_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),
+    "cm_critic_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cm_critic_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_grad_norm_clip_adam": (_i, [_p, _p, _p, _p, _l, _i, _d, _d, _d, _d, _d, _i, _d, _d, _p, _p]),
     "cm_gru_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

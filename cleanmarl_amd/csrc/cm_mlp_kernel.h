@@ -34,7 +34,10 @@ constexpr int KJMAX = KMAX / 4;  // head outputs owned per lane (4 lanes per row
 constexpr int NTHREADS = 256;
 // Workgroups per CU: two independent workgroups overlap each other's VALU and MFMA phases (needs <= 80 KB of LDS
 // and <= 256 registers); kernels with many layer-0 gradient chunks keep one workgroup per CU and 512 registers.
-constexpr int wgs_per_cu(int nch) { return nch <= 2 ? 2 : 1; }
+#ifndef CM_WG2_MAX_NCH
+#define CM_WG2_MAX_NCH 2
+#endif
+constexpr int wgs_per_cu(int nch) { return nch <= CM_WG2_MAX_NCH ? 2 : 1; }
 
 enum Mode { M_FWD = 0, M_ACT = 1, M_ACTOR = 2, M_CRITIC = 3 };
 
@@ -51,6 +54,8 @@ struct MlpArgs {
     int A, T, per_agent;
     float clip_lo, clip_hi, clip_eps, ent_coef;
     float* partial; int PS;  // per-workgroup partial gradients + stats, row stride PS floats
+    float* dz0;  // training kernels instantiated with NCH == 0: layer-0 pre-activation gradient [rows][HP] goes to HBM
+                 // and the layer-0 weight gradient is computed by the streaming kernel k_dw0_stream instead
     unsigned long long* prof;  // CM_PHASE_PROF builds only: [grid][16] cycle counters
 };
 
@@ -355,11 +360,11 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             {
                 const bool last = (c + 1 == nch);
                 const int cn = last ? 0 : c + 1;
-                const bool again = TRAIN && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
+                const bool again = TRAIN && NCH > 0 && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
                 const long r0n = last ? (again ? row0 : next_row0) : row0;
                 const int wn_ = min(KC, din - cn * KC);
                 tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
-                if (!w0_resident && !(last && TRAIN)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
+                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
             }
             if (c == 0) {
                 // per-row head inputs: issued here, consumed (raw) only in the head phases after the MFMA layers
@@ -653,8 +658,17 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     for (int r = 0; r < TM / 4; ++r) s += Z0[(part * (TM / 4) + r) * LDT + c];
                     dbh[0] += s;
                 }
+                if (NCH == 0) {  // external layer-0 weight gradient: hand dZ0 to k_dw0_stream (coalesced 16-byte stores)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = tid + NTHREADS * i;
+                        const int r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < a.rows)
+                            *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < (NCH > 0 ? NCH : 0); ++c) {
                     if (NCH > 1 || L >= 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
                         __syncthreads();
                         tile_store<VEC>(Xs, px);
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         float* out = a.partial + (size_t)blockIdx.x * a.PS;
         // dW0: wave (wm, wn) holds rows n = 32wm + i, cols k = 64c + 32wn + j
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < (NCH > 0 ? NCH : 0); ++c) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int n = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
@@ -755,21 +769,32 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     }
 }
 
-// sum per-workgroup partials: out[i] = sum_w partial[w][i]
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, int nparts, int PS, int n,
-                                                         float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nparts; w += 4) {
-        s0 += partial[(size_t)w * PS + i];
-        s1 += partial[(size_t)(w + 1) * PS + i];
-        s2 += partial[(size_t)(w + 2) * PS + i];
-        s3 += partial[(size_t)(w + 3) * PS + i];
+// sum per-workgroup partials: out[i] = sum_w partial[w][i] for i in the window [i0, n).
+// 1024 threads = 64 columns x 16 row groups: every group streams its share of the partial rows with 256-byte
+// coalesced reads, the 16 partial sums meet in LDS in a fixed order (deterministic).
+constexpr int RED_COLS = 64, RED_GROUPS = 16;
+__global__ __launch_bounds__(RED_COLS * RED_GROUPS) void k_reduce_partials(const float* __restrict__ partial, int nparts, int PS,
+                                                                           int i0, int n, float* __restrict__ out) {
+    __shared__ float sh[RED_GROUPS][RED_COLS];
+    const int c = threadIdx.x & (RED_COLS - 1), g = threadIdx.x / RED_COLS;
+    const int i = i0 + blockIdx.x * RED_COLS + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int w = g;
+        for (; w + RED_GROUPS < nparts; w += 2 * RED_GROUPS) {
+            s0 += partial[(size_t)w * PS + i];
+            s1 += partial[(size_t)(w + RED_GROUPS) * PS + i];
+        }
+        if (w < nparts) s0 += partial[(size_t)w * PS + i];
     }
-    for (; w < nparts; ++w) s0 += partial[(size_t)w * PS + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    sh[g][c] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < RED_GROUPS; ++q) t += sh[q][c];
+        out[i] = t;
+    }
 }
 
 constexpr int MAX_GRID = 512;  // persistent workgroups: up to two per CU

@@ -12,9 +12,9 @@ inline size_t train_ws_bytes(int din, int hidden, int n_hidden_layers, int dout)
     return (size_t)MAX_GRID * PS * sizeof(float);
 }
 
-inline int finish_train(const MlpArgs& a, int grid, int64_t P, float* grad_and_stats, hipStream_t s, const char* who) {
+inline int finish_train(const MlpArgs& a, int grid, int64_t P, float* grad_and_stats, hipStream_t s, const char* who, int i0 = 0) {
     const int n = (int)(P + CM_NUM_STATS);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, grid, a.PS, n, grad_and_stats);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n - i0 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, a.partial, grid, a.PS, i0, n, grad_and_stats);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) CM_FAIL(-2, "%s: reduce launch failed: %s", who, hipGetErrorString(e));
     return 0;

@@ -163,10 +163,7 @@ class PPOLearner:
         self.g_actor = self.gbuf[:Pa + N.NUM_STATS]
         self.g_critic = self.gbuf[Pa + N.NUM_STATS:]
         self.norms = torch.zeros(2, dtype=torch.float32, device=device)
-        ws_a = self.lib.cm_mlp_train_workspace_bytes(actor_spec.din, actor_spec.hidden, actor_spec.n_layers, actor_spec.dout) \
-            if actor_spec.kind == "mlp" else 0
-        ws_c = self.lib.cm_mlp_train_workspace_bytes(critic_spec.din, critic_spec.hidden, critic_spec.n_layers, 1)
-        self.ws = torch.empty(max(ws_a, ws_c, 1024), dtype=torch.uint8, device=device)
+        self.ws = None  # sized on first use (the critic workspace depends on the batch shape)
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
@@ -227,7 +224,16 @@ class PPOLearner:
         e1.record()
         self.events.append((kind, e0, e1))
 
+    def _ensure_ws(self, b):
+        a, c = self.actor_spec, self.critic_spec
+        need = self.lib.cm_critic_workspace_bytes(b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, c.din, c.hidden, c.n_layers)
+        if a.kind == "mlp":
+            need = max(need, self.lib.cm_mlp_train_workspace_bytes(a.din, a.hidden, a.n_layers, a.dout))
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+
     def critic_pass(self, b, s):
+        self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
         N.check(self.lib.cm_critic_fwd_bwd(N.ptr(x), N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
@@ -236,6 +242,7 @@ class PPOLearner:
                 "cm_critic_fwd_bwd")
 
     def actor_pass(self, b, s):
+        self._ensure_ws(b)
         a = self.actor_spec
         N.check(self.lib.cm_ppo_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
                                               N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,

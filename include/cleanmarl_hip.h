@@ -114,6 +114,9 @@ int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* 
 /* ---- a8 / a9: critic MSE forward + backward  (cleanmarl/mappo_multienvs.py:554-558, 582) ----
  * per_agent = 0 (MAPPO): rows = E*T of x = state[E][T][din]; target mean over the A agents of ret.
  * per_agent = 1 (IPPO):  rows = E*A*T of x = obs[E][A][T][din]  (cleanmarl/ippo_multienvs.py:554). */
+/* workspace query for cm_critic_fwd_bwd (wide inputs add a dZ0[rows][64] hand-off buffer for the streaming
+ * layer-0 weight-gradient kernel, see csrc/cm_mlp_critic.hip) */
+size_t cm_critic_workspace_bytes(int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers);
 int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,
                       int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                       const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
