@@ -82,19 +82,22 @@ struct Lds {
     __host__ __device__ int Hs(int l) const { return l == 0 ? Hs0 : (l == 1 ? Xs : Hs0 + (l - 1) * TM * LDT); }
     __host__ __device__ int bl(int l) const { return bl0 + l * HP; }
 };
+constexpr int WLD = 68;  // row stride of the head weight image (conflict-free ds_read_b128 down a column of rows)
+__host__ __device__ inline int head_kp(int dout) { return dout <= 8 ? 8 : KMAX; }      // ls row stride (= KJ * 4)
+__host__ __device__ inline int head_wr(int dout) { return dout <= 8 ? 16 : KMAX; }     // zero-padded rows of the head weights
 __host__ __device__ inline Lds make_lds(int L, int dout) {
     Lds s; int p = 0;
     s.Xs = p; p += TM * LDT;
     s.W0s = p; p += HP * LDT;
     s.Hs0 = p; p += (L >= 1 ? L : 1) * TM * LDT;
     s.Ws = p; if (L > 0) p += HP * LDT;
-    s.wout = p; p += ((dout + 3) & ~3) * HP;  // rows >= dout are zero
+    s.wout = p; p += head_wr(dout) * WLD;  // rows >= dout are zero (MFMA operand padding)
     s.b0 = p; p += HP;
     s.bl0 = p; p += L * HP;
     s.bout = p; p += KMAX;
-    s.ls = p; p += TM * LSP;
+    s.ls = p; p += TM * head_kp(dout);
     p = (p + 3) & ~3;
-    s.red = p; p += 4 * HP;  // 256 floats
+    s.red = s.Xs;  // 256 floats of scratch for the final partial write: the X buffer is dead by then
     s.total = p;
     return s;
 }
@@ -179,6 +182,58 @@ __device__ __forceinline__ void colred(f32x16& acc, const float* Zs_n0, const fl
         for (int i = 0; i < 4; ++i) acc = mfma32(a[i], b[i], acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// logits[16 rows of this wave][16 head outputs] = H_L[rows][64] * Wout[16][64]^T on v_mfma_f32_16x16x4_f32
+// (32-cycle issue; 16 of them per tile).  k is consumed in the permuted order {16j + 4g + i}: lane group g = lane>>4
+// reads floats [16j + 4g, 16j + 4g + 4) of its row as one b128.  Result: lane (n = lane & 15, g) holds rows 4g..4g+3.
+__device__ __forceinline__ f32x4 head_logits_mfma(const float* HLw /* H_L + 16*wave*LDT */, const float* wts /* wouts + 16*ct*WLD */) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float4* ap = reinterpret_cast<const float4*>(HLw + n * LDT + 4 * g);
+    const float4* bp = reinterpret_cast<const float4*>(wts + n * WLD + 4 * g);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HP / 16; ++j) {
+        const float4 a = ap[4 * j], b = bp[4 * j];
+        acc = mfma16(a.x, b.x, acc);
+        acc = mfma16(a.y, b.y, acc);
+        acc = mfma16(a.z, b.z, acc);
+        acc = mfma16(a.w, b.w, acc);
+    }
+    return acc;
+}
+
+// acc[32 (k) x 32 (c)] += sum over 32 rows of dlogits[row][k] * H[row][c0 + c], dlogits rows of stride KP (head
+// outputs k >= KP are zero-filled in registers instead of in LDS)
+template <int KP>
+__device__ __forceinline__ void colred_head_k(f32x16& acc, const float* ls_r0, const float* Hs_r0_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = ls_r0 + h * KP + (r < KP ? r : 0);
+    const float* bp = Hs_r0_c0 + h * LDT + r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const float av = (r < KP) ? ap[2 * kk * KP] : 0.0f;
+        acc = mfma32(av, bp[2 * kk * LDT], acc);
+    }
+}
+
+// acc[32 rows x 32 cols] = dlogits[32 rows][KP] * Wout[KP][32 cols]   (backward through the head, K = KP)
+template <int KP>
+__device__ __forceinline__ void head_bwd_mfma(f32x16& acc, const float* ls_r0, const float* wts_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < KP / 8; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(ls_r0 + r * KP + 8 * j + 4 * h);
+        const float* bp = wts_c0 + (8 * j + 4 * h) * WLD + r;
+        acc = mfma32(a.x, bp[0], acc);
+        acc = mfma32(a.y, bp[WLD], acc);
+        acc = mfma32(a.z, bp[2 * WLD], acc);
+        acc = mfma32(a.w, bp[3 * WLD], acc);
     }
 }
 
@@ -287,12 +342,14 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     float* wouts = smem + lds.wout;
     float* ls = smem + lds.ls;
     float* red = smem + lds.red;
-    constexpr int lstride = LSP;
+    constexpr int KP = KJ * 4;           // head outputs handled by this instantiation (8 or 32)
+    constexpr int lstride = KP;
+    constexpr int WR = (KJ == 2) ? 16 : KMAX;  // rows of the zero-padded head weight image
 
     // ---- one-time staging of small tensors (+ resident weights)
-    for (int i = tid; i < ((dout + 3) & ~3) * HP; i += NTHREADS) {
+    for (int i = tid; i < WR * HP; i += NTHREADS) {
         const int k = i / HP, c = i % HP;
-        wouts[i] = (c < H && k < dout) ? a.params[off.Wout + k * H + c] : 0.0f;
+        wouts[k * WLD + c] = (c < H && k < dout) ? a.params[off.Wout + k * H + c] : 0.0f;
     }
     for (int i = tid; i < HP; i += NTHREADS) {
         smem[lds.b0 + i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
@@ -300,7 +357,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             if (l < L) smem[lds.bl(l) + i] = (i < H) ? a.params[off.bl(l) + i] : 0.0f;
     }
     for (int i = tid; i < KMAX; i += NTHREADS) smem[lds.bout + i] = (i < dout) ? a.params[off.bout + i] : 0.0f;
-    for (int i = tid; i < TM * LSP; i += NTHREADS) ls[i] = 0.0f;  // columns >= dout stay zero (MFMA operand padding)
+    for (int i = tid; i < TM * KP; i += NTHREADS) ls[i] = 0.0f;
     if (w0_resident) stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
     if (ws_resident && L >= 1) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
 
@@ -423,39 +480,27 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
         }
         PH(2);
-        // ================= head forward (VALU) =================
+        // ================= head forward: 16x16x4 MFMA, wave w owns rows 16w..16w+15 (= the rows of its quad lanes) ====
         float* HL = smem + lds.Hs(L);
-        float hreg[16];
         {
-            const float4* hp4 = reinterpret_cast<const float4*>(HL + hrow * LDT + 16 * hq);
+            const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = hp4[i];
-                hreg[4 * i] = v.x; hreg[4 * i + 1] = v.y; hreg[4 * i + 2] = v.z; hreg[4 * i + 3] = v.w;
+            for (int ct = 0; ct < WR / 16; ++ct) {
+                const f32x4 lg = head_logits_mfma(HL + 16 * wave * LDT, wouts + 16 * ct * WLD);
+                const int k = 16 * ct + n;
+                if (k < KP) {
+                    const float bias = smem[lds.bout + k];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * lstride + k] = lg[q] + bias;
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();  // same-wave LDS hand-off (DS ops of one wave execute in order)
         float zreg[KJ];
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
             zreg[j] = -1e9f;
-            if (4 * j < dout) {  // wave-uniform
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = 4 * j + q;
-                    if (k < dout) {
-                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + k * HP + 16 * hq);
-                        float p = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 w4 = wp4[i];
-                            p = fmaf(hreg[4 * i], w4.x, p); p = fmaf(hreg[4 * i + 1], w4.y, p);
-                            p = fmaf(hreg[4 * i + 2], w4.z, p); p = fmaf(hreg[4 * i + 3], w4.w, p);
-                        }
-                        p = quad_sum(p);
-                        if (hq == q) zreg[j] = ri.avb[j] ? p + smem[lds.bout + k] : -1e9f;  // masked_fill(~avail, -1e9)
-                    }
-                }
-            }
+            if (4 * j + hq < dout && ri.avb[j]) zreg[j] = ls[hrow * lstride + 4 * j + hq];  // masked_fill(~avail, -1e9)
         }
         if (MODE == M_FWD) {
 #pragma unroll
@@ -572,46 +617,27 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             PH(4);
             // ---- dWout, dbout (contraction over the tile's rows; reads HL before it is overwritten)
             // wave (wm, wn): rows 32wm..32wm+31 of the tile, hidden columns 32wn..32wn+31, all 32 (padded) head rows
-            colred_head(accWo, ls + 32 * wm * LSP, HL + 32 * wm * LDT + 32 * wn);
+            colred_head_k<KP>(accWo, ls + 32 * wm * KP, HL + 32 * wm * LDT + 32 * wn);
             {
                 const int k = tid & 31, part = tid >> 5;
                 float sb = 0.0f;
+                if (k < KP) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) sb += ls[(part * 8 + r) * LSP + k];
+                    for (int r = 0; r < 8; ++r) sb += ls[(part * 8 + r) * KP + k];
+                }
                 dbo += sb;
             }
+            // ---- dZ_L = (dlogits * Wout) .* relu'(H_L): MFMA into registers now, in-place write after the barrier
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+            head_bwd_mfma<KP>(acc, ls + 32 * wm * KP, wouts + 32 * wn);
             __syncthreads();
             PH(5);
-            // ---- dZ_L = (dlogits * Wout) .* relu'(H_L), in place (each lane owns its 16 columns)
-            {
-                float dz[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dz[i] = 0.0f;
-                for (int k0 = 0; k0 < dout; k0 += 4) {  // ls columns and wouts rows beyond dout are zero
-                    const float4 d4 = *reinterpret_cast<const float4*>(ls + hrow * lstride + k0);
-                    const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + (k0 + q) * HP + 16 * hq);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 w4 = wp4[i];
-                            dz[4 * i] = fmaf(dk[q], w4.x, dz[4 * i]); dz[4 * i + 1] = fmaf(dk[q], w4.y, dz[4 * i + 1]);
-                            dz[4 * i + 2] = fmaf(dk[q], w4.z, dz[4 * i + 2]); dz[4 * i + 3] = fmaf(dk[q], w4.w, dz[4 * i + 3]);
-                        }
-                    }
-                }
-                float4* hp4 = reinterpret_cast<float4*>(HL + hrow * LDT + 16 * hq);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 hv = hp4[i];  // relu mask re-read from LDS (cheaper than 16 live registers)
-                    float4 v;
-                    v.x = hv.x > 0.0f ? dz[4 * i] : 0.0f;
-                    v.y = hv.y > 0.0f ? dz[4 * i + 1] : 0.0f;
-                    v.z = hv.z > 0.0f ? dz[4 * i + 2] : 0.0f;
-                    v.w = hv.w > 0.0f ? dz[4 * i + 3] : 0.0f;
-                    hp4[i] = v;
-                }
+            for (int g = 0; g < 16; ++g) {
+                const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                float* p = HL + row * LDT + 32 * wn + lc;
+                *p = (*p > 0.0f) ? acc[g] : 0.0f;
             }
             __syncthreads();
             PH(6);
