@@ -47,16 +47,30 @@ enum { CM_STREAM_ACT = 1, CM_STREAM_ENV_RESET = 2, CM_STREAM_ENV_STEP = 3 };
 __device__ __forceinline__ void cm_categorical_sample(const float* z, int K, float u, int* action, float* logp) {
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, z[k]);
-    float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
-    const float thr = u * s;
-    float cum = 0.0f;
+    float s = 0.0f, cum = 0.0f;
     int chosen = -1, last = 0;
-    for (int k = 0; k < K; ++k) {
-        if (z[k] > -5e8f) {
-            cum += expf(z[k] - m);
-            last = k;
-            if (chosen < 0 && thr < cum) chosen = k;
+    if (K <= 8) {  // common case: keep the K exponentials in registers (one expf per action)
+        float e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e[k] = (k < K) ? expf(z[k] - m) : 0.0f; s += e[k]; }
+        const float thr = u * s;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K && z[k] > -5e8f) {
+                cum += e[k];
+                last = k;
+                if (chosen < 0 && thr < cum) chosen = k;
+            }
+        }
+    } else {
+        for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+        const float thr = u * s;
+        for (int k = 0; k < K; ++k) {
+            if (z[k] > -5e8f) {
+                cum += expf(z[k] - m);
+                last = k;
+                if (chosen < 0 && thr < cum) chosen = k;
+            }
         }
     }
     if (chosen < 0) chosen = last;

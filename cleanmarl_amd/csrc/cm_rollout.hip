@@ -63,8 +63,8 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     float* W0s = Xs + TM * LDT;
     float* H0 = W0s + HP * LDT;
     float* Ws = H0 + TM * LDT;
-    float* wouts = Ws + HP * LDT;        // [8][HP]
-    float* b0s = wouts + 8 * HP;
+    float* wouts = Ws + HP * LDT;        // [16][WLD], rows >= K zero (operand of the 16x16x4 MFMA head)
+    float* b0s = wouts + 16 * WLD;
     float* b1s = b0s + HP;
     float* bos = b1s + HP;               // [8]
     float* ls = bos + 8;                 // [TM][8] logits
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     long* sbase = obase + TM;                          // [TM] state row base
     float* rscr = reinterpret_cast<float*>(sbase + TM);  // [2][TM] reward partials
 
-    for (int i = tid; i < 8 * HP; i += NTHREADS) {
+    for (int i = tid; i < 16 * HP; i += NTHREADS) {
         const int k = i / HP, c = i % HP;
-        wouts[i] = (c < H && k < K) ? a.params[off.Wout + k * H + c] : 0.0f;
+        wouts[k * WLD + c] = (c < H && k < K) ? a.params[off.Wout + k * H + c] : 0.0f;
     }
     for (int i = tid; i < HP; i += NTHREADS) {
         b0s[i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
@@ -90,6 +90,8 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
 
     const int ntiles = (a.E + EPT - 1) / EPT;
     const int hrow = tid >> 2, hq = tid & 3;
+    // 16-byte buffer stores need 4-float-aligned obs rows and state segments and <= 1024 / 768 quads per tile
+    const bool vecw = (din % 4 == 0) && ((6 * A) % 4 == 0) && (TM * (din >> 2) <= 4 * NTHREADS) && (TM * ((6 * A) >> 2) <= 3 * NTHREADS);
     PH_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * EPT;
@@ -101,6 +103,19 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             const bool live = tid < RT && e < a.E;
             obase[tid] = live ? (e * A + i) * (long)T * din : -1;
             sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+        }
+        // 16-byte store slots of this thread: obs rows are din/4 quads wide, state segments 6A/4 quads (<= 4 / 3 slots)
+        int oslot[4], sslot[3];
+        {
+            const int nq = din >> 2, ns = (6 * A) >> 2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + NTHREADS * it;
+                const int r = idx / nq, c4 = idx - r * nq;
+                oslot[it] = (vecw && r < RT && e0 + r / A < a.E) ? ((r << 8) | c4) : -1;
+                const int r2 = idx / ns, c42 = idx - r2 * ns;
+                if (it < 3) sslot[it] = (vecw && r2 < RT && e0 + r2 / A < a.E) ? ((r2 << 8) | c42) : -1;
+            }
         }
         if (tid < RT) {
             const int el = tid / A, i = tid - el * A;
@@ -116,9 +131,29 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             }
             evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
         }
+        // nearest-agent distance per landmark and collisions per agent from the CURRENT positions (thread per row)
+        auto reward_partials = [&]() {
+            if (tid < RT) {
+                const int el = tid / A, l = tid - el * A;
+                const float* pos = epos + el * 2 * A;
+                const float lx = elm[2 * tid], ly = elm[2 * tid + 1];
+                const float qx = pos[2 * l], qy = pos[2 * l + 1];
+                float best = 3.0e38f, col = 0.0f;
+                for (int j = 0; j < A; ++j) {
+                    const float dx = pos[2 * j] - lx, dy = pos[2 * j + 1] - ly;
+                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
+                    if (j > l) {
+                        const float cx = qx - pos[2 * j], cy = qy - pos[2 * j + 1];
+                        if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < COLLIDE) col += 1.0f;
+                    }
+                }
+                rscr[tid] = best; rscr[TM + tid] = col;
+            }
+        };
         for (int t = 0; t < T; ++t) {
             __syncthreads();
             PH(0);
+            if (t > 0) reward_partials();  // reward of step t-1: positions after its physics update
             // ---------------- observations of step t -> Xs (4 lanes per row, features f = hq, hq+4, ...)
             {   // 4 lanes per row: lane hq handles entities j = hq, hq+4, ... (landmark j, other agent j, id j)
                 const int el = hrow / A, i = hrow - el * A;
@@ -146,14 +181,37 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             __syncthreads();
             PH(1);
             // ---------------- rollout-buffer writes (coalesced along the feature axis)
-#pragma unroll 4
-            for (int r = wave; r < TM; r += 4) {  // wave-uniform row; lane = feature column
-                const long ob = obase[r];
-                if (ob >= 0) {
-                    const float v = Xs[r * LDT + lane];
-                    if (lane < din) a.obs[ob + (long)t * din + lane] = v;
-                    if (lane < 6 * A) a.state[sbase[r] + (long)t * Ds + lane] = v;
+            if (vecw) {  // 16-byte stores: thread-private (row, quad-column) slots precomputed per tile
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (oslot[it] >= 0) {
+                        const int r = oslot[it] >> 8, c4 = oslot[it] & 255;
+                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * din + 4 * c4) =
+                            *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                    }
+                    if (it < 3 && sslot[it] >= 0) {
+                        const int r = sslot[it] >> 8, c4 = sslot[it] & 255;
+                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * Ds + 4 * c4) =
+                            *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                    }
                 }
+            } else {
+#pragma unroll 4
+                for (int r = wave; r < TM; r += 4) {  // wave-uniform row; lane = feature column
+                    const long ob = obase[r];
+                    if (ob >= 0) {
+                        const float v = Xs[r * LDT + lane];
+                        if (lane < din) a.obs[ob + (long)t * din + lane] = v;
+                        if (lane < 6 * A) a.state[sbase[r] + (long)t * Ds + lane] = v;
+                    }
+                }
+            }
+            // team reward of step t-1 (its partials were produced in the obs phase from the post-physics positions)
+            if (t > 0 && tid < EPT && e0 + tid < a.E) {
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+                for (int l = 0; l < A; ++l) r -= rscr[TM + tid * A + l];
+                a.reward[(long)(e0 + tid) * T + (t - 1)] = r;
             }
             PH(2);
             // the step's uniform does not depend on the logits: issue the Philox rounds here so they interleave with
@@ -195,29 +253,14 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 __syncthreads();
             }
             PH(3);
-            // ---------------- head: logits (4 lanes per row x 16 hidden columns), all K actions available
+            // ---------------- head: logits on the 16x16x4 MFMA (same routine and summation order as k_mlp<M_ACT>)
             {
-                float hreg[16];
-                const float4* hp4 = reinterpret_cast<const float4*>(HL + hrow * LDT + 16 * hq);
+                const f32x4 lg = head_logits_mfma(HL + 16 * wave * LDT, wouts);
+                const int n = lane & 15, g4 = lane >> 4;
+                if (n < 8) {
+                    const float bias = bos[n];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 v = hp4[i];
-                    hreg[4 * i] = v.x; hreg[4 * i + 1] = v.y; hreg[4 * i + 2] = v.z; hreg[4 * i + 3] = v.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k < K) {
-                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + k * HP + 16 * hq);
-                        float p = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 w4 = wp4[i];
-                            p = fmaf(hreg[4 * i], w4.x, p); p = fmaf(hreg[4 * i + 1], w4.y, p);
-                            p = fmaf(hreg[4 * i + 2], w4.z, p); p = fmaf(hreg[4 * i + 3], w4.w, p);
-                        }
-                        p = quad_sum(p);
-                        if (hq == (k & 3)) ls[hrow * 8 + k] = p + bos[k];
-                    }
+                    for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * 8 + n] = lg[q] + bias;
                 }
             }
             __syncthreads();
@@ -241,33 +284,17 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                     epos[2 * tid] += vx * DT; epos[2 * tid + 1] += vy * DT;
                 }
             }
-            __syncthreads();
-            PH(5);
-            // ---------------- team reward of step t: one thread per env
-            if (tid < RT) {  // thread (env el, index l): nearest agent to landmark l, and collisions of agent l with q > l
-                const int el = tid / A, l = tid - el * A;
-                const float* pos = epos + el * 2 * A;
-                const float lx = elm[2 * tid], ly = elm[2 * tid + 1];
-                const float qx = pos[2 * l], qy = pos[2 * l + 1];
-                float best = 3.0e38f, col = 0.0f;
-                for (int j = 0; j < A; ++j) {
-                    const float dx = pos[2 * j] - lx, dy = pos[2 * j + 1] - ly;
-                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
-                    if (j > l) {
-                        const float cx = qx - pos[2 * j], cy = qy - pos[2 * j + 1];
-                        if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < COLLIDE) col += 1.0f;
-                    }
-                }
-                rscr[tid] = best; rscr[TM + tid] = col;
-            }
-            __syncthreads();
-            if (tid < EPT && e0 + tid < a.E) {
-                float r = 0.0f;
-                for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
-                for (int l = 0; l < A; ++l) r -= rscr[TM + tid * A + l];
-                a.reward[(long)(e0 + tid) * T + t] = r;
-            }
-            PH(6);
+            PH(5);  // the barrier at the top of the next step orders the physics update before its readers
+        }
+        // reward of the last step
+        __syncthreads();
+        reward_partials();
+        __syncthreads();
+        if (tid < EPT && e0 + tid < a.E) {
+            float r = 0.0f;
+            for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+            for (int l = 0; l < A; ++l) r -= rscr[TM + tid * A + l];
+            a.reward[(long)(e0 + tid) * T + (T - 1)] = r;
         }
         __syncthreads();
         // ---------------- final env state back to global (pos | vel | landmarks)
@@ -308,7 +335,7 @@ extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agen
 #endif
     const int EPT = TM / A;
     const int ntiles = (E + EPT - 1) / EPT;
-    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 8 * HP + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM + 4 * TM + 2 * TM;
+    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM + 4 * TM + 2 * TM;
     const size_t lds_bytes = lds_floats * sizeof(float);
     const int grid = ntiles < 512 ? ntiles : 512;  // <= 80 KB of LDS: two workgroups per CU overlap each other's latencies
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

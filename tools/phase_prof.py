@@ -61,7 +61,7 @@ tot = float(ph.sum())
 if which == "rollout":
     ph = prof.double().mean(0).cpu(); tot = float(ph.sum())
     print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase (512 WGs, 1 tile each):")
-    for i, n in enumerate(["barrier_top", "obs_features", "buffer_writes", "fwd_mlp", "head_logits", "sample+physics", "reward"]):
+    for i, n in enumerate(["barrier_top", "obs+reward_partials", "buffer_writes", "fwd_mlp", "head_logits(mfma)", "sample+physics"]):
         print(f"  {n:24s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
     print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
     sys.exit(0)
