@@ -12,7 +12,7 @@
 // pettingzoo itself is not installed here, so this is "MPE-like", not a bit-copy of simple_spread_v3.
 // Randomness: Philox4x32-10 keyed by the run seed and counted by (global env index, episode, entity), so
 // the same env gets the same episode no matter which GPU owns it.
-// oracle/synth_env.py is the numpy twin used by the parity tests.
+// cleanmarl_amd/env/synthetic.py is the numpy twin (CommonInterface env) the parity tests compare against.
 #include "cm_common.h"
 
 namespace {

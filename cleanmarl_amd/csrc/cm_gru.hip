@@ -6,7 +6,9 @@
 //     sum_{t in chunk} (-pg_t - c_ent * ent_t) / (N_chunk * T_chunk)
 // is back-propagated through the chunk only (h detached at the chunk boundary) and followed by an optimiser step.
 //
-// One workgroup owns a tile of 64 (env,agent) sequences and walks the chunk twice: forward t0..t1-1 (saving
+// One workgroup owns a tile of 64 (env,agent) sequences; the chunk is walked by two launches with the same tiling
+// (k_gru_chunk_fwd keeps no accumulators, k_gru_chunk_bwd keeps eight MFMA accumulator tiles -- as one kernel the
+// register allocator spilled ~500 VGPRs): forward t0..t1-1 (saving
 // x1, r, z, n, W_hn h + b_hn and h' per step to a workspace in HBM and the per-step dlogits of the PPO head),
 // then backward t1-1..t0 with dh carried in LDS.  Every GEMM is a 64x64x64 block on v_mfma_f32_32x32x2_f32
 // (same three forms as cm_mlp_kernel.h); gate weight blocks are streamed through LDS, weight-gradient
@@ -16,6 +18,23 @@
 #include "cm_mlp_train.h"
 
 namespace {
+
+// weight-block / obs staging for the GRU kernels: the same mapping as stage_rows but only 4 loads in flight per
+// thread (these kernels carry up to eight MFMA accumulator tiles and cannot afford 16 staging registers)
+__device__ __forceinline__ void stage_lite(float* dst, const float* src, long row0, long nrows, long stride, int col0, int ncols) {
+    const int k = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const bool kok = k < ncols;
+    const float* p = src + (row0 + r0) * stride + col0 + k;
+    const long step = 4 * stride;
+#pragma unroll 1
+    for (int i = 0; i < TM / 4; i += 4) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = (kok && row0 + r0 + 4 * (i + q) < nrows) ? *p : 0.0f; p += step; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(r0 + 4 * (i + q)) * LDT + k] = v[q];
+    }
+}
 
 struct GruOff { int W1, b1, Wih, Whh, bih, bhh, W2, b2, P; };
 __host__ __device__ inline GruOff gru_offsets(int din, int H, int K) {
@@ -86,8 +105,8 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
     f32x16 acc;
     // ---- F1: x1 = relu(fc1(obs))
     __syncthreads();
-    stage_rows(X, xbase, row0, nrows, xstride, 0, din);
-    stage_rows(W, a.params + off.W1, 0, H, din, 0, din);
+    stage_lite(X, xbase, row0, nrows, xstride, 0, din);
+    stage_lite(W, a.params + off.W1, 0, H, din, 0, din);
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -106,8 +125,8 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
 #pragma unroll
     for (int gate = 0; gate < 2; ++gate) {
         __syncthreads();  // A1 complete / previous readers of W, W2 done
-        stage_rows(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
-        stage_rows(W2, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+        stage_lite(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
+        stage_lite(W2, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -125,8 +144,8 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
     }
     // ---- F3: candidate n and the new hidden state
     __syncthreads();
-    stage_rows(W, a.params + off.Wih + 2 * H * H, 0, H, H, 0, H);
-    stage_rows(W2, a.params + off.Whh + 2 * H * H, 0, H, H, 0, H);
+    stage_lite(W, a.params + off.Wih + 2 * H * H, 0, H, H, 0, H);
+    stage_lite(W2, a.params + off.Whh + 2 * H * H, 0, H, H, 0, H);
     __syncthreads();
     f32x16 acch;
 #pragma unroll
@@ -189,7 +208,7 @@ __device__ __forceinline__ void gru_head_logits(const GruLds& L, const float* hn
 
 // ============================================================================================ chunk fwd + bwd
 template <int KJ>
-__global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
+__global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = KJ * 4;
     const GruOff off = gru_offsets(a.din, a.H, a.K);
@@ -202,15 +221,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
     const int col = 32 * wn + lc;
     gru_stage_consts(L, a, off, KP);
 
-    f32x16 accW1, accWih[3], accWhh[3], accWo;
-    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbo = 0.f;
     float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        accW1[g] = 0.f; accWo[g] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
-    }
     const long ntiles = (R + TM - 1) / TM;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * TM;
@@ -294,6 +305,49 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
                 const int r = i >> 6, c = i & 63;
                 if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
             }
+    }
+    // statistics of this workgroup (the gradient part of the partial row is written by k_gru_chunk_bwd)
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = cm_wave_sum(sv6[q]);
+        if (lane == 0) L.red[q * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < CM_NUM_STATS) {
+        float v = 0.f;
+        if (tid < 6) v = L.red[tid * 4] + L.red[tid * 4 + 1] + L.red[tid * 4 + 2] + L.red[tid * 4 + 3];
+        out[off.P + tid] = v;
+    }
+}
+
+template <int KJ>
+__global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = KJ * 4;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    const GruLds L = gru_lds(smem, KP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int hrow = tid >> 2, hq = tid & 3;
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const int col = 32 * wn + lc;
+    gru_stage_consts(L, a, off, KP);
+
+    f32x16 accW1, accWih[3], accWhh[3], accWo;
+    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbo = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        accW1[g] = 0.f; accWo[g] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
+    }
+    const long ntiles = (R + TM - 1) / TM;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * TM;
         // ================================ backward through the chunk
         float *DH = L.b[0], *W = L.b[1], *A1 = L.b[2], *HPV = L.b[3], *G0 = L.b[4], *G1 = L.b[5], *G2 = L.b[6], *G3 = L.b[7];
         __syncthreads();
@@ -303,10 +357,12 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
             const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
             // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
             __syncthreads();
+#pragma unroll 1
             for (int i = tid; i < TM * KP; i += NTHREADS) {
                 const int r = i / KP, k = i - r * KP;
                 L.ls[r * LSP + k] = (row0 + r < R && k < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + k] : 0.0f;
             }
+#pragma unroll 4
             for (int i = tid; i < TM * HP; i += NTHREADS) {
                 const int r = i >> 6, c = i & 63;
                 G3[r * LDT + c] = (row0 + r < R) ? fmaxf(wsS[(long)r * WS_ACT + 5 * HP + c], 0.0f) : 0.0f;
@@ -345,6 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
             }
             __syncthreads();
             // ---- B2: gate derivatives (elementwise, flat mapping), h_prev -> HPV, x1 -> A1
+#pragma unroll 2
             for (int i = tid; i < TM * HP; i += NTHREADS) {
                 const int r = i >> 6, c = i & 63;
                 float rr = 0.f, zz = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, x1 = 0.f;
@@ -388,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
                 __syncthreads();
-                stage_rows(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
+                stage_lite(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
                 __syncthreads();
                 rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G2) + 32 * wm * LDT, W + 32 * wn);
             }
@@ -399,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
                 __syncthreads();
-                stage_rows(W, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+                stage_lite(W, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
                 __syncthreads();
                 rowpar_tn(acch, (gate == 0 ? G0 : gate == 1 ? G1 : G3) + 32 * wm * LDT, W + 32 * wn);
             }
@@ -412,7 +469,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
                 DH[row * LDT + col] += acch[g];
             }
             // ---- B6: fc1 weight gradient: obs tile -> G0
-            stage_rows(G0, a.obs + (long)t * din, row0, R, (long)T * din, 0, din);
+            stage_lite(G0, a.obs + (long)t * din, row0, R, (long)T * din, 0, din);
             __syncthreads();
             colred(accW1, A1 + 32 * wm, G0 + 32 * wn);
             {
@@ -479,19 +536,6 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk(const GruArgs a) {
                 else out[off.bhh + 2 * H + tid] = sv;                                                  // b_hn (scaled by r)
             }
         }
-    }
-    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const float v = cm_wave_sum(sv6[q]);
-        if (lane == 0) L.red[q * 4 + wave] = v;
-    }
-    __syncthreads();
-    if (tid < CM_NUM_STATS) {
-        float v = 0.f;
-        if (tid < 6) v = L.red[tid * 4] + L.red[tid * 4 + 1] + L.red[tid * 4 + 2] + L.red[tid * 4 + 3];
-        out[off.P + tid] = v;
     }
 }
 
@@ -587,11 +631,15 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     const int grid = grid_for((long)R);
     const size_t lds = gru_lds_bytes(n_actions);
     if (n_actions <= 8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_chunk<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_chunk_fwd<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_gru_chunk_bwd<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_chunk<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_fwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gru_chunk_fwd<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_gru_chunk_bwd<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
     }
     CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
     MlpArgs m = {};

@@ -31,7 +31,7 @@ extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, cons
     a.prof = g_prof;
 #endif
     const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
-    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     if (int rc = launch_train<M_ACTOR>(a, grid, lds_bytes, (hipStream_t)stream)) return rc;
     CM_CHECK_LAUNCH("cm_ppo_actor_fwd_bwd");
     return finish_train(a, grid, P, grad_and_stats, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");

@@ -113,7 +113,7 @@ extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
-    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     if (!use_split(din)) {
         const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
         if (int rc = launch_train<M_CRITIC>(a, grid, lds_bytes, s)) return rc;

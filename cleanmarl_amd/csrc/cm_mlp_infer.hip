@@ -8,7 +8,7 @@ extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden,
     MlpArgs a = {};
     a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
-    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_mlp_forward");
     return 0;
@@ -24,7 +24,7 @@ extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t
     a.x = x; a.x_stride = x_row_stride; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.avail = avail; a.avail_stride = avail_row_stride;
     a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
-    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout).total * sizeof(float);
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act");
     return 0;

@@ -15,7 +15,8 @@
 //   rowpar_tn : dX[64 x 64] = dZ[64 x 64] * W[64 x 64]       (backward data path)
 //   colred    : dW[64 x 64] += dZ[64 rows x 64]^T * X[64 rows x 64]  (weight gradients; the accumulators
 //               stay in registers across ALL row tiles of the persistent workgroup and are written once)
-// The tiny head (K <= 32 outputs) and all softmax / PPO / MSE math run on the VALU out of LDS.
+// The head (K <= 32 outputs) runs on v_mfma_f32_16x16x4_f32 (logits) and 32x32x2 (backward); the softmax / PPO /
+// MSE math runs on the VALU with the K logits of a row spread over 4 lanes (DPP quad reductions).
 // Hidden widths H <= 64 are zero-padded to 64 in LDS (dead units have zero activations and zero
 // gradients), the input width is processed in chunks of 64 columns.
 #pragma once
@@ -29,7 +30,7 @@ constexpr int KC = 64;    // input chunk width
 constexpr int LDT = 68;   // LDS row stride in floats (4*17: conflict-free ds_read_b128 down a column of rows)
 constexpr int LMAX = 2;   // max hidden->hidden layers (kernels are compiled for LCAP = 1 or 2)
 constexpr int KMAX = 32;  // max head width
-constexpr int LSP = 32;   // row stride of the per-row head scratch (logits / dlogits) = KMAX, zero padded
+constexpr int LSP = 32;   // row stride of the per-row head scratch in the GRU kernels (= KMAX, zero padded)
 constexpr int KJMAX = KMAX / 4;  // head outputs owned per lane (4 lanes per row); kernels compiled for KJ = 2 or 8
 constexpr int NTHREADS = 256;
 // Workgroups per CU: two independent workgroups overlap each other's VALU and MFMA phases (needs <= 80 KB of LDS
@@ -85,7 +86,7 @@ struct Lds {
 constexpr int WLD = 68;  // row stride of the head weight image (conflict-free ds_read_b128 down a column of rows)
 __host__ __device__ inline int head_kp(int dout) { return dout <= 8 ? 8 : KMAX; }      // ls row stride (= KJ * 4)
 __host__ __device__ inline int head_wr(int dout) { return dout <= 8 ? 16 : KMAX; }     // zero-padded rows of the head weights
-__host__ __device__ inline Lds make_lds(int L, int dout) {
+__host__ __device__ inline Lds make_lds(int L, int dout, int nch) {
     Lds s; int p = 0;
     s.Xs = p; p += TM * LDT;
     s.W0s = p; p += HP * LDT;
@@ -95,7 +96,10 @@ __host__ __device__ inline Lds make_lds(int L, int dout) {
     s.b0 = p; p += HP;
     s.bl0 = p; p += L * HP;
     s.bout = p; p += KMAX;
-    s.ls = p; p += TM * head_kp(dout);
+    // the per-row head scratch is only live between the forward of layer 0 and the backward of the hidden layers;
+    // when W0 is streamed per tile (nch > 1) its chunk buffer is free in exactly that window -> alias (keeps K > 8
+    // heads under the 80 KB that two workgroups per CU allow)
+    if (nch > 1) s.ls = s.W0s; else { s.ls = p; p += TM * head_kp(dout); }
     p = (p + 3) & ~3;
     s.red = s.Xs;  // 256 floats of scratch for the final partial write: the X buffer is dead by then
     s.total = p;
@@ -249,14 +253,19 @@ __device__ __forceinline__ void colred_head(f32x16& acc, const float* ls_r0, con
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, long row0, long nrows, long stride,
                                            int col0, int ncols) {
     // dst[r][k] = src[(row0+r)*stride + col0 + k]  for r < TM, k < KC; zero outside [nrows) x [ncols)
-#pragma unroll 4
-    for (int i = threadIdx.x; i < TM * KC; i += NTHREADS) {
-        const int r = i >> 6, k = i & 63;
-        const long row = row0 + r;
-        float v = 0.0f;
-        if (row < nrows && k < ncols) v = src[row * stride + col0 + k];
-        dst[r * LDT + k] = v;
+    // thread (r0 = tid/64, k = tid%64) walks rows r0, r0+4, ...: one pointer bump per element, no multiplies
+    const int k = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const bool kok = k < ncols;
+    const float* p = src + (row0 + r0) * stride + col0 + k;
+    const long step = 4 * stride;
+    float v[TM / 4];
+#pragma unroll
+    for (int i = 0; i < TM / 4; ++i) {
+        v[i] = (kok && row0 + r0 + 4 * i < nrows) ? *p : 0.0f;
+        p += step;
     }
+#pragma unroll
+    for (int i = 0; i < TM / 4; ++i) dst[(r0 + 4 * i) * LDT + k] = v[i];
 }
 
 // ---- register-staged tile prefetch (T14 "issue early / write late"): a 64x64 fp32 tile = 16 floats per thread.
@@ -278,14 +287,14 @@ __device__ __forceinline__ void tile_load(Tile16& t, const float* src, long row0
         }
     } else {
         float* f = reinterpret_cast<float*>(t.v);
+        const int k = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+        const bool kok = k < ncols;
+        const float* p = src + (row0 + r0) * stride + col0 + k;
+        const long step = 4 * stride;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int idx = threadIdx.x + NTHREADS * i;
-            const int r = idx >> 6, k = idx & 63;
-            const long row = row0 + r;
-            float v = 0.0f;
-            if (row < nrows && k < ncols) v = src[row * stride + col0 + k];
-            f[i] = v;
+        for (int i = 0; i < 16; ++i) {  // element i = row r0 + 4i, column k: one pointer bump per load
+            f[i] = (kok && row0 + r0 + 4 * i < nrows) ? *p : 0.0f;
+            p += step;
         }
     }
 }
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     constexpr bool TRAIN = (MODE == M_ACTOR || MODE == M_CRITIC);
     constexpr int NC = (NCH > 0 ? NCH : 1);
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
-    const Lds lds = make_lds(a.L, a.dout);
+    const Lds lds = make_lds(a.L, a.dout, (a.din + KC - 1) / KC);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
     const int H = a.H, L = a.L, dout = a.dout, din = a.din;
@@ -357,7 +366,6 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             if (l < L) smem[lds.bl(l) + i] = (i < H) ? a.params[off.bl(l) + i] : 0.0f;
     }
     for (int i = tid; i < KMAX; i += NTHREADS) smem[lds.bout + i] = (i < dout) ? a.params[off.bout + i] : 0.0f;
-    for (int i = tid; i < TM * KP; i += NTHREADS) ls[i] = 0.0f;
     if (w0_resident) stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
     if (ws_resident && L >= 1) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
 

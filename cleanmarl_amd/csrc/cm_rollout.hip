@@ -29,27 +29,6 @@ struct RolloutArgs {
     unsigned long long* prof;
 };
 
-// feature f of agent i's observation (cm_env.hip write_obs order)
-__device__ __forceinline__ float obs_feature(int f, int i, int A, const float* pos, const float* vel, const float* lm,
-                                             int agent_ids) {
-    const float px = pos[2 * i], py = pos[2 * i + 1];
-    if (f < 2) return vel[2 * i + f];
-    if (f < 4) return f == 2 ? px : py;
-    f -= 4;
-    if (f < 2 * A) return lm[f] - ((f & 1) ? py : px);
-    f -= 2 * A;
-    if (f < 2 * (A - 1)) {
-        int j = f >> 1;
-        if (j >= i) ++j;
-        return pos[2 * j + (f & 1)] - ((f & 1) ? py : px);
-    }
-    f -= 2 * (A - 1);
-    if (f < 2 * (A - 1)) return 0.0f;
-    f -= 2 * (A - 1);
-    if (agent_ids && f < A) return f == i ? 1.0f : 0.0f;
-    return 0.0f;  // zero padding up to the 64-column MFMA chunk
-}
-
 __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
