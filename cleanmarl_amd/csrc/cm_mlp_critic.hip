@@ -19,7 +19,7 @@ constexpr int RB = 8;  // row pairs per software-pipeline batch (16 rows)
 template <int KTW>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restrict__ dz0, const float* __restrict__ x,
                                                             long rows, int din, int H, long rows_per_wg,
-                                                            float* __restrict__ partial, int PS2) {
+                                                            float* __restrict__ partial, int PS2, int col0) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const long row_lo = (long)blockIdx.x * rows_per_wg;
     const long row_hi = min(rows, row_lo + rows_per_wg);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restr
     int col[KTW];
     bool cok[KTW];
 #pragma unroll
-    for (int j = 0; j < KTW; ++j) { col[j] = 32 * (w + 4 * j) + r; cok[j] = col[j] < din; }
+    for (int j = 0; j < KTW; ++j) { col[j] = col0 + 32 * (w + 4 * j) + r; cok[j] = col[j] < din; }
 
     float a0[RB], a1[RB], b[RB][KTW], na0[RB], na1[RB], nb[RB][KTW];
     auto load = [&](long base, float (&A0)[RB], float (&A1)[RB], float (&B)[RB][KTW]) {
@@ -120,7 +120,6 @@ extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t
         CM_CHECK_LAUNCH("cm_critic_fwd_bwd");
         return finish_train(a, grid, P, grad_and_stats, s, "cm_critic_fwd_bwd");
     }
-    CM_REQUIRE(din <= 512, "cm_critic_fwd_bwd: input width %d > 512 is not supported by this build", din);
     // ---- split schedule: fused kernel without dW0 (two workgroups per CU) ...
     a.dz0 = (float*)ws + (size_t)MAX_GRID * a.PS;
     float* part2 = a.dz0 + (size_t)rows * HP;
@@ -129,16 +128,18 @@ extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t
     CM_CHECK_LAUNCH("cm_critic_fwd_bwd/fused");
     if (int rc = finish_train(a, grid, P, grad_and_stats, s, "cm_critic_fwd_bwd", hidden * din)) return rc;  // all but W0
     // ---- ... then the streaming layer-0 weight gradient
-    const int nkt = (din + 31) / 32, ktw = (nkt + 3) / 4;
     long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
     rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
     const int grid2 = (int)((rows + rpw - 1) / rpw);
     const int PS2 = hidden * din;
-    switch (ktw) {
-        case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2); break;
-        case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2); break;
-        case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2); break;
-        default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2); break;
+    for (int col0 = 0; col0 < din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
+        const int nkt = (min(512, din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
+        switch (ktw) {
+            case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
+            case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
+            case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
+            default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
+        }
     }
     CM_CHECK_LAUNCH("cm_critic_fwd_bwd/dw0");
     hipLaunchKernelGGL(k_reduce_partials, dim3((PS2 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part2, grid2, PS2, 0, PS2, grad_and_stats);

@@ -94,6 +94,10 @@ def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
     ("ippo", 5, 3, 8, 7, 11, 3, 48, 0),         # no hidden->hidden layer, odd H
 ])
 def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
+    _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
+
+
+def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize):
     from oracle import restatement as R
     from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
     torch.manual_seed(1)
@@ -102,7 +106,7 @@ def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
     cspec = NetSpec(Ds if algo == "mappo" else Do, H, L, 1)
     ap = init_params_like_torch(aspec)
     cp = init_params_like_torch(cspec)
-    hp = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=True, normalize_return=False, epochs=2, ppo_clip=0.2,
+    hp = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=normalize, normalize_return=False, epochs=2, ppo_clip=0.2,
               entropy_coef=0.01, clip_gradients=0.5, optimizer="Adam", learning_rate_actor=8e-4, learning_rate_critic=8e-4)
     dev = torch.device("cuda:0")
     b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"],
@@ -420,3 +424,55 @@ def test_full_size_update_is_deterministic_and_finite():
     assert torch.equal(L.actor, L2.actor) and torch.equal(L.critic, L2.critic)  # no atomics anywhere on the path
     assert all(np.isfinite(v) for r in r1 for v in r.values())
     assert [r["actor_loss"] for r in r1] == [r["actor_loss"] for r in r2]
+
+
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
+    ("mappo", 1, 1, 1, 3, 5, 2, 8, 1),      # smallest possible batch: one env, one agent, one step
+    ("ippo", 1, 2, 3, 4, 9, 1, 64, 1),      # single action (degenerate softmax), E = 1 (the reference's IPPO crashes here)
+    ("mappo", 3, 4, 70, 130, 1100, 32, 64, 2),  # widest supported head / 3 actor chunks / split critic schedule, 3 column windows
+])
+def test_update_edge_shapes_match_oracle(algo, E, A, T, Do, Ds, K, H, L):
+    _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=False)  # a single sample has no unbiased std
+
+
+def test_all_steps_masked_is_finite_and_a_no_op_for_the_gradient():
+    """ep_len == 0 everywhere (N = 0): statistics are zero, the gradient is zero, nothing is NaN."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    dev = torch.device("cuda:0")
+    E, A, T, Do, Ds, K = 5, 3, 9, 21, 54, 5
+    b = DeviceBatch(E, A, T, Do, Ds, K, dev)
+    b.obs.normal_(); b.state.normal_(); b.avail.fill_(1); b.reward.normal_()  # ep_len stays 0
+    torch.manual_seed(0)
+    L = PPOLearner("mappo", NetSpec(Do, 64, 1, K), NetSpec(Ds, 64, 1, 1), A, HParams(epochs=1), dev)
+    L.compute_targets(b)
+    assert (b.ret == 0).all() and (b.adv == 0).all()
+    s = N.stream_ptr()
+    L.actor_pass(b, s); L.critic_pass(b, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(L.gbuf).all() and (L.gbuf == 0).all()
+
+
+def test_rollout_edge_shapes():
+    """fused rollout with A that does not divide 64, a single env, T = 1; per-step path with an unsupported fused shape."""
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    from cleanmarl_amd.rollout import SyntheticSpreadRollout
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    for (E, A, T) in [(1, 7, 1), (130, 9, 3), (5, 1, 4)]:
+        ra = SyntheticSpreadRollout(E, A, T, seed=3, device=dev); rb = SyntheticSpreadRollout(E, A, T, seed=3, device=dev)
+        spec = NetSpec(ra.Do, 64, 1, 5)
+        p = flatten_params(init_params_like_torch(spec), dev)
+        ba, bb = ra.collect(p, spec, fused=True), rb.collect(p, spec, fused=False)
+        torch.cuda.synchronize()
+        assert torch.equal(ba.obs[:, :, 0], bb.obs[:, :, 0])
+        assert (ba.action == bb.action).float().mean().item() >= 0.98
+        assert torch.isfinite(ba.reward).all() and torch.isfinite(ba.logp).all()
+    r = SyntheticSpreadRollout(4, 12, 3, seed=3, device=dev)  # Do = 84 > 64: fused kernel refuses, per-step path serves it
+    spec = NetSpec(r.Do, 64, 1, 5)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    with pytest.raises(Exception):
+        r.collect(p, spec, fused=True)
+    b = r.collect(p, spec)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b.obs).all() and (b.action >= 0).all() and (b.action < 5).all()
