@@ -36,6 +36,16 @@ __device__ __forceinline__ void stage_lite(float* dst, const float* src, long ro
     }
 }
 
+// register-staged 64x64 block prefetch (Tile16 of cm_mlp_kernel.h).  The six H x H gate blocks use 16-byte loads when
+// the kernel is instantiated with WV (H % 4 == 0 and 16-byte aligned parameters); the obs tile and W1 (row stride
+// din, arbitrary) always use 4-byte loads -- they are one block out of seven per step.
+template <bool WV>
+__device__ __forceinline__ void gate_load(Tile16& t, const float* src, int H) { tile_load<WV>(t, src, 0, H, H, 0, H); }
+__device__ __forceinline__ void x_load(Tile16& t, const float* src, long row0, long nrows, long stride, int ncols) {
+    tile_load<false>(t, src, row0, nrows, stride, 0, ncols);
+}
+inline bool gru_wvec(const float* params, int H) { return (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0); }
+
 struct GruOff { int W1, b1, Wih, Whh, bih, bhh, W2, b2, P; };
 __host__ __device__ inline GruOff gru_offsets(int din, int H, int K) {
     GruOff o;
@@ -94,9 +104,13 @@ __device__ __forceinline__ void gru_stage_consts(const GruLds& L, const GruArgs&
 
 // One GRU forward step for the tile whose obs rows are already addressable through (xbase, xstride).
 // X=b0 W=b1 A1=b2 HP=hp HN=hn GR=b5 GZ=b6 W2=b7.  SAVE: also write the activations the backward pass needs.
-template <bool SAVE>
-__device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, const GruOff& off, const float* xbase,
-                                             long xstride, long row0, long nrows, float* hp, float* hn, float* wsrow /* ws_act + (s*R + row0)*WS_ACT */) {
+// tA / tB arrive holding this step's obs tile and W1 (issued by the caller or by the previous step); every weight block
+// of the step is requested one phase ahead of the ds_write that needs it, and the next step's obs tile + W1 are
+// requested under the last MFMA phase, so no staging load is ever waited for right after it was issued.
+template <bool SAVE, bool WV>
+__device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, const GruOff& off, Tile16& tA, Tile16& tB,
+                                             const float* xnext, long xstride, long row0, long nrows,
+                                             float* hp, float* hn, float* wsrow /* ws_act + (s*R + row0)*WS_ACT */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
     const int H = a.H, din = a.din;
@@ -105,8 +119,10 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
     f32x16 acc;
     // ---- F1: x1 = relu(fc1(obs))
     __syncthreads();
-    stage_lite(X, xbase, row0, nrows, xstride, 0, din);
-    stage_lite(W, a.params + off.W1, 0, H, din, 0, din);
+    tile_store<false>(X, tA);
+    tile_store<false>(W, tB);
+    gate_load<WV>(tA, a.params + off.Wih, H);
+    gate_load<WV>(tB, a.params + off.Whh, H);
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -125,8 +141,10 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
 #pragma unroll
     for (int gate = 0; gate < 2; ++gate) {
         __syncthreads();  // A1 complete / previous readers of W, W2 done
-        stage_lite(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
-        stage_lite(W2, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+        tile_store<WV>(W, tA);
+        tile_store<WV>(W2, tB);
+        gate_load<WV>(tA, a.params + off.Wih + (gate + 1) * H * H, H);
+        gate_load<WV>(tB, a.params + off.Whh + (gate + 1) * H * H, H);
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -144,8 +162,12 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
     }
     // ---- F3: candidate n and the new hidden state
     __syncthreads();
-    stage_lite(W, a.params + off.Wih + 2 * H * H, 0, H, H, 0, H);
-    stage_lite(W2, a.params + off.Whh + 2 * H * H, 0, H, H, 0, H);
+    tile_store<WV>(W, tA);
+    tile_store<WV>(W2, tB);
+    if (xnext) {  // next step's obs tile + W1 land under this phase's MFMAs
+        x_load(tA, xnext, row0, nrows, xstride, din);
+        x_load(tB, a.params + off.W1, 0, H, din, din);
+    }
     __syncthreads();
     f32x16 acch;
 #pragma unroll
@@ -207,7 +229,7 @@ __device__ __forceinline__ void gru_head_logits(const GruLds& L, const float* hn
 }
 
 // ============================================================================================ chunk fwd + bwd
-template <int KJ>
+template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = KJ * 4;
@@ -239,9 +261,13 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
             hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
         }
         // ================================ forward over the chunk
+        Tile16 tA, tB;
+        x_load(tA, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
+        x_load(tB, a.params + off.W1, 0, H, din, din);
         for (int s = 0; s < CL; ++s) {
             const int t = a.t0 + s;
-            gru_fwd_step<true>(L, a, off, a.obs + (long)t * din, (long)T * din, row0, R, hp, hn, a.ws_act + (s * R + row0) * WS_ACT);
+            gru_fwd_step<true, WV>(L, a, off, tA, tB, (s + 1 < CL) ? a.obs + (long)(t + 1) * din : nullptr, (long)T * din, row0, R,
+                               hp, hn, a.ws_act + (s * R + row0) * WS_ACT);
             // ---- PPO head on relu(h'): statistics + dlogits (saved for the backward sweep)
             unsigned char avb[KJ];
 #pragma unroll
@@ -323,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
     }
 }
 
-template <int KJ>
+template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = KJ * 4;
@@ -421,7 +447,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
                 DH[r * LDT + c] = dh * zz;
             }
             __syncthreads();
-            // ---- B3: weight gradients of the gates
+            // ---- B3: weight gradients of the gates (the first weight block of B4 is requested now, under these MFMAs)
+            Tile16 tw;
+            gate_load<WV>(tw, a.params + off.Wih, H);
             colred(accWih[0], G0 + 32 * wm, A1 + 32 * wn);
             colred(accWih[1], G1 + 32 * wm, A1 + 32 * wn);
             colred(accWih[2], G2 + 32 * wm, A1 + 32 * wn);
@@ -445,7 +473,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
                 __syncthreads();
-                stage_lite(W, a.params + off.Wih + gate * H * H, 0, H, H, 0, H);
+                tile_store<WV>(W, tw);
+                gate_load<WV>(tw, a.params + (gate < 2 ? off.Wih + (gate + 1) * H * H : off.Whh), H);
                 __syncthreads();
                 rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G2) + 32 * wm * LDT, W + 32 * wn);
             }
@@ -456,7 +485,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
                 __syncthreads();
-                stage_lite(W, a.params + off.Whh + gate * H * H, 0, H, H, 0, H);
+                tile_store<WV>(W, tw);
+                if (gate < 2) gate_load<WV>(tw, a.params + off.Whh + (gate + 1) * H * H, H);
+                else x_load(tw, a.obs + (long)t * din, row0, R, (long)T * din, din);  // obs tile for B6
                 __syncthreads();
                 rowpar_tn(acch, (gate == 0 ? G0 : gate == 1 ? G1 : G3) + 32 * wm * LDT, W + 32 * wn);
             }
@@ -469,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
                 DH[row * LDT + col] += acch[g];
             }
             // ---- B6: fc1 weight gradient: obs tile -> G0
-            stage_lite(G0, a.obs + (long)t * din, row0, R, (long)T * din, 0, din);
+            tile_store<false>(G0, tw);
             __syncthreads();
             colred(accW1, A1 + 32 * wm, G0 + 32 * wn);
             {
@@ -540,7 +571,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
 }
 
 // ============================================================================================ rollout step
-template <int KJ>
+template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = KJ * 4;
@@ -559,7 +590,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
             const int r = i >> 6, c = i & 63;
             hp[r * LDT + c] = (row0 + r < a.rows && c < H) ? a.h[(row0 + r) * H + c] : 0.0f;
         }
-        gru_fwd_step<false>(L, a, off, a.x, a.x_stride, row0, a.rows, hp, hn, nullptr);
+        Tile16 tA, tB;
+        x_load(tA, a.x, row0, a.rows, a.x_stride, a.din);
+        x_load(tB, a.params + off.W1, 0, H, a.din, a.din);
+        gru_fwd_step<false, WV>(L, a, off, tA, tB, nullptr, a.x_stride, row0, a.rows, hp, hn, nullptr);
         for (int i = tid; i < TM * HP; i += NTHREADS) {
             const int r = i >> 6, c = i & 63;
             if (row0 + r < a.rows && c < H) a.h[(row0 + r) * H + c] = hn[r * LDT + c];
@@ -630,17 +664,15 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     a.PS = (int)gru_ps(din, hidden, n_actions);
     const int grid = grid_for((long)R);
     const size_t lds = gru_lds_bytes(n_actions);
-    if (n_actions <= 8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_chunk_fwd<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-        hipLaunchKernelGGL((k_gru_chunk_bwd<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_fwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_chunk_fwd<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-        hipLaunchKernelGGL((k_gru_chunk_bwd<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-    }
+    const bool wv = gru_wvec(params, hidden);
+#define CM_GRU_LAUNCH2(KJ_, WV_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_fwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_gru_chunk_fwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); \
+        hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
+    if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
+    else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }
+#undef CM_GRU_LAUNCH2
     CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
     MlpArgs m = {};
     m.partial = a.partial; m.PS = a.PS;
@@ -660,13 +692,13 @@ extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uin
     a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
     const size_t lds = gru_lds_bytes(n_actions);
     const int grid = grid_for(rows);
-    if (n_actions <= 8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_act<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_act<2>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_act<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_gru_act<8>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a);
-    }
+    const bool wv = gru_wvec(params, hidden);
+#define CM_GRU_LAUNCH1(KJ_, WV_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_act<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_gru_act<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
+    if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH1(2, true); else CM_GRU_LAUNCH1(2, false); }
+    else { if (wv) CM_GRU_LAUNCH1(8, true); else CM_GRU_LAUNCH1(8, false); }
+#undef CM_GRU_LAUNCH1
     CM_CHECK_LAUNCH("cm_gru_policy_act");
     return 0;
 }
