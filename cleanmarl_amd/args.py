@@ -81,6 +81,12 @@ class Args:
     """ [build] number of agents of the synthetic MPE-like env"""
     synthetic_steps: int = 25
     """ [build] fixed episode length (max_cycles) of the synthetic env"""
+    checkpoint: str = ""
+    """ [build] path of a checkpoint file: loaded at start if it exists, written at the end (and every checkpoint_every iterations)"""
+    checkpoint_every: int = 0
+    """ [build] write the checkpoint every N training iterations (0 = only at the end)"""
+    greedy_eval: bool = False
+    """ [build] evaluate with argmax actions instead of sampling (MLP actors; the reference always samples)"""
 
 
 # per-script default overrides (SURVEY.md Appendix B)

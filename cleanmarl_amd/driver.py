@@ -34,7 +34,7 @@ class HostActor:
         self.lib = N.load()
         self.calls = 0
 
-    def act(self, obs, avail, h=None, seed=0):
+    def act(self, obs, avail, h=None, seed=0, greedy=False):
         spec = self.L.actor_spec
         x = torch.as_tensor(np.ascontiguousarray(obs), dtype=torch.float32).reshape(-1, spec.din).to(self.dev)
         av = torch.as_tensor(np.ascontiguousarray(avail)).reshape(-1, spec.dout).to(torch.uint8).to(self.dev)
@@ -42,6 +42,13 @@ class HostActor:
         action = torch.empty(rows, dtype=torch.int32, device=self.dev)
         logp = torch.empty(rows, dtype=torch.float32, device=self.dev)
         self.calls += 1
+        if greedy and not self.recurrent:  # argmax of the masked logits (eval only; a few rows)
+            logits = torch.empty(rows, spec.dout, dtype=torch.float32, device=self.dev)
+            N.check(self.lib.cm_mlp_forward(N.ptr(x), rows, spec.din, spec.hidden, spec.n_layers, spec.dout, N.ptr(self.L.actor),
+                                            N.ptr(av), N.ptr(logits), N.stream_ptr()), "cm_mlp_forward")
+            a = logits.argmax(-1)
+            lp = torch.log_softmax(logits, -1).gather(-1, a[:, None])[:, 0]
+            return a.int().cpu().numpy(), lp.cpu().numpy(), h
         if self.recurrent:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
@@ -168,6 +175,18 @@ def run(script, argv=None):
 
     ep_rewards, ep_lengths, ep_stats = [], [], []
     training_step = num_episodes = step = 0
+    if args.checkpoint and os.path.exists(args.checkpoint):  # resume (every rank loads the same replicated state)
+        ck = torch.load(args.checkpoint, map_location="cpu")
+        learner.load_state_dict(ck["learner"])
+        training_step, num_episodes, step = ck["training_step"], ck["num_episodes"], ck["step"]
+        if roll is not None:
+            roll.episode = ck.get("episode", 0)
+
+    def save_checkpoint():
+        if args.checkpoint and rank == 0:
+            torch.save(dict(learner=learner.state_dict(), training_step=training_step, num_episodes=num_episodes, step=step,
+                            episode=roll.episode if roll is not None else 0), args.checkpoint)
+    iteration = 0
     while step < args.total_timesteps:
         if device_env:
             b = roll.collect(learner.actor, actor_spec)
@@ -195,6 +214,9 @@ def run(script, argv=None):
 
         recs = learner.train_iteration(b)
         training_step += len(recs)
+        iteration += 1
+        if args.checkpoint_every and iteration % args.checkpoint_every == 0:
+            save_checkpoint()
         if writer:  # train/* are means over epochs (:605-612)
             m = lambda k: float(np.mean([r[k] for r in recs]))
             writer.add_scalar("train/critic_loss", m("critic_loss"), step)
@@ -211,7 +233,7 @@ def run(script, argv=None):
             rets, lens, infos_l, cur_r, cur_l, h_eval = [], [], [], 0.0, 0, None
             while len(rets) < args.num_eval_ep:
                 act, _, h_eval = host_actor.act(eval_obs[None], np.asarray(eval_env.get_avail_actions())[None], h=h_eval,
-                                                seed=args.seed + 7919)
+                                                seed=args.seed + 7919, greedy=args.greedy_eval)
                 eval_obs, r, done, trunc, info = eval_env.step(act.reshape(-1))
                 cur_r += r; cur_l += 1
                 if done or trunc:
@@ -223,6 +245,7 @@ def run(script, argv=None):
             if args.env_type == "smaclite":
                 writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
 
+    save_checkpoint()
     if writer:
         writer.close()
     if args.use_wnb and rank == 0:

@@ -286,3 +286,18 @@ class PPOLearner:
     def train_iteration(self, b, keep_grads=False):
         self.compute_targets(b)
         return self.update(b, keep_grads=keep_grads)
+
+    # ------------------------------------------------------------------ checkpointing (README TODO of the reference)
+    def state_dict(self):
+        """Flat parameters + Adam moments + step counters (CPU tensors; torch.save-able)."""
+        return dict(algo=self.algo, actor_spec=vars(self.actor_spec), critic_spec=vars(self.critic_spec),
+                    actor=self.actor.cpu(), critic=self.critic.cpu(),
+                    opt_a=dict(m=self.opt_a.m.cpu(), v=self.opt_a.v.cpu(), step=self.opt_a.step),
+                    opt_c=dict(m=self.opt_c.m.cpu(), v=self.opt_c.v.cpu(), step=self.opt_c.step))
+
+    def load_state_dict(self, sd):
+        if sd["algo"] != self.algo or sd["actor_spec"] != vars(self.actor_spec) or sd["critic_spec"] != vars(self.critic_spec):
+            raise N.NativeError("checkpoint was written for a different algorithm / network shape")
+        self.actor.copy_(sd["actor"]); self.critic.copy_(sd["critic"])
+        for opt, o in ((self.opt_a, sd["opt_a"]), (self.opt_c, sd["opt_c"])):
+            opt.m.copy_(o["m"]); opt.v.copy_(o["v"]); opt.step = int(o["step"])

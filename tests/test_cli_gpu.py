@@ -37,3 +37,19 @@ def test_learning_signal_on_synthetic_env(tmp_path, monkeypatch):
     assert len(r) >= 100
     first, last = sum(r[:10]) / 10, sum(r[-10:]) / 10
     assert last > first + 0.05 * abs(first), (first, last)
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path, monkeypatch):
+    """train 4 iterations in one go == train 2, checkpoint, resume 2 (replicated state + counter-based env/action RNG)."""
+    import torch
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    common = ["--env_type=synthetic", "--batch_size=16", "--synthetic_agents=3", "--synthetic_steps=10", "--eval_steps=100000",
+              "--greedy_eval"]
+    full = run("mappo_multienvs", common + ["--total_timesteps=640"])
+    ck = str(tmp_path / "ck.pt")
+    run("mappo_multienvs", common + ["--total_timesteps=320", f"--checkpoint={ck}"])
+    res = run("mappo_multienvs", common + ["--total_timesteps=640", f"--checkpoint={ck}"])
+    assert res["training_step"] == full["training_step"] == 12
+    assert torch.equal(res["learner"].actor, full["learner"].actor) and torch.equal(res["learner"].critic, full["learner"].critic)
+    assert torch.equal(res["learner"].opt_a.v, full["learner"].opt_a.v)
