@@ -81,6 +81,10 @@ class Args:
     """ [build] number of agents of the synthetic MPE-like env"""
     synthetic_steps: int = 25
     """ [build] fixed episode length (max_cycles) of the synthetic env"""
+    vector_env: str = "shm"
+    """ [build] host-env vectorisation: shm (shared-memory, batched step per worker) or pipe (the reference's one process + Pipe per env)"""
+    env_workers: int = 0
+    """ [build] worker processes of the shm vector env (0 = one per host core, at most one per env)"""
     checkpoint: str = ""
     """ [build] path of a checkpoint file: loaded at start if it exists, written at the end (and every checkpoint_every iterations)"""
     checkpoint_every: int = 0

@@ -15,6 +15,7 @@ import torch
 
 from . import _native as N
 from .args import parse_args
+from .env.shm_vector import ShmVectorEnv
 from .env.vector import PipeVectorEnv, environment
 from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
 from .logger import ScalarWriter
@@ -113,6 +114,31 @@ def host_rollout(venv, actor, E, A, seed, recurrent, device):
     return b, dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
 
 
+def host_rollout_shm(venv, actor, E, A, seed, recurrent, device):
+    """Same episode collection through the shared-memory batched-step vector env: one token per
+    WORKER per step instead of one pickled round trip per ENV.  Returns the same (DeviceBatch, stats)."""
+    hstate = {"h": None}
+
+    def act_fn(obs, avail, alive):
+        h_in = None
+        if recurrent and hstate["h"] is not None:
+            idx = torch.as_tensor(alive, device=device)
+            h_in = hstate["h"].reshape(E, A, -1)[idx].reshape(len(alive) * A, -1).contiguous()
+        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed)
+        if recurrent:
+            if hstate["h"] is None:
+                hstate["h"] = h_out
+            else:
+                hstate["h"].reshape(E, A, -1)[torch.as_tensor(alive, device=device)] = h_out.reshape(len(alive), A, -1)
+        return act.reshape(len(alive), A), logp.reshape(len(alive), A)
+
+    out, mask, stats = venv.collect_episode(act_fn)
+    t = torch.from_numpy
+    b = DeviceBatch.from_reference_layout(t(out["obs"]), t(out["act"]), t(out["logp"]), t(out["rew"]), t(out["state"]),
+                                          t(out["avail"]), t(mask), device)
+    return b, stats
+
+
 def run(script, argv=None):
     args = parse_args(script, argv)
     algo = "mappo" if script.startswith("mappo") else "ippo"
@@ -159,8 +185,10 @@ def run(script, argv=None):
         else:
             roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
                                           env_offset=env_offset)
-    else:
+    elif args.vector_env == "pipe":
         venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
+    else:
+        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None)
     host_actor = HostActor(learner, A, recurrent, device)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
@@ -193,7 +221,8 @@ def run(script, argv=None):
             rew = b.reward.sum(1).cpu().tolist()
             stats = dict(ep_reward=rew, ep_len=[b.T] * E, infos=[None] * E)
         else:
-            b, stats = host_rollout(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
+            collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
+            b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
         n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
         if world > 1:
             torch.distributed.all_reduce(n_steps, group=pg)

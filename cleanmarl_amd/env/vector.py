@@ -13,8 +13,10 @@ def environment(env_type, env_name, env_family, agent_ids, kwargs=None, index=0,
     if env_type in ("synthetic", "synthetic_cpu"):
         from .synthetic import SyntheticSpreadEnv
         s = synthetic or {}
-        return SyntheticSpreadEnv(n_agents=s.get("agents", 3), agent_ids=agent_ids, max_cycles=s.get("steps", 25),
-                                  seed=seed, env_index=index)
+        steps = s.get("steps", 25)
+        if s.get("ragged"):  # episodes of different lengths (exercises the shrinking alive set / zero padding)
+            steps = max(1, steps - index % 4)
+        return SyntheticSpreadEnv(n_agents=s.get("agents", 3), agent_ids=agent_ids, max_cycles=steps, seed=seed, env_index=index)
     if env_type == "pz":
         mod = importlib.import_module("cleanmarl_amd.env.pettingzoo_wrapper")
         return mod.PettingZooWrapper(family=env_family, env_name=env_name, agent_ids=agent_ids, **kwargs)

@@ -69,6 +69,34 @@ def test_pipe_vector_env_and_collation():
     assert b.avail.all() and (b.logp == -1.5).all()
 
 
+def test_shm_vector_env_matches_pipe_protocol_and_is_faster():
+    """the shared-memory batched-step vector env collects the same batch as the reference-style
+    pipe-per-env protocol (ragged episode lengths included) with fewer host round trips."""
+    import time
+    from cleanmarl_amd.driver import host_rollout, host_rollout_shm
+    from cleanmarl_amd.env.shm_vector import ShmVectorEnv
+    from cleanmarl_amd.env.vector import PipeVectorEnv
+    E, A, T = 24, 3, 12
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=5,
+               synthetic=dict(agents=A, steps=T, ragged=True))
+
+    class Stub:  # deterministic actor: the action is a function of the observation only
+        def act(self, obs, avail, h=None, seed=0):
+            a = (np.abs(obs[..., :4]).sum(-1) * 1000).astype(np.int64) % 5
+            return a.reshape(-1).astype(np.int32), np.full(a.size, -0.7, np.float32), None
+
+    pv = PipeVectorEnv(E, fac)
+    t0 = time.perf_counter(); b1, s1 = host_rollout(pv, Stub(), E, A, 0, False, torch.device("cpu")); t_pipe = time.perf_counter() - t0
+    pv.close()
+    sv = ShmVectorEnv(E, fac, n_workers=4)
+    t0 = time.perf_counter(); b2, s2 = host_rollout_shm(sv, Stub(), E, A, 0, False, torch.device("cpu")); t_shm = time.perf_counter() - t0
+    sv.close()
+    for k in ("obs", "state", "avail", "action", "logp", "reward", "ep_len"):
+        assert torch.equal(getattr(b1, k), getattr(b2, k)), k
+    assert s1["ep_len"] == s2["ep_len"] and len(set(s1["ep_len"])) > 1 and np.allclose(s1["ep_reward"], s2["ep_reward"], atol=1e-5)
+    assert t_shm < t_pipe * 1.5  # not a benchmark (24 tiny envs); tools/bench_host_env.py measures the real gap
+
+
 def test_library_exports_every_declared_symbol():
     """include/cleanmarl_hip.h <-> libcleanmarl_hip.so <-> ctypes table stay in sync (no GPU needed)."""
     from cleanmarl_amd import _native
