@@ -38,7 +38,7 @@ __host__ __device__ inline cm_u4 cm_philox4x32(uint32_t c0, uint32_t c1, uint32_
 // uniform in [0,1) with 24 random bits (exactly representable in fp32)
 __host__ __device__ inline float cm_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-enum { CM_STREAM_ACT = 1, CM_STREAM_ENV_RESET = 2, CM_STREAM_ENV_STEP = 3 };
+enum { CM_STREAM_ACT = 1, CM_STREAM_ENV_RESET = 2 };  // Philox stream ids (4th counter word)
 
 // Categorical(logits).sample() + log_prob (cleanmarl/mappo_multienvs.py:172-176) by inverse CDF on one uniform u.
 // z: K logits already masked with -1e9 (entries <= -5e8 count as unavailable).  One exp per action:

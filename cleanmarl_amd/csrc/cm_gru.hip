@@ -19,23 +19,6 @@
 
 namespace {
 
-// weight-block / obs staging for the GRU kernels: the same mapping as stage_rows but only 4 loads in flight per
-// thread (these kernels carry up to eight MFMA accumulator tiles and cannot afford 16 staging registers)
-__device__ __forceinline__ void stage_lite(float* dst, const float* src, long row0, long nrows, long stride, int col0, int ncols) {
-    const int k = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-    const bool kok = k < ncols;
-    const float* p = src + (row0 + r0) * stride + col0 + k;
-    const long step = 4 * stride;
-#pragma unroll 1
-    for (int i = 0; i < TM / 4; i += 4) {
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = (kok && row0 + r0 + 4 * (i + q) < nrows) ? *p : 0.0f; p += step; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[(r0 + 4 * (i + q)) * LDT + k] = v[q];
-    }
-}
-
 // register-staged 64x64 block prefetch (Tile16 of cm_mlp_kernel.h).  The six H x H gate blocks use 16-byte loads when
 // the kernel is instantiated with WV (H % 4 == 0 and 16-byte aligned parameters); the obs tile and W1 (row stride
 // din, arbitrary) always use 4-byte loads -- they are one block out of seven per step.

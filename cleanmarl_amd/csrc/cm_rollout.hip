@@ -50,8 +50,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     float* epos = ls + TM * 8;           // [TM][2] per row (env-local agent)
     float* evel = epos + TM * 2;
     float* elm = evel + TM * 2;          // [EPT*A][2] landmarks of env el at elm + el*2A
-    int* eact = reinterpret_cast<int*>(elm + TM * 2);  // [TM]
-    long* obase = reinterpret_cast<long*>(eact + TM);  // [TM] obs row base (elements), -1 = dead row
+    long* obase = reinterpret_cast<long*>(elm + TM * 2 + TM);  // [TM] obs row base (elements), -1 = dead row (8-byte aligned: +TM pad)
     long* sbase = obase + TM;                          // [TM] state row base
     float* rscr = reinterpret_cast<float*>(sbase + TM);  // [2][TM] reward partials
 

@@ -6,7 +6,6 @@ Mirrors the inline learner of the reference script (cleanmarl/mappo_multienvs.py
 but every numeric step is a call into libcleanmarl_hip.so on the current HIP stream.  PyTorch only
 provides device memory, streams and (for env-sharded multi-GPU runs) torch.distributed.
 """
-import math
 from dataclasses import dataclass
 
 import torch
@@ -42,7 +41,7 @@ class NetSpec:
         return s + [(K, H), (K,)]
 
 
-def init_params_like_torch(spec, generator=None):
+def init_params_like_torch(spec):
     """nn.Linear / nn.GRUCell default init (U(+-1/sqrt(fan_in))), drawn on the CPU in the reference's
     construction order so `torch.manual_seed(seed)` reproduces the reference's initial weights
     (cleanmarl/mappo_multienvs.py:329-339)."""
@@ -58,15 +57,6 @@ def init_params_like_torch(spec, generator=None):
 
 def flatten_params(plist, device):
     return torch.cat([p.reshape(-1).float() for p in plist]).contiguous().to(device)
-
-
-def unflatten_params(flat, spec):
-    out, o = [], 0
-    for shp in spec.shapes():
-        n = math.prod(shp)
-        out.append(flat[o:o + n].reshape(shp))
-        o += n
-    return out
 
 
 class DeviceBatch:

@@ -85,9 +85,9 @@ int cm_td_lambda_scan(const float* reward, const float* values, const int32_t* e
                       float* ret, float* adv, cm_stream_t stream);
 
 /* ---- a2 / a7: masked moments + normalisation ----
- * moments of the AGENT-MEAN of x[E][A][T] over valid (e,t):  out[0]=count, out[1]=sum, out[2]=sum of
- * squares about the shard mean... see cm_masked_moments for the exact (count, mean, M2) triple so that
- * shards can be merged Chan-style across GPUs.  (cleanmarl/mappo_multienvs.py:143-146, 505-512) */
+ * Moments of the AGENT-MEAN y[e,t] = mean_a x[e][a][t] over the valid (e,t) pairs, as a float64 triple
+ * out = (count, mean, M2 = sum (y - mean)^2) that env shards can merge Chan-style across GPUs before the
+ * unbiased std is taken (cleanmarl/mappo_multienvs.py:143-146 with A = 1 for rewards, :505-512). */
 size_t cm_masked_moments_workspace_bytes(int E, int A, int T);
 int cm_masked_moments(const float* x, const int32_t* ep_len, int E, int A, int T,
                       double* out_count_mean_m2 /* device, 3 doubles */, void* ws, size_t ws_bytes,
