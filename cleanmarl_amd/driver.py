@@ -17,7 +17,7 @@ from . import _native as N
 from .args import parse_args
 from .env.shm_vector import ShmVectorEnv
 from .env.vector import PipeVectorEnv, environment
-from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch, pad_time
 from .logger import ScalarWriter
 from .rollout import SyntheticSpreadRollout
 
@@ -226,6 +226,10 @@ def run(script, argv=None):
         n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
         if world > 1:
             torch.distributed.all_reduce(n_steps, group=pg)
+            if not device_env:  # host envs end at different steps on different ranks: agree on the padded length
+                t_max = torch.tensor([b.T], device=device)
+                torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX, group=pg)
+                b = pad_time(b, int(t_max.item()))
         step += int(n_steps.item())  # counts ENV steps, like the reference (:435)
         ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
         if args.env_type == "smaclite":

@@ -92,6 +92,18 @@ class DeviceBatch:
         return self
 
 
+def pad_time(b, T):
+    """Zero-pad a DeviceBatch along the time axis to T steps (ep_len unchanged: the extra steps are masked).  Used so
+    that env-sharded ranks with host envs agree on T (same TBPTT chunk schedule => same number of all-reduces)."""
+    if T == b.T:
+        return b
+    assert T > b.T
+    n = DeviceBatch(b.E, b.A, T, b.Do, b.Ds, b.K, b.device)
+    n.obs[:, :, :b.T] = b.obs; n.state[:, :b.T] = b.state; n.avail[:, :, :b.T] = b.avail; n.action[:, :, :b.T] = b.action
+    n.logp[:, :, :b.T] = b.logp; n.reward[:, :b.T] = b.reward; n.ep_len.copy_(b.ep_len)
+    return n
+
+
 @dataclass
 class HParams:
     """The learner-relevant subset of the reference's Args (cleanmarl/mappo_multienvs.py:18-79)."""

@@ -476,3 +476,28 @@ def test_rollout_edge_shapes():
     b = r.collect(p, spec)
     torch.cuda.synchronize()
     assert torch.isfinite(b.obs).all() and (b.action >= 0).all() and (b.action < 5).all()
+
+
+def test_time_padding_does_not_change_the_update():
+    """pad_time (used to align T across env-sharded ranks) adds masked steps only: identical targets, losses, params.
+    (MLP scripts only: the GRU scripts divide each TBPTT chunk loss by the chunk's step count INCLUDING padded steps,
+    cleanmarl/mappo_lstm_multienvs.py:603-607, so there T must be -- and is -- the global maximum, as in the reference.)"""
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch, pad_time
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    batch = _random_case(77, 9, 3, 11, 21, 54, 5)
+    aspec, cspec = NetSpec(21, 64, 1, 5), NetSpec(54, 64, 1, 1)
+    ap, cp = init_params_like_torch(aspec), init_params_like_torch(cspec)
+    outs = []
+    for T_pad in (11, 20):
+        b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"],
+                                              batch["states"], batch["avail"], batch["mask"], dev)
+        b = pad_time(b, T_pad)
+        L = PPOLearner("mappo", aspec, cspec, 3, HParams(epochs=2), dev, [p.clone() for p in ap], [p.clone() for p in cp])
+        recs = L.train_iteration(b)
+        outs.append((b.ret[:, :, :11].clone(), L.actor.clone(), L.critic.clone(), [r["actor_loss"] for r in recs]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    # row tiles are cut at different places (rows = (e*A + a)*T + t), so sums re-associate: equal to fp32 round-off
+    assert _err(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 1e-6
+    assert _err(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 1e-6
+    assert _err(outs[0][3], outs[1][3]) <= 1e-6
