@@ -25,9 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (E, A, T, algo, description)   -- BASELINE.json configs[2] is the headline (metric is quoted on it)
-    "cfg3": (4096, 8, 128, "mappo", "MAPPO synthetic-MPE 4096 envs x 8 agents x 128 steps, 2x64 MLP (BASELINE.json configs[2])"),
-    "cfg2": (1024, 3, 128, "mappo", "MAPPO synthetic-MPE 1024 envs x 3 agents x 128 steps, 2x64 MLP (BASELINE.json configs[1])"),
+    # name: (envs per GPU, A, T, algo, env, actor, description) -- BASELINE.json configs[2] is the headline (the metric is
+    # quoted on it) and the default; the others are parity-test cases that can be timed on request (--workload)
+    "cfg3": (4096, 8, 128, "mappo", "spread", "mlp", "MAPPO synthetic-MPE 4096 envs x 8 agents x 128 steps, 2x64 MLP (BASELINE.json configs[2])"),
+    "cfg2": (1024, 3, 128, "mappo", "spread", "mlp", "MAPPO synthetic-MPE 1024 envs x 3 agents x 128 steps, 2x64 MLP (BASELINE.json configs[1])"),
+    "cfg4": (256, 10, 256, "ippo", "shape", "mlp", "IPPO smaclite-shape synthetic, 256 envs per GPU (2048 / 8 GPUs) x 10 agents x 256 steps, 2x64 MLP (BASELINE.json configs[3])"),
+    "cfg5": (1024, 5, 128, "mappo", "spread", "gru", "MAPPO-GRU synthetic-MPE 1024 envs x 5 agents x 128 steps, GRU hidden 64, tbptt 10 (BASELINE.json configs[4])"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
@@ -56,21 +59,26 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = torch.distributed.group.WORLD
 
+    from cleanmarl_amd.gru import GRUPPOLearner, GRUSyntheticRollout
     from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch
-    from cleanmarl_amd.rollout import SyntheticSpreadRollout
+    from cleanmarl_amd.rollout import SyntheticShapeRollout, SyntheticSpreadRollout
 
-    E, A, T, algo, desc = WORKLOADS[args.workload]
+    E, A, T, algo, env_kind, actor_kind, desc = WORKLOADS[args.workload]
     if args.envs:
         E = args.envs
-    hp = HParams()  # reference defaults: gamma .99, lambda .95, eps .2, c_ent 1e-3, lr 8e-4, epochs 3
-    roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
-    aspec = NetSpec(roll.Do, 64, 1, roll.K)
-    cspec = NetSpec(roll.Ds, 64, 1, 1)
+    hp = HParams()  # reference defaults: gamma .99, lambda .95, eps .2, c_ent 1e-3, lr 8e-4, epochs 3 (tbptt 10)
+    if env_kind == "shape":
+        roll = SyntheticShapeRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
+    elif actor_kind == "gru":
+        roll = GRUSyntheticRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
+    else:
+        roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
+    aspec = NetSpec(roll.Do, 64, 0 if actor_kind == "gru" else 1, roll.K, actor_kind)
+    cspec = NetSpec(roll.Ds if algo == "mappo" else roll.Do, 64, 1, 1)
     torch.manual_seed(1)  # reference construction order actor -> critic (:329-339); identical on every rank
     a_init = init_params_like_torch(aspec)
     c_init = init_params_like_torch(cspec)
-    learner = PPOLearner(algo, aspec, cspec, A, hp, dev, actor_params=a_init, critic_params=c_init,
-                         process_group=pg, world_size=world)
+    learner = (GRUPPOLearner if actor_kind == "gru" else PPOLearner)(algo, aspec, cspec, A, hp, dev, a_init, c_init, pg, world)
 
     def barrier():
         if world > 1:
@@ -122,7 +130,10 @@ def main():
     if rank == 0:
         units = world * E * A * T * args.steps
         rows_a = E * A * T
-        Pa = aspec.din * 64 + 64 * 64 + 64 * roll.K
+        if actor_kind == "gru":  # fc1 + 6 gate blocks + head
+            Pa = aspec.din * 64 + 6 * 64 * 64 + 64 * roll.K
+        else:
+            Pa = aspec.din * 64 + 64 * 64 + 64 * roll.K
         flop_actor = rows_a * (2 * Pa + 2 * Pa + 2 * (Pa - aspec.din * 64))  # fwd + dW + dX
         avg_actor_ms = sum(act_ms) / max(1, len(act_ms))
         achieved = flop_actor / (avg_actor_ms * 1e-3) / 1e12 if avg_actor_ms > 0 else 0.0
@@ -136,7 +147,8 @@ def main():
             "ppo_update_ms": phases[2], "ppo_update_ms_per_epoch": phases[2] / hp.epochs,
             "phase_ms": {"rollout": phases[0], "value_pass_scan": phases[1], "update": phases[2]},
             "kernel_ms": {"actor_fwd_bwd": avg_actor_ms, "critic_fwd_bwd": sum(cri_ms) / max(1, len(cri_ms))},
-            "roofline": {"kernel": "k_mlp<1,M_ACTOR> (cm_ppo_actor_fwd_bwd)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_mlp<NCH,M_ACTOR> (cm_ppo_actor_fwd_bwd)" if actor_kind == "mlp" else
+                         "k_gru_chunk_fwd + k_gru_chunk_bwd (all TBPTT chunks of one epoch)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "flop_per_launch": flop_actor},
         }

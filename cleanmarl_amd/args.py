@@ -5,7 +5,8 @@ Every field, default and help string mirrors the reference's ``@dataclass Args``
 cleanmarl/ippo_lstm_multienvs.py:18-80); tyro is not a dependency here, so an argparse front-end reproduces its
 spelling rules: ``--a_b=v``, ``--a_b v``, ``--a-b v`` and ``--flag / --no-flag`` (also ``--flag=True|False``).
 Build-only additions never change an existing default: ``--env_type=synthetic`` (on-device MPE-like env) /
-``synthetic_cpu`` (same env on the host behind the pipe protocol) with ``--synthetic_agents`` and
+``synthetic_cpu`` (same env on the host behind the vector-env protocol), ``synthetic_shape`` / ``synthetic_shape_cpu``
+(SMAClite-shaped random-feature env with availability masks) with ``--synthetic_agents`` and
 ``--synthetic_steps``; ``--device`` defaults to ``cuda`` because this build has no CPU compute path.
 """
 import argparse
@@ -81,6 +82,14 @@ class Args:
     """ [build] number of agents of the synthetic MPE-like env"""
     synthetic_steps: int = 25
     """ [build] fixed episode length (max_cycles) of the synthetic env"""
+    synthetic_obs: int = 105
+    """ [build] raw obs width of --env_type=synthetic_shape (one-hot agent ids are appended when agent_ids)"""
+    synthetic_state: int = 243
+    """ [build] global state width of --env_type=synthetic_shape"""
+    synthetic_actions: int = 17
+    """ [build] number of actions of --env_type=synthetic_shape (action 0 is always available)"""
+    synthetic_avail_p: float = 0.7
+    """ [build] availability probability of the other actions of --env_type=synthetic_shape"""
     vector_env: str = "shm"
     """ [build] host-env vectorisation: shm (shared-memory, batched step per worker) or pipe (the reference's one process + Pipe per env)"""
     env_workers: int = 0

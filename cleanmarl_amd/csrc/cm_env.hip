@@ -114,7 +114,80 @@ __global__ __launch_bounds__(256) void k_env_step(float* __restrict__ env_state,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "shape" env: a fixed-shape stand-in for envs we cannot ship (SMAClite-like: wide obs, separate global state, 17
+// actions with availability masks).  Observations / states / masks are a pure function of (seed, env, episode, t),
+// so the whole episode's inputs are generated by ONE launch; the team reward depends on the sampled actions.
+__device__ __forceinline__ float normal01(uint32_t a, uint32_t b) {  // Box-Muller on two Philox words
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = cm_u01(b);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__global__ __launch_bounds__(256) void k_shape_fill(int E, int A, int T, int obs_raw, int agent_ids, int Ds, int K, float avail_p,
+                                                    unsigned long long seed, long env_offset, long episode,
+                                                    float* __restrict__ obs, float* __restrict__ state, uint8_t* __restrict__ avail) {
+    const int Do = obs_raw + (agent_ids ? A : 0);
+    const long n_obs = (long)E * A * T * Do, n_state = (long)E * T * Ds, n_av = (long)E * A * T * K;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_obs + n_state + n_av; i += (long)gridDim.x * 256) {
+        if (i < n_obs) {
+            const int f = (int)(i % Do); const long r = i / Do; const int t = (int)(r % T); const long ea = r / T;
+            const int ag = (int)(ea % A); const unsigned long long ge = (unsigned long long)(env_offset + ea / A);
+            float v;
+            if (f < obs_raw) {
+                const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)(t * A + ag), 0x100u + (uint32_t)f, k0, k1);
+                v = normal01(w.x, w.y);
+            } else v = (f - obs_raw == ag) ? 1.0f : 0.0f;
+            obs[i] = v;
+        } else if (i < n_obs + n_state) {
+            const long j = i - n_obs; const int f = (int)(j % Ds); const long r = j / Ds; const int t = (int)(r % T);
+            const unsigned long long ge = (unsigned long long)(env_offset + r / T);
+            const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)t, 0x40000000u + (uint32_t)f, k0, k1);
+            state[j] = normal01(w.x, w.y);
+        } else {
+            const long j = i - n_obs - n_state; const int k = (int)(j % K); const long r = j / K; const int t = (int)(r % T);
+            const long ea = r / T; const int ag = (int)(ea % A); const unsigned long long ge = (unsigned long long)(env_offset + ea / A);
+            const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)(t * A + ag), 0x80000000u + (uint32_t)k, k0, k1);
+            avail[j] = (k == 0 || cm_u01(w.x) < avail_p) ? 1 : 0;  // action 0 is always legal
+        }
+    }
+}
+
+// reward[e][t] = N(0,1) noise + fraction of agents that picked action (t mod K)
+__global__ __launch_bounds__(256) void k_shape_reward(int E, int A, int T, int K, unsigned long long seed, long env_offset,
+                                                      long episode, const int* __restrict__ action, float* __restrict__ reward) {
+    const long n = (long)E * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T); const long e = i / T;
+        const unsigned long long ge = (unsigned long long)(env_offset + e);
+        const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)t, 0xC0000000u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        int hits = 0;
+        for (int a = 0; a < A; ++a) hits += (action[(e * A + a) * (long)T + t] == t % K) ? 1 : 0;
+        reward[i] = normal01(w.x, w.y) + (float)hits / (float)A;
+    }
+}
+
 }  // namespace
+
+extern "C" int cm_shape_env_fill(int E, int A, int T, int obs_raw, int agent_ids, int state_dim, int n_actions, double avail_p,
+                                 uint64_t seed, int64_t env_offset, int64_t episode, float* obs, float* state, uint8_t* avail,
+                                 cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_raw > 0 && state_dim > 0 && n_actions > 0, "cm_shape_env_fill: bad dims");
+    hipLaunchKernelGGL(k_shape_fill, dim3(2048), dim3(256), 0, (hipStream_t)stream, E, A, T, obs_raw, agent_ids, state_dim, n_actions,
+                       (float)avail_p, (unsigned long long)seed, (long)env_offset, (long)episode, obs, state, avail);
+    CM_CHECK_LAUNCH("cm_shape_env_fill");
+    return 0;
+}
+
+extern "C" int cm_shape_env_reward(int E, int A, int T, int n_actions, uint64_t seed, int64_t env_offset, int64_t episode,
+                                   const int32_t* action, float* reward, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && n_actions > 0, "cm_shape_env_reward: bad dims");
+    const long n = (long)E * T;
+    hipLaunchKernelGGL(k_shape_reward, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       E, A, T, n_actions, (unsigned long long)seed, (long)env_offset, (long)episode, action, reward);
+    CM_CHECK_LAUNCH("cm_shape_env_reward");
+    return 0;
+}
 
 extern "C" int cm_synth_env_reset(float* env_state, int E, int A, int agent_ids, uint64_t seed, int64_t env_offset,
                                   int64_t episode, float* obs, float* state, int T, cm_stream_t stream) {

@@ -19,7 +19,7 @@ from .env.shm_vector import ShmVectorEnv
 from .env.vector import PipeVectorEnv, environment
 from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch, pad_time
 from .logger import ScalarWriter
-from .rollout import SyntheticSpreadRollout
+from .rollout import SyntheticShapeRollout, SyntheticSpreadRollout
 
 RUN_PREFIX = {  # run-name strings of the four scripts (sic)
     "mappo_multienvs": "MAPPO-multienvs", "ippo_multienvs": "IPPO-multienvs",
@@ -158,7 +158,8 @@ def run(script, argv=None):
     E_glob = args.batch_size
     E = E_glob // world + (1 if rank < E_glob % world else 0)  # env shard of this rank
     env_offset = rank * (E_glob // world) + min(rank, E_glob % world)
-    synth = dict(agents=args.synthetic_agents, steps=args.synthetic_steps)
+    synth = dict(agents=args.synthetic_agents, steps=args.synthetic_steps, obs=args.synthetic_obs, state=args.synthetic_state,
+                 actions=args.synthetic_actions, avail_p=args.synthetic_avail_p)
     fac = dict(env_type=args.env_type, env_name=args.env_name, env_family=args.env_family, agent_ids=args.agent_ids,
                kwargs={}, seed=args.seed, synthetic=synth)
     eval_env = environment(**dict(fac, index=10 ** 6))
@@ -175,9 +176,13 @@ def run(script, argv=None):
     else:
         learner = PPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
 
-    device_env = args.env_type == "synthetic"
+    device_env = args.env_type in ("synthetic", "synthetic_shape")
     venv = roll = None
-    if device_env:
+    if args.env_type == "synthetic_shape":
+        roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
+                                     n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
+                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset)
+    elif device_env:
         if recurrent:
             from .gru import GRUSyntheticRollout
             roll = GRUSyntheticRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,

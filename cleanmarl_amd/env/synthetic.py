@@ -91,3 +91,74 @@ class SyntheticSpreadEnv(CommonInterface):
         if self.agent_ids:
             raw = np.concatenate([raw, np.eye(A, dtype=F)], 1)
         return raw
+
+
+def _normal01(a, b):
+    """Box-Muller on two Philox words, fp32 -- twin of normal01() in csrc/cm_env.hip."""
+    u1 = ((np.asarray(a, np.uint32) >> np.uint32(8)).astype(F) + F(0.5)) * F(1.0 / 16777216.0)
+    u2 = u01(b)
+    return (np.sqrt(F(-2.0) * np.log(u1)) * np.cos(F(6.283185307179586) * u2)).astype(F)
+
+
+class SyntheticShapeEnv(CommonInterface):
+    """CPU twin of the on-device "shape" env (cm_shape_env_fill / cm_shape_env_reward): wide random observations, a
+    separate global state, availability masks with action 0 always legal, fixed horizon -- BASELINE config 4's
+    SMAClite-like shapes (obs 105 + 10 ids, state 243, 17 actions) without the SMAClite dependency."""
+
+    def __init__(self, n_agents=10, obs_raw=105, state_dim=243, n_actions=17, avail_p=0.7, agent_ids=True, max_cycles=256,
+                 seed=1, env_index=0, **kwargs):
+        self.n_agents, self.obs_raw, self.state_dim, self.K = int(n_agents), int(obs_raw), int(state_dim), int(n_actions)
+        self.avail_p, self.agent_ids, self.max_cycles = F(avail_p), bool(agent_ids), int(max_cycles)
+        self.seed, self.env_index = int(seed), int(env_index)
+        self.episode, self.t = -1, 0
+
+    def _words(self, c2, c3):
+        k0, k1 = split_seed(self.seed)
+        return philox4x32(np.uint32(self.env_index & 0xFFFFFFFF), np.uint32(self.episode), np.asarray(c2, np.uint32),
+                          np.asarray(c3, np.uint32), k0, k1)
+
+    def _observe(self):
+        A, t = self.n_agents, self.t
+        c2 = (t * A + np.arange(A, dtype=np.uint32))[:, None]
+        x, y, _, _ = self._words(c2, np.uint32(0x100) + np.arange(self.obs_raw, dtype=np.uint32)[None, :])
+        raw = _normal01(x, y)
+        x, y, _, _ = self._words(np.uint32(t), np.uint32(0x40000000) + np.arange(self.state_dim, dtype=np.uint32))
+        self.state = _normal01(x, y)
+        x, _, _, _ = self._words(c2, np.uint32(0x80000000) + np.arange(self.K, dtype=np.uint32)[None, :])
+        av = (u01(x) < self.avail_p)
+        av[:, 0] = True
+        self.avail = av.astype(np.int64)
+        return np.concatenate([raw, np.eye(A, dtype=F)], 1) if self.agent_ids else raw
+
+    def reset(self, seed=None):
+        self.episode += 1
+        self.t = 0
+        return self._observe(), {}
+
+    def step(self, actions):
+        x, y, _, _ = self._words(np.uint32(self.t), np.uint32(0xC0000000))
+        hits = sum(int(a) == self.t % self.K for a in actions)
+        r = F(_normal01(x, y) + F(hits) / F(self.n_agents))
+        self.t += 1
+        return self._observe(), float(r), False, bool(self.t >= self.max_cycles), {}
+
+    def get_avail_actions(self):
+        return self.avail
+
+    def get_action_size(self):
+        return self.K
+
+    def get_state(self):
+        return self.state
+
+    def get_state_size(self):
+        return self.state_dim
+
+    def get_obs_size(self):
+        return self.obs_raw + self.agent_ids * self.n_agents
+
+    def sample(self):
+        return [int(np.random.choice(np.flatnonzero(r))) for r in self.avail]
+
+    def close(self):
+        pass

@@ -17,13 +17,19 @@ def environment(env_type, env_name, env_family, agent_ids, kwargs=None, index=0,
         if s.get("ragged"):  # episodes of different lengths (exercises the shrinking alive set / zero padding)
             steps = max(1, steps - index % 4)
         return SyntheticSpreadEnv(n_agents=s.get("agents", 3), agent_ids=agent_ids, max_cycles=steps, seed=seed, env_index=index)
+    if env_type in ("synthetic_shape", "synthetic_shape_cpu"):
+        from .synthetic import SyntheticShapeEnv
+        s = synthetic or {}
+        return SyntheticShapeEnv(n_agents=s.get("agents", 10), obs_raw=s.get("obs", 105), state_dim=s.get("state", 243),
+                                 n_actions=s.get("actions", 17), avail_p=s.get("avail_p", 0.7), agent_ids=agent_ids,
+                                 max_cycles=s.get("steps", 25), seed=seed, env_index=index)
     if env_type == "pz":
         mod = importlib.import_module("cleanmarl_amd.env.pettingzoo_wrapper")
         return mod.PettingZooWrapper(family=env_family, env_name=env_name, agent_ids=agent_ids, **kwargs)
     if env_type == "smaclite":
         mod = importlib.import_module("cleanmarl_amd.env.smaclite_wrapper")
         return mod.SMACliteWrapper(map_name=env_name, agent_ids=agent_ids, **kwargs)
-    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, synthetic, synthetic_cpu)")
+    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, synthetic[_cpu], synthetic_shape[_cpu])")
 
 
 def env_worker(conn, factory_args):

@@ -45,6 +45,9 @@ class GRUPPOLearner(PPOLearner):
         for ep in range(nE):
             steps = []
             h_in = None
+            if self.events is not None:  # bench.py: one event pair around all TBPTT chunks of the epoch
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for ci, (t0, t1) in enumerate(chunks):
                 h_out = self.h[ci & 1]
                 N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
@@ -59,6 +62,9 @@ class GRUPPOLearner(PPOLearner):
                 if keep_grads:
                     steps.append((self.g_actor[:Pa].clone(), self.actor.clone()))
                 h_in = h_out
+            if self.events is not None:
+                ev1.record()
+                self.events.append(("actor", ev0, ev1))
             self._timed("critic", self.critic_pass, b, s)
             self._allreduce(self.g_critic)
             self._adam(self.critic, self.g_critic, self.opt_c, 1, s)

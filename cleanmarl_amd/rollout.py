@@ -65,3 +65,45 @@ class SyntheticSpreadRollout:
                                           N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
         self.episode += 1
         return b
+
+
+class SyntheticShapeRollout:
+    """Device rollout of the "shape" env (BASELINE config 4 shapes): one launch generates the episode's observations /
+    states / availability masks, T x cm_policy_act (or cm_gru_policy_act) samples actions, one launch computes rewards."""
+
+    def __init__(self, E, A, T, obs_raw=105, state_dim=243, n_actions=17, avail_p=0.7, seed=1, agent_ids=True, device="cuda:0",
+                 env_offset=0):
+        self.lib = N.load()
+        self.E, self.A, self.T, self.K = E, A, T, n_actions
+        self.obs_raw, self.agent_ids, self.avail_p = obs_raw, bool(agent_ids), float(avail_p)
+        self.Do, self.Ds = obs_raw + (A if agent_ids else 0), state_dim
+        self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
+        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
+        self.batch.ep_len.fill_(T)
+        self.h = None
+        self.episode = 0
+
+    def collect(self, actor_flat, actor_spec, fused=None):
+        lib, b, s = self.lib, self.batch, N.stream_ptr()
+        E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        N.check(lib.cm_shape_env_fill(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
+                                      self.episode, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.avail), s), "cm_shape_env_fill")
+        act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+        gru = actor_spec.kind == "gru"
+        if gru:
+            if self.h is None:
+                self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)
+            self.h.zero_()
+        for t in range(T):
+            if gru:
+                N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                              actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
+                                              _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
+            else:
+                N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                          actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A, t,
+                                          _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_policy_act")
+        N.check(lib.cm_shape_env_reward(E, A, T, K, self.seed, self.env_offset, self.episode, N.ptr(b.action), N.ptr(b.reward), s),
+                "cm_shape_env_reward")
+        self.episode += 1
+        return b

@@ -162,6 +162,17 @@ int cm_synth_env_reset(float* env_state, int E, int A, int agent_ids, uint64_t s
 int cm_synth_env_step(float* env_state, const int32_t* action, int E, int A, int agent_ids, int t, int T,
                       float* reward, float* obs, float* state, cm_stream_t stream);
 
+/* ---- a15: "shape" env -- fixed-shape stand-in for envs with wide observations, a separate global state and
+ * availability masks (SMAClite-like, BASELINE config 4).  obs ~ N(0,1) (+ one-hot ids), state ~ N(0,1),
+ * avail ~ Bernoulli(avail_p) with action 0 always legal: all a pure function of (seed, env, episode, t), so one
+ * launch fills the whole episode; the team reward (noise + fraction of agents choosing action t mod K) is
+ * computed from the sampled actions afterwards.  CPU twin: cleanmarl_amd/env/synthetic.py::SyntheticShapeEnv. */
+int cm_shape_env_fill(int E, int A, int T, int obs_raw, int agent_ids, int state_dim, int n_actions, double avail_p,
+                      uint64_t seed, int64_t env_offset, int64_t episode, float* obs, float* state, uint8_t* avail,
+                      cm_stream_t stream);
+int cm_shape_env_reward(int E, int A, int T, int n_actions, uint64_t seed, int64_t env_offset, int64_t episode,
+                        const int32_t* action, float* reward, cm_stream_t stream);
+
 /* ---- a15 (fused): the WHOLE rollout of the synthetic env in one persistent launch ----
  * Equivalent to cm_synth_env_reset followed by T x (cm_policy_act; cm_synth_env_step) with the same seeds
  * (replaces cleanmarl/mappo_multienvs.py:393-453 + the collate of :109-157): each workgroup keeps floor(64/A)

@@ -26,6 +26,19 @@ def test_script_runs_and_logs_reference_tags(script, env_type, tmp_path, monkeyp
     assert steps == sorted(steps) and steps[0] == 100  # x-axis = env steps (4 envs x 25 steps), like the reference
 
 
+@pytest.mark.parametrize("script", ["ippo_multienvs", "ippo_lstm_multienvs"])
+def test_shape_env_scripts(script, tmp_path, monkeypatch):
+    """IPPO on the SMAClite-shaped device env (availability masks, 17 actions, obs 33 + ids) and on its CPU twin."""
+    import math
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    for env_type in ("synthetic_shape", "synthetic_shape_cpu"):
+        out = run(script, [f"--env_type={env_type}", "--batch_size=6", "--synthetic_agents=4", "--synthetic_steps=12",
+                           "--synthetic_obs=33", "--synthetic_state=50", "--synthetic_actions=17", "--total_timesteps=144",
+                           "--eval_steps=1", "--num_eval_ep=1", "--log_every=1", "--critic_hidden_dim=64"])
+        assert TAGS <= {t for t, _, _ in out["history"]} and all(math.isfinite(v) for _, v, _ in out["history"])
+
+
 def test_learning_signal_on_synthetic_env(tmp_path, monkeypatch):
     """A few hundred iterations of MAPPO on the on-device env must improve the episode return."""
     from cleanmarl_amd.driver import run

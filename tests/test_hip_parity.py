@@ -501,3 +501,31 @@ def test_time_padding_does_not_change_the_update():
     assert _err(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 1e-6
     assert _err(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 1e-6
     assert _err(outs[0][3], outs[1][3]) <= 1e-6
+
+
+def test_shape_env_kernels_match_numpy_twin():
+    """cm_shape_env_fill / cm_shape_env_reward vs cleanmarl_amd/env/synthetic.py::SyntheticShapeEnv."""
+    from cleanmarl_amd.env.synthetic import SyntheticShapeEnv
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    from cleanmarl_amd.rollout import SyntheticShapeRollout
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    E, A, T, raw, Ds, K = 6, 4, 5, 13, 9, 7
+    r = SyntheticShapeRollout(E, A, T, obs_raw=raw, state_dim=Ds, n_actions=K, avail_p=0.6, seed=11, device=dev, env_offset=40)
+    spec = NetSpec(r.Do, 64, 1, K)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    for ep in range(2):
+        b = r.collect(p, spec)
+    torch.cuda.synchronize()
+    obs, st, av, act, rew = (x.cpu().numpy() for x in (b.obs, b.state, b.avail, b.action, b.reward))
+    assert av[..., 0].all() and 0.3 < av[..., 1:].mean() < 0.9
+    assert (av[np.arange(E)[:, None, None], np.arange(A)[None, :, None], np.arange(T)[None, None, :], act] == 1).all()
+    for e in range(E):
+        env = SyntheticShapeEnv(A, raw, Ds, K, 0.6, True, T, seed=11, env_index=40 + e)
+        env.episode = 0  # the next reset() is episode 1 = the second collect()
+        o, _ = env.reset()
+        for t in range(T):
+            assert np.abs(obs[e, :, t] - o).max() <= 1e-5 and np.abs(st[e, t] - env.get_state()).max() <= 1e-5
+            assert (av[e, :, t] == env.get_avail_actions()).all()
+            o, rr, d, tr, _ = env.step(act[e, :, t])
+            assert abs(rew[e, t] - rr) <= 1e-5
