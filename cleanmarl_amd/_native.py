@@ -30,6 +30,7 @@ SIGNATURES = {
     "cm_gru_param_count": (_l, [_i, _i, _i]),
     "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),
     "cm_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_policy_act_episode": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p]),
     "cm_td_lambda_scan": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _p, _p, _p]),
     "cm_masked_moments_workspace_bytes": (_sz, [_i, _i, _i]),
     "cm_masked_moments": (_i, [_p, _p, _i, _i, _i, _p, _p, _sz, _p]),

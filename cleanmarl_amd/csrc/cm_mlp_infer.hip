@@ -30,3 +30,23 @@ extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t
     return 0;
 }
 
+
+/* Act for EVERY step of an episode in one launch when the observations do not depend on the actions (e.g. the shape
+ * env): x is [n_seq][T][din] contiguous, avail [n_seq][T][K]; row (s, t) draws Philox(seed, row_offset + s, t), i.e.
+ * exactly what T calls of cm_policy_act with t = 0..T-1 draw.  Outputs action / logp [n_seq][T]. */
+extern "C" int cm_policy_act_episode(const float* x, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
+                                     int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
+                                     int32_t* action, float* logp, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_policy_act_episode", din, hidden, n_hidden_layers, n_actions)) return rc;
+    CM_REQUIRE(T > 0, "cm_policy_act_episode: T=%d", T);
+    if (n_seq <= 0) return 0;
+    if (int rc = check_rows("cm_policy_act_episode", n_seq * T)) return rc;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = din; a.rows = n_seq * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = params; a.avail = avail; a.avail_stride = n_actions;
+    a.seed = seed; a.row_offset = row_offset; a.t = 0; a.t_decode = T; a.action_out = action; a.logp_out = logp; a.out_stride = 1;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    launch_infer<M_ACT>(a, grid_for(a.rows), lds_bytes, (hipStream_t)stream);
+    CM_CHECK_LAUNCH("cm_policy_act_episode");
+    return 0;
+}

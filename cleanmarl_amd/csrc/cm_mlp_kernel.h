@@ -50,6 +50,7 @@ struct MlpArgs {
     const uint8_t* avail; long avail_stride; float* y;
     // M_ACT
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+    int t_decode;  // > 0: rows are (sequence, t) pairs with t = row % t_decode (whole-episode act pass), else a.t
     // training
     const int* action; const float* logp_old; const float* adv; const float* ret; const int* ep_len;
     int A, T, per_agent;
@@ -527,8 +528,10 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         // ================= per-row head math: lane hq == 0 of every row =================
         if (MODE == M_ACT) {
             if (hq == 0 && rvalid) {
-                const unsigned long long gr = (unsigned long long)(a.row_offset + grow);
-                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)a.t, CM_STREAM_ACT,
+                const int seq = a.t_decode > 0 ? grow / a.t_decode : grow;
+                const int tt = a.t_decode > 0 ? grow - seq * a.t_decode : a.t;
+                const unsigned long long gr = (unsigned long long)(a.row_offset + seq);
+                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)tt, CM_STREAM_ACT,
                                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
                 int chosen; float lp;
                 cm_categorical_sample(ls + hrow * lstride, dout, cm_u01(rnd.x), &chosen, &lp);

@@ -90,6 +90,14 @@ class SyntheticShapeRollout:
                                       self.episode, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.avail), s), "cm_shape_env_fill")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
         gru = actor_spec.kind == "gru"
+        if not gru and fused is not False:  # obs do not depend on the actions: sample every step in ONE launch
+            N.check(lib.cm_policy_act_episode(N.ptr(b.obs), N.ptr(b.avail), E * A, T, actor_spec.din, actor_spec.hidden,
+                                              actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A,
+                                              N.ptr(b.action), N.ptr(b.logp), s), "cm_policy_act_episode")
+            N.check(lib.cm_shape_env_reward(E, A, T, K, self.seed, self.env_offset, self.episode, N.ptr(b.action), N.ptr(b.reward), s),
+                    "cm_shape_env_reward")
+            self.episode += 1
+            return b
         if gru:
             if self.h is None:
                 self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)

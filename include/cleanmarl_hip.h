@@ -77,6 +77,13 @@ int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, in
                   const float* params, uint64_t seed, int64_t row_offset, int t,
                   int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
 
+/* a4, whole episode in one launch: for envs whose observations do not depend on the actions (shape env) every step
+ * can be sampled at once.  x [n_seq][T][din], avail [n_seq][T][n_actions] contiguous; row (s, t) uses the Philox key
+ * (seed, row_offset + s, t), i.e. the draws of T calls of cm_policy_act with t = 0..T-1.  action / logp [n_seq][T]. */
+int cm_policy_act_episode(const float* x, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
+                          int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
+                          int32_t* action, float* logp, cm_stream_t stream);
+
 /* ---- a6: TD(lambda) return + advantage  (cleanmarl/mappo_multienvs.py:484-504; ippo :483-503) ----
  * R_t = r_t + gamma*(lam*R_{t+1} + (1-lam)*V_{t+1}),  R = V = 0 beyond the last valid step,
  * A_t = R_t - V_t, zeros on padded steps.  Av = 1 broadcasts one value sequence to all A agents. */

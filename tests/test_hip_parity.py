@@ -529,3 +529,18 @@ def test_shape_env_kernels_match_numpy_twin():
             assert (av[e, :, t] == env.get_avail_actions()).all()
             o, rr, d, tr, _ = env.step(act[e, :, t])
             assert abs(rew[e, t] - rr) <= 1e-5
+
+
+def test_episode_act_equals_per_step_act():
+    """cm_policy_act_episode (one launch for all T steps) == T x cm_policy_act on the shape env."""
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    from cleanmarl_amd.rollout import SyntheticShapeRollout
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    ra = SyntheticShapeRollout(9, 3, 7, obs_raw=29, state_dim=11, n_actions=17, seed=5, device=dev, env_offset=3)
+    rb = SyntheticShapeRollout(9, 3, 7, obs_raw=29, state_dim=11, n_actions=17, seed=5, device=dev, env_offset=3)
+    spec = NetSpec(ra.Do, 64, 1, 17)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    ba, bb = ra.collect(p, spec, fused=True), rb.collect(p, spec, fused=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ba.action, bb.action) and torch.equal(ba.logp, bb.logp) and torch.equal(ba.reward, bb.reward)
