@@ -79,3 +79,19 @@ def test_logged_scalars_are_epoch_means(golden_dir):
     assert abs(vals[tags.index("train/actor_loss")] - z["actor_losses"].mean()) < 1e-9
     assert abs(vals[tags.index("train/critic_loss")] - z["critic_losses"].mean()) < 1e-9
     assert vals[tags.index("train/num_updates")] == 3
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_dense", "mappo"), ("mappo_deep", "mappo"), ("ippo_dense", "ippo")])
+def test_c_td_lambda_matches_reference(golden_dir, name, algo):
+    """oracle/td_lambda.c (literal per-episode reverse loop in C) against the reference's return_lambda / advantages
+    (cases without advantage / return normalisation, where the golden arrays are the raw scan outputs)."""
+    from oracle.build_c import td_lambda_c
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    with torch.no_grad():
+        values = R.critic_values(cp, batch, algo).contiguous()
+        values = values * batch["mask"].unsqueeze(-1)
+    ret, adv = td_lambda_c(batch["reward"].numpy(), values.numpy(), batch["mask"].numpy(), hp["gamma"], hp["td_lambda"])
+    _close(ret, z["return_lambda"])
+    _close(adv, z["advantages"])
+    r2, a2 = R.td_lambda(batch["reward"], values, batch["mask"], hp["gamma"], hp["td_lambda"])
+    _close(ret, r2.numpy(), 1e-6)
