@@ -51,7 +51,14 @@ struct GruArgs {
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate non-linearities on the hardware exp (v_exp_f32, ~1 ulp): 48 transcendental evaluations per lane per step make
+// the libm versions (~30 instructions each) a visible part of the sequential per-step latency
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(-2.0f * fabsf(x));           // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, x);
+}
 
 // LDS carve: 8 activation/weight buffers + head weights + per-row scratch + biases
 struct GruLds { float *b[8], *wouts, *ls, *b1, *bih, *bhh, *b2, *red; };
@@ -164,7 +171,7 @@ __device__ __forceinline__ void gru_fwd_step(const GruLds& L, const GruArgs& a, 
             const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
             const float ghn = acch[g] + bh;
             const float r = GR[row * LDT + col], z = GZ[row * LDT + col], hprev = hp[row * LDT + col];
-            const float n = tanhf(acc[g] + bi + r * ghn);
+            const float n = tanhf_(acc[g] + bi + r * ghn);
             const float hv = (col < H) ? (1.0f - z) * n + z * hprev : 0.0f;
             hn[row * LDT + col] = hv;
             if (SAVE && row0 + row < nrows) {
