@@ -399,6 +399,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
 
     // ---- software pipeline prologue: first X chunk (and W0 chunk when it is streamed) of the first tile
     Tile16 px, pw;
+    Tile16 pn;  // NCH == 1 training kernels: the NEXT tile's X, requested mid-tile (px is busy holding this tile's X for dW0)
+    constexpr bool EARLY_NEXT = TRAIN && NCH == 1;
     if ((long)blockIdx.x < ntiles) {
         tile_load<VEC>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
         if (!w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
         }
         PH(2);
+        if (EARLY_NEXT && L >= 1) tile_load<VEC>(pn, a.x, next_row0, a.rows, a.x_stride, 0, min(KC, din));
         // ================= head forward: 16x16x4 MFMA, wave w owns rows 16w..16w+15 (= the rows of its quad lanes) ====
         float* HL = smem + lds.Hs(L);
         {
@@ -711,7 +714,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         tile_store<VEC>(Xs, px);
                         const bool last = (c + 1 == NCH);
                         const int cn = last ? 0 : c + 1;
-                        tile_load<VEC>(px, a.x, last ? next_row0 : row0, a.rows, a.x_stride, cn * KC, min(KC, din - cn * KC));
+                        if (EARLY_NEXT) px = pn;  // already in flight since the head phase
+                        else tile_load<VEC>(px, a.x, last ? next_row0 : row0, a.rows, a.x_stride, cn * KC, min(KC, din - cn * KC));
                         if (last && !w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
                         __syncthreads();
                     }
