@@ -213,17 +213,20 @@ __device__ __forceinline__ f32x4 head_logits_mfma(const float* HLw /* H_L + 16*w
     return acc;
 }
 
-// acc[32 (k) x 32 (c)] += sum over 32 rows of dlogits[row][k] * H[row][c0 + c], dlogits rows of stride KP (head
-// outputs k >= KP are zero-filled in registers instead of in LDS)
+// head weight gradient on the 16x16x4 MFMA: acc[16 (k) x 16 (c)] += sum over the tile's 64 rows of
+// dlogits[row][k0 + k] * H[row][c0 + c].  One wave owns one 16-column slice of the hidden units for ALL rows, so no
+// cross-wave combine is needed and the accumulator is 4 registers (the 32x32 form spent 16 MFMAs x 64 cycles on a
+// K = 5 head; this spends 16 x 32).
 template <int KP>
-__device__ __forceinline__ void colred_head_k(f32x16& acc, const float* ls_r0, const float* Hs_r0_c0) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const float* ap = ls_r0 + h * KP + (r < KP ? r : 0);
-    const float* bp = Hs_r0_c0 + h * LDT + r;
+__device__ __forceinline__ void colred_head16(f32x4& acc, const float* ls, int k0, const float* Hs_c0) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const bool kok = (k0 + n) < KP;
+    const float* ap = ls + g * KP + (kok ? k0 + n : 0);
+    const float* bp = Hs_c0 + g * LDT + n;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const float av = (r < KP) ? ap[2 * kk * KP] : 0.0f;
-        acc = mfma32(av, bp[2 * kk * LDT], acc);
+    for (int kk = 0; kk < TM / 4; ++kk) {
+        const float av = kok ? ap[4 * kk * KP] : 0.0f;
+        acc = mfma16(av, bp[4 * kk * LDT], acc);
     }
 }
 
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // ---- persistent accumulators (training)
     f32x16 accW0[NC];
     f32x16 accWl[LCAP];
-    f32x16 accWo;  // dWout[k (32) x 32 hidden cols], rows of the tile split over the two wave-rows
+    f32x4 accWo[WR / 16];  // dWout[k (16 per tile) x 16 hidden cols]: wave w owns hidden columns 16w..16w+15
     float dbo = 0.0f;
     float dbh[LCAP + 1];
     float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_vl = 0.f, st_cnt = 0.f;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
 #pragma unroll
             for (int g = 0; g < 16; ++g) accWl[l][g] = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) accWo[g] = 0.0f;
+        for (int q = 0; q < WR / 16; ++q) accWo[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int l = 0; l <= LCAP; ++l) dbh[l] = 0.0f;
     }
@@ -631,7 +634,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             PH(4);
             // ---- dWout, dbout (contraction over the tile's rows; reads HL before it is overwritten)
             // wave (wm, wn): rows 32wm..32wm+31 of the tile, hidden columns 32wn..32wn+31, all 32 (padded) head rows
-            colred_head_k<KP>(accWo, ls + 32 * wm * KP, HL + 32 * wm * LDT + 32 * wn);
+#pragma unroll
+            for (int q = 0; q < WR / 16; ++q) colred_head16<KP>(accWo[q], ls, 16 * q, HL + 16 * wave);
             {
                 const int k = tid & 31, part = tid >> 5;
                 float sb = 0.0f;
@@ -751,25 +755,15 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 }
             }
         }
-        {   // dWout: the two wave-rows hold partial sums of the same [32 x 32] tile -> combine through LDS
-            float* scr = smem + lds.Hs(0);  // activations are dead now: [2 (wn)][32 (k)][33] scratch
-            __syncthreads();
-            if (wm == 1) {
+        {   // dWout: lane (n = lane & 15, g = lane >> 4) of wave w holds k = 16q + 4g + r (r = 0..3), column 16w + n
+            const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
-                    scr[(wn * 32 + k) * 33 + lc] = accWo[g];
-                }
-            }
-            __syncthreads();
-            if (wm == 0) {
+            for (int q = 0; q < WR / 16; ++q)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
-                    const int c = 32 * wn + lc;
-                    if (k < dout && c < H) out[off.Wout + k * H + c] = accWo[g] + scr[(wn * 32 + k) * 33 + lc];
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * q + 4 * g4 + r, c = 16 * wave + n;
+                    if (k < dout && c < H) out[off.Wout + k * H + c] = accWo[q][r];
                 }
-            }
             __syncthreads();
             red[tid] = dbo;  // [8 parts][32 k]
             __syncthreads();
