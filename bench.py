@@ -51,12 +51,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CM_BENCH_BACKEND=gloo is a TEST hook (tests/test_dist_gpu.py): RCCL refuses two ranks on one device, gloo does
+    # not, so the N > 1 code path of this file can be exercised on a 1-GPU box with every rank on cuda:0.
+    backend = os.environ.get("CM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
 
     from cleanmarl_amd.gru import GRUPPOLearner, GRUSyntheticRollout

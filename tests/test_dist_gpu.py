@@ -1,0 +1,110 @@
+"""N = 2 product path on ONE MI355X: two processes share cuda:0, each owns half of the envs of a golden batch,
+runs the real PPOLearner (HIP kernels through the C-ABI) and the real collectives of cleanmarl_amd/dist.py --
+over gloo here, because RCCL refuses two ranks on one device; the learner code is backend-agnostic -- and must
+land on what the UNMODIFIED single-process reference produced for the full batch (tests/golden/*.npz):
+post-update parameters of every epoch, returns/advantages of the shard, logged scalars.  This is the
+"env sharding == full batch" claim of SURVEY.md 8(e) checked end to end on the hardware."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+
+
+def _worker(rank, world, port, gold, algo, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import restatement as R
+    from cleanmarl_amd import dist
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    batch, ap, cp, hp, z = R.load_golden(gold)
+    dev = torch.device("cuda:0")
+    reward = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else batch["reward"]
+    lo, n = dist.shard(batch["obs"].shape[0], rank, world)
+    sl = slice(lo, lo + n)
+    b = DeviceBatch.from_reference_layout(batch["obs"][sl], batch["actions"][sl], batch["log_probs"][sl], reward[sl],
+                                          batch["states"][sl], batch["avail"][sl], batch["mask"][sl], dev)
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"],
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = PPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
+                   process_group=torch.distributed.group.WORLD, world_size=world)
+    recs = L.train_iteration(b, keep_grads=True)
+    res = dict(lo=lo, n=n, ret=b.ret.permute(0, 2, 1).cpu(), adv=b.adv.permute(0, 2, 1).cpu(),
+               recs=[{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in r.items()} for r in recs])
+    torch.save(res, f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_ragged_norm", "mappo"), ("ippo_ragged_norm", "ippo"), ("mappo_dense", "mappo")])
+def test_two_ranks_reproduce_the_single_process_reference(golden_dir, tmp_path, name, algo):
+    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+    gold = os.path.join(golden_dir, name + ".npz")
+    mp.spawn(_worker, args=(world, port, gold, algo, out), nprocs=world, join=True)
+    z = np.load(gold)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    for g in got:
+        sl = slice(g["lo"], g["lo"] + g["n"])
+        assert _err(g["ret"].numpy(), z["return_lambda"][sl]) <= TOL
+        assert _err(g["adv"].numpy(), z["advantages"][sl]) <= TOL
+        for e, r in enumerate(g["recs"]):
+            assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL
+            assert _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+            assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
+            assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
+            assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
+            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
+            assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+            assert _err(r["actor_grads"].numpy(), z["actor_grads"][e]) <= TOL
+            assert _err(r["critic_grads"].numpy(), z["critic_grads"][e]) <= TOL
+            assert _err(r["actor_after"].numpy(), z["actor_after"][e]) <= TOL
+            assert _err(r["critic_after"].numpy(), z["critic_after"][e]) <= TOL
+    # replicated parameters stay bit-identical across ranks (same reduced buffer, same Adam kernel)
+    for e in range(len(got[0]["recs"])):
+        assert torch.equal(got[0]["recs"][e]["actor_after"], got[1]["recs"][e]["actor_after"])
+        assert torch.equal(got[0]["recs"][e]["critic_after"], got[1]["recs"][e]["critic_after"])
+
+
+def test_bench_two_rank_launch_on_one_gpu():
+    """bench.py's N > 1 branch (rendezvous, env_offset sharding, barriers, MAX-over-ranks timing, rank-0 JSON line)
+    launched exactly as the driver launches it, but over gloo with both ranks on cuda:0 (CM_BENCH_BACKEND test hook)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg2", "--envs", "96"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    assert out["roofline"]["frac"] > 0

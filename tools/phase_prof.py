@@ -47,7 +47,7 @@ else:
     p = flatten_params(init_params_like_torch(spec), dev)
     st = torch.randn(E, T, Ds, device=dev); ret = torch.randn(E, A, T, device=dev)
     g = torch.zeros(spec.nparams + 8, device=dev)
-    ws = torch.empty(lib.cm_mlp_train_workspace_bytes(Ds, 64, 1, 1), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.cm_critic_workspace_bytes(E, A, T, 0, Ds, 64, 1), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_critic_fwd_bwd(N.ptr(st), N.ptr(ret), N.ptr(ep_len), E, A, T, 0, Ds, 64, 1, N.ptr(p),
                                                 N.ptr(g), N.ptr(ws), ws.numel(), s), "critic")
 for _ in range(2):
@@ -67,7 +67,7 @@ if which == "rollout":
     sys.exit(0)
 names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
 rows = (E * A * T) if which == "actor" else E * T
-tiles_per_wg = rows / 64 / 256
+tiles_per_wg = rows / 64 / 512  # two workgroups per CU
 print(f"{which}: {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks (100 MHz const clock?) per tile:")
 for i, n in enumerate(names):
     print(f"  {n:24s} {float(ph[i]) / tiles_per_wg:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
