@@ -1,4 +1,4 @@
-"""Command-line surface of the four hot-path scripts.
+"""Command-line surface of the hot-path scripts (four *_multienvs.py + their four single-environment siblings).
 
 Every field, default and help string mirrors the reference's ``@dataclass Args`` parsed by ``tyro.cli``
 (cleanmarl/mappo_multienvs.py:18-79, cleanmarl/ippo_multienvs.py:18-79, cleanmarl/mappo_lstm_multienvs.py:18-80,
@@ -108,6 +108,11 @@ SCRIPT_DEFAULTS = {
     "ippo_multienvs": dict(critic_hidden_dim=32),
     "mappo_lstm_multienvs": dict(num_eval_ep=5, tbptt=10),
     "ippo_lstm_multienvs": dict(critic_hidden_dim=32, optimizer="AdamW", tbptt=5),
+    # single-environment front-ends (cleanmarl/mappo.py:18-77, ippo.py, mappo_lstm.py, ippo_lstm.py)
+    "mappo": dict(eval_steps=10),
+    "ippo": dict(critic_hidden_dim=32),
+    "mappo_lstm": dict(num_eval_ep=5, tbptt=10),
+    "ippo_lstm": dict(critic_hidden_dim=32, tbptt=5),
 }
 
 

@@ -1,5 +1,6 @@
-"""Training driver behind the four single-file scripts (mappo_multienvs.py, ippo_multienvs.py and the
-*_lstm_* pair).  Control flow follows the reference's ``__main__`` block (cleanmarl/mappo_multienvs.py:288-659):
+"""Training driver behind the single-file scripts: the vectorised mappo_multienvs.py, ippo_multienvs.py and their
+*_lstm_* pair, plus the single-environment front-ends mappo.py, ippo.py, mappo_lstm.py, ippo_lstm.py (same learner,
+episodes collected one after the other from one in-process env).  Control flow follows the reference's ``__main__`` block (cleanmarl/mappo_multienvs.py:288-659):
 seed -> envs -> networks/optimisers -> writer -> while step < total_timesteps: rollout, TD(lambda), epochs of
 PPO, logging, periodic eval -> shutdown.  All numerics run in libcleanmarl_hip.so on the GPU.
 
@@ -24,6 +25,8 @@ from .rollout import SyntheticShapeRollout, SyntheticSpreadRollout
 RUN_PREFIX = {  # run-name strings of the four scripts (sic)
     "mappo_multienvs": "MAPPO-multienvs", "ippo_multienvs": "IPPO-multienvs",
     "mappo_lstm_multienvs": "MAPPO-lstm-multienv", "ippo_lstm_multienvs": "IPPO-lstm-multienvs",
+    # single-environment front-ends (cleanmarl/mappo.py:279, ippo.py:279, mappo_lstm.py:280, ippo_lstm.py:279)
+    "mappo": "MAPPO", "ippo": "IPPO", "mappo_lstm": "MAPPO-lstm", "ippo_lstm": "IPPO-lstm",
 }
 
 
@@ -99,19 +102,45 @@ def host_rollout(venv, actor, E, A, seed, recurrent, device):
         alive = still
         if alive:
             obs, state, avail = np.stack(nobs), np.stack(nstate), np.stack(navail)
+    return _collate(eps, ep_len, E, A, device), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
+
+
+def _collate(eps, ep_len, E, A, device):
+    """Zero-pad the per-episode lists to the longest episode + build the mask (RolloutBuffer.get_batch, :109-142)."""
     T = max(ep_len)
     Do, Ds, K = eps[0]["obs"][0].shape[-1], eps[0]["state"][0].shape[-1], eps[0]["avail"][0].shape[-1]
     b_obs = np.zeros((E, T, A, Do), np.float32); b_av = np.zeros((E, T, A, K), bool); b_act = np.zeros((E, T, A), np.int64)
     b_lp = np.zeros((E, T, A), np.float32); b_rew = np.zeros((E, T), np.float32); b_st = np.zeros((E, T, Ds), np.float32)
     b_mask = np.zeros((E, T), bool)
-    for j, e in enumerate(eps):  # zero-pad + mask: RolloutBuffer.get_batch, :109-142
+    for j, e in enumerate(eps):
         n = ep_len[j]
         b_obs[j, :n] = np.stack(e["obs"]); b_av[j, :n] = np.stack(e["avail"]).astype(bool); b_act[j, :n] = np.stack(e["actions"])
         b_lp[j, :n] = np.stack(e["logp"]); b_rew[j, :n] = np.asarray(e["reward"], np.float32); b_st[j, :n] = np.stack(e["state"])
         b_mask[j, :n] = True
     t = torch.from_numpy
-    b = DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device)
-    return b, dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
+    return DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device)
+
+
+def host_rollout_single(env, actor, E, A, seed, recurrent, device):
+    """The single-environment front-ends (cleanmarl/mappo.py:302-343, ippo.py, mappo_lstm.py, ippo_lstm.py): ``batch_size``
+    episodes collected ONE AFTER THE OTHER from one in-process env (no worker processes); the GRU hidden state starts at
+    zero with every episode (mappo_lstm.py:306-318).  Returns the same (DeviceBatch, stats) as the vectorised collectors."""
+    eps, ep_reward, ep_len, ep_info = [], [], [], []
+    for _ in range(E):
+        e = dict(obs=[], actions=[], logp=[], reward=[], state=[], avail=[])
+        obs, _ = env.reset()
+        done = trunc = False
+        tot, n, h, info = 0.0, 0, None, None
+        while not (done or trunc):
+            avail, state = np.asarray(env.get_avail_actions()), np.asarray(env.get_state())
+            act, logp, h = actor.act(np.asarray(obs)[None], avail[None], h=h, seed=seed)
+            nobs, r, done, trunc, info = env.step(act.reshape(-1))
+            e["obs"].append(np.asarray(obs, np.float32)); e["actions"].append(act.reshape(A)); e["logp"].append(logp.reshape(A))
+            e["reward"].append(r); e["state"].append(state); e["avail"].append(avail)
+            tot += r; n += 1
+            obs = nobs
+        eps.append(e); ep_reward.append(tot); ep_len.append(n); ep_info.append(info)
+    return _collate(eps, ep_len, E, A, device), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
 
 
 def host_rollout_shm(venv, actor, E, A, seed, recurrent, device):
@@ -143,6 +172,7 @@ def run(script, argv=None):
     args = parse_args(script, argv)
     algo = "mappo" if script.startswith("mappo") else "ippo"
     recurrent = "lstm" in script
+    single_env = not script.endswith("multienvs")  # mappo.py / ippo.py / mappo_lstm.py / ippo_lstm.py
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not str(args.device).startswith("cuda"):
@@ -177,7 +207,7 @@ def run(script, argv=None):
         learner = PPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
 
     device_env = args.env_type in ("synthetic", "synthetic_shape")
-    venv = roll = None
+    venv = roll = the_env = None
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
@@ -190,6 +220,8 @@ def run(script, argv=None):
         else:
             roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
                                           env_offset=env_offset)
+    elif single_env:
+        the_env = environment(**dict(fac, index=env_offset))  # cleanmarl/mappo.py:235-241: one in-process env
     elif args.vector_env == "pipe":
         venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
     else:
@@ -225,6 +257,8 @@ def run(script, argv=None):
             b = roll.collect(learner.actor, actor_spec)
             rew = b.reward.sum(1).cpu().tolist()
             stats = dict(ep_reward=rew, ep_len=[b.T] * E, infos=[None] * E)
+        elif single_env:
+            b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, recurrent, device)
         else:
             collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
             b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
@@ -292,6 +326,8 @@ def run(script, argv=None):
     eval_env.close()
     if venv:
         venv.close()
+    if the_env is not None:
+        the_env.close()
     if world > 1:
         torch.distributed.destroy_process_group()
     return dict(step=step, training_step=training_step, history=writer.history if writer else [], learner=learner)

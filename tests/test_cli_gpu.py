@@ -26,6 +26,23 @@ def test_script_runs_and_logs_reference_tags(script, env_type, tmp_path, monkeyp
     assert steps == sorted(steps) and steps[0] == 100  # x-axis = env steps (4 envs x 25 steps), like the reference
 
 
+@pytest.mark.parametrize("script", ["mappo", "ippo", "mappo_lstm", "ippo_lstm"])
+def test_single_env_front_ends(script, tmp_path, monkeypatch):
+    """cleanmarl/mappo.py, ippo.py, mappo_lstm.py, ippo_lstm.py: batch_size episodes collected sequentially from ONE
+    in-process env (ragged episode lengths via the CPU env's per-index horizon are not needed: fixed 25 steps)."""
+    import math
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    out = run(script, ["--env_type=synthetic_cpu", "--batch_size=3", "--synthetic_agents=3", "--synthetic_steps=25",
+                       "--total_timesteps=150", "--eval_steps=1", "--num_eval_ep=1", "--log_every=1"])
+    tags = {t for t, _, _ in out["history"]}
+    assert TAGS <= tags and {"rollout/ep_reward", "rollout/ep_length", "rollout/num_episodes", "eval/ep_reward"} <= tags
+    assert all(math.isfinite(v) for _, v, _ in out["history"])
+    assert out["step"] == 150 and out["training_step"] == 6
+    ne = [v for t, v, _ in out["history"] if t == "rollout/num_episodes"]
+    assert ne and ne[-1] == 6  # 2 iterations x batch_size 3
+
+
 @pytest.mark.parametrize("script", ["ippo_multienvs", "ippo_lstm_multienvs"])
 def test_shape_env_scripts(script, tmp_path, monkeypatch):
     """IPPO on the SMAClite-shaped device env (availability masks, 17 actions, obs 33 + ids) and on its CPU twin."""

@@ -25,6 +25,13 @@ def test_cli_defaults_match_reference_scripts():
     assert (m.tbptt, m.num_eval_ep, m.optimizer) == (10, 5, "Adam")            # cleanmarl/mappo_lstm_multienvs.py:64,70
     i = parse_args("ippo_lstm_multienvs", [])
     assert (i.tbptt, i.num_eval_ep, i.optimizer, i.critic_hidden_dim) == (5, 10, "AdamW", 32)  # ippo_lstm :38,66
+    # single-environment front-ends: cleanmarl/mappo.py:65, ippo.py:33,65, mappo_lstm.py:61,69, ippo_lstm.py:33,37,65
+    assert parse_args("mappo", []).eval_steps == 10 and parse_args("mappo", []).critic_hidden_dim == 64
+    assert (parse_args("ippo", []).eval_steps, parse_args("ippo", []).critic_hidden_dim) == (50, 32)
+    ml = parse_args("mappo_lstm", [])
+    assert (ml.tbptt, ml.num_eval_ep, ml.eval_steps, ml.optimizer) == (10, 5, 50, "Adam")
+    il = parse_args("ippo_lstm", [])
+    assert (il.tbptt, il.num_eval_ep, il.optimizer, il.critic_hidden_dim) == (5, 10, "Adam", 32)
     b = parse_args("mappo_multienvs", ["--env_type=pz", "--env-name", "simple_spread_v3", "--batch_size", "4",
                                        "--normalize_reward", "--no-agent_ids", "--clip_gradients=0.5", "--use_wnb=False"])
     assert (b.env_type, b.env_name, b.batch_size, b.normalize_reward, b.agent_ids, b.clip_gradients) == \
