@@ -225,6 +225,32 @@ def pack(g, snaps, log, extra=None):
     return out
 
 
+def pack_coma(g, snaps, log):
+    """COMA (cleanmarl/coma_multienvs.py): one iteration = TD(lambda)/n-step targets from the TARGET critic, ONE critic
+    step, polyak target update, ONE actor step (no epochs, no stored log-probs)."""
+    a = g["args"]
+    out = {}
+    for k in ("b_obs", "b_actions", "b_reward", "b_states", "b_avail_actions", "b_done", "b_mask", "return_lambda"):
+        out[k] = g[k].detach().cpu().numpy()
+    for name, sn in zip(("actor", "critic"), snaps):
+        for i, p in enumerate(sn["init"]):
+            out[f"{name}_init_{i}"] = p
+        out[f"{name}_nparam"] = np.int64(len(sn["init"]))
+        out[f"{name}_grads"] = np.stack([_flat(x) for x in sn["grads"]])
+        out[f"{name}_after"] = np.stack([_flat(x) for x in sn["after"]])
+    out["target_after"] = _flat([p.detach().numpy() for p in g["target_critic"].parameters()])
+    out["epsilon"] = np.float64(g["epsilon"])
+    for k in ("cr_loss", "ac_loss", "entropies", "actor_gradients", "critic_gradients"):
+        out[k] = np.float64(float(g[k]))
+    hp = {f.name: getattr(a, f.name) for f in dataclasses.fields(a)}
+    for k, v in hp.items():
+        out["hp_" + k] = np.float64(v) if isinstance(v, (bool, int, float)) else np.array(str(v))
+    out["log_tags"] = np.array([t for t, _, _ in log])
+    out["log_vals"] = np.array([v for _, v, _ in log], dtype=np.float64)
+    out["log_steps"] = np.array([st for _, _, st in log], dtype=np.int64)
+    return out
+
+
 CASES = {
     # name: (script, overrides, env_spec)
     "mappo_dense": ("mappo_multienvs.py",
@@ -255,6 +281,14 @@ CASES = {
                          dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=32, epochs=2,
                               normalize_advantage=True),
                          dict(A=3, obs_raw=7, K=6, horizon=17, ragged=True, avail_p=0.7, state_dim=13, done_mode="done")),
+    # COMA: TD(lambda) targets (default) and n-step targets; per-time-step advantage normalisation is the default
+    "coma_tdlambda": ("coma_multienvs.py",
+                      dict(batch_size=6, actor_hidden_dim=64, critic_hidden_dim=64, clip_gradients=0.5, normalize_return=True),
+                      dict(A=3, obs_raw=6, K=5, horizon=15, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
+    "coma_nstep": ("coma_multienvs.py",
+                   dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=128, use_tdlamda=False, nsteps=3,
+                        normalize_advantage=False, normalize_reward=True),
+                   dict(A=4, obs_raw=9, K=6, horizon=12, ragged=True, avail_p=1.0, state_dim=14, done_mode="truncate")),
 }
 
 
@@ -264,6 +298,16 @@ def main(names=None):
         if names and name not in names:
             continue
         g, snaps, log = run_reference(script, ov, spec)
+        if script.startswith("coma"):
+            out = pack_coma(g, snaps, log)
+            if ov.get("normalize_reward"):
+                g2, _, _ = run_reference(script, dict(ov, normalize_reward=False), spec)
+                assert np.array_equal(g2["b_actions"].numpy(), g["b_actions"].numpy())
+                out["b_reward_raw"] = g2["b_reward"].numpy()
+            path = os.path.join(OUT, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) B,T,A={out['b_obs'].shape[:3]}")
+            continue
         extra = {}
         if ov.get("normalize_reward"):
             # identical run without reward normalisation -> raw rewards (rollout is

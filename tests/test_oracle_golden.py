@@ -95,3 +95,26 @@ def test_c_td_lambda_matches_reference(golden_dir, name, algo):
     _close(adv, z["advantages"])
     r2, a2 = R.td_lambda(batch["reward"], values, batch["mask"], hp["gamma"], hp["td_lambda"])
     _close(ret, r2.numpy(), 1e-6)
+
+
+@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep"])
+def test_coma_restatement_matches_reference_golden(golden_dir, name):
+    """oracle/coma.py vs the unmodified cleanmarl/coma_multienvs.py (one iteration: targets, critic step, polyak, actor step)."""
+    from oracle import coma as C
+    batch, ap, cp, hp, z = C.load_golden(os.path.join(golden_dir, name + ".npz"))
+    if "b_reward_raw" in z.files:
+        raw = torch.from_numpy(z["b_reward_raw"])
+        assert np.abs(R.normalize_reward(raw, batch["mask"]).numpy() - z["b_reward"]).max() < 1e-6
+    tp = [p.clone() for p in cp]
+    rec = C.update(ap, cp, tp, batch, hp)
+    assert np.abs(rec["ret"].numpy() - z["return_lambda"]).max() < 2e-5
+    assert abs(rec["critic_loss"] - float(z["cr_loss"])) < 1e-5 * (1 + abs(float(z["cr_loss"])))
+    assert abs(rec["actor_loss"] - float(z["ac_loss"])) < 1e-5 * (1 + abs(float(z["ac_loss"])))
+    assert abs(rec["entropy"] - float(z["entropies"])) < 1e-6
+    assert abs(rec["critic_gnorm"] - float(z["critic_gradients"])) < 1e-5 * (1 + float(z["critic_gradients"]))
+    assert abs(rec["actor_gnorm"] - float(z["actor_gradients"])) < 1e-5 * (1 + float(z["actor_gradients"]))
+    assert np.abs(rec["critic_grads"].numpy() - z["critic_grads"][0]).max() < 2e-6
+    assert np.abs(rec["actor_grads"].numpy() - z["actor_grads"][0]).max() < 2e-6
+    assert np.abs(R.flat(cp).numpy() - z["critic_after"][0]).max() < 2e-6
+    assert np.abs(R.flat(ap).numpy() - z["actor_after"][0]).max() < 2e-6
+    assert np.abs(R.flat(tp).numpy() - z["target_after"]).max() < 1e-7
