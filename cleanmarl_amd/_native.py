@@ -30,6 +30,17 @@ SIGNATURES = {
     "cm_gru_param_count": (_l, [_i, _i, _i]),
     "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),
     "cm_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_policy_act_eps": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _d, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_coma_build_inputs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "cm_gather_taken": (_i, [_p, _p, _l, _i, _p, _p]),
+    "cm_nstep_returns": (_i, [_p, _p, _p, _i, _i, _i, _d, _i, _p, _p]),
+    "cm_mlp_split_workspace_bytes": (_sz, [_l, _i, _i, _i, _i]),
+    "cm_qcritic_fwd_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_coma_advantage_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cm_coma_advantage": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_coma_normalize_adv": (_i, [_p, _p, _i, _i, _i, _p]),
+    "cm_coma_actor_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _p, _p, _sz, _p]),
+    "cm_polyak_update": (_i, [_p, _p, _l, _d, _p]),
     "cm_policy_act_episode": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p]),
     "cm_td_lambda_scan": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _p, _p, _p]),
     "cm_masked_moments_workspace_bytes": (_sz, [_i, _i, _i]),

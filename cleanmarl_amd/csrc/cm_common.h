@@ -78,6 +78,30 @@ __device__ __forceinline__ void cm_categorical_sample(const float* z, int K, flo
     *logp = z[chosen] - (m + logf(s));
 }
 
+// COMA exploration (cleanmarl/coma_multienvs.py:177-186): probs = (1 - eps) * softmax(z) + eps * avail / n_avail, inverse CDF
+// over the available actions in index order; *logp = log(probs[action]).
+__device__ __forceinline__ void cm_categorical_sample_eps(const float* z, int K, float u, float eps, int* action, float* logp) {
+    float m = -INFINITY;
+    int navail = 0;
+    for (int k = 0; k < K; ++k) { m = fmaxf(m, z[k]); navail += (z[k] > -5e8f) ? 1 : 0; }
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+    const float a = (1.0f - eps) / s, b = eps / (float)max(navail, 1);
+    float cum = 0.0f, pc = 0.0f, plast = 0.0f;
+    int chosen = -1, last = 0;
+    for (int k = 0; k < K; ++k) {
+        if (z[k] > -5e8f) {
+            const float p = a * expf(z[k] - m) + b;
+            cum += p;
+            last = k; plast = p;
+            if (chosen < 0 && u < cum) { chosen = k; pc = p; }
+        }
+    }
+    if (chosen < 0) { chosen = last; pc = plast; }
+    *action = chosen;
+    *logp = logf(pc);
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float cm_wave_sum(float v) {
 #pragma unroll

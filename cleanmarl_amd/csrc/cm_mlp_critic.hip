@@ -1,96 +1,9 @@
-// cm_mlp_critic.hip -- cm_critic_fwd_bwd (a8/a9, critic side)
-//
-// Two schedules, chosen by the input width:
-//   * Din <= 128 (<= 2 chunks): everything fused in k_mlp<NCH, M_CRITIC> (layer-0 weight-gradient accumulators fit
-//     the 256-register budget of two workgroups per CU).
-//   * wider inputs (MAPPO's central state, e.g. 384 at config 3): k_mlp<0, M_CRITIC> streams X once for the forward
-//     pass, runs the backward pass down to dZ0 and writes dZ0[rows][64] to HBM; the layer-0 weight gradient
-//     dW0[64 x Din] = dZ0^T X is then a pure streaming GEMM (k_dw0_stream): no LDS, no barriers, every wave owns a
-//     set of 32-column tiles of X, operands go straight from HBM/L2 into MFMA registers with a two-batch software
-//     pipeline.  X is read twice from HBM (2 x 0.8 GB at config 3) instead of being held hostage by 96 accumulator
-//     registers per lane that limit the fused kernel to one workgroup per CU.
-#include "cm_mlp_train.h"
-
-namespace {
-
-constexpr int RB = 8;  // row pairs per software-pipeline batch (16 rows)
-
-// wave w of the workgroup owns k-tiles {w, w+4, ...} (32 columns each); both 32-row halves of the 64 hidden units.
-template <int KTW>
-__global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restrict__ dz0, const float* __restrict__ x,
-                                                            long rows, int din, int H, long rows_per_wg,
-                                                            float* __restrict__ partial, int PS2, int col0) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const long row_lo = (long)blockIdx.x * rows_per_wg;
-    const long row_hi = min(rows, row_lo + rows_per_wg);
-    f32x16 acc[2][KTW];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < KTW; ++j)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.0f;
-    int col[KTW];
-    bool cok[KTW];
-#pragma unroll
-    for (int j = 0; j < KTW; ++j) { col[j] = col0 + 32 * (w + 4 * j) + r; cok[j] = col[j] < din; }
-
-    float a0[RB], a1[RB], b[RB][KTW], na0[RB], na1[RB], nb[RB][KTW];
-    auto load = [&](long base, float (&A0)[RB], float (&A1)[RB], float (&B)[RB][KTW]) {
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            const long row = base + 2 * p + h;
-            const bool ok = row < row_hi;
-            A0[p] = ok ? dz0[row * HP + r] : 0.0f;
-            A1[p] = ok ? dz0[row * HP + 32 + r] : 0.0f;
-#pragma unroll
-            for (int j = 0; j < KTW; ++j) B[p][j] = (ok && cok[j]) ? x[row * din + col[j]] : 0.0f;
-        }
-    };
-    if (row_lo < row_hi) load(row_lo, a0, a1, b);
-    for (long base = row_lo; base < row_hi; base += 2 * RB) {
-        if (base + 2 * RB < row_hi) load(base + 2 * RB, na0, na1, nb);  // next batch in flight under this batch's MFMAs
-#pragma unroll
-        for (int p = 0; p < RB; ++p)
-#pragma unroll
-            for (int j = 0; j < KTW; ++j) {
-                acc[0][j] = mfma32(a0[p], b[p][j], acc[0][j]);
-                acc[1][j] = mfma32(a1[p], b[p][j], acc[1][j]);
-            }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            a0[p] = na0[p]; a1[p] = na1[p];
-#pragma unroll
-            for (int j = 0; j < KTW; ++j) b[p][j] = nb[p][j];
-        }
-    }
-    float* out = partial + (size_t)blockIdx.x * PS2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < KTW; ++j)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int n = 32 * i + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (n < H && cok[j]) out[n * din + col[j]] = acc[i][j][g];
-            }
-}
-
-constexpr int DW0_GRID = 512;
-
-inline bool use_split(int din) { return (din + KC - 1) / KC > CM_WG2_MAX_NCH; }
-
-inline size_t critic_ws_bytes(long rows, int din, int hidden, int L) {
-    size_t b = train_ws_bytes(din, hidden, L, 1);
-    if (use_split(din)) b += ((size_t)rows * HP + (size_t)DW0_GRID * hidden * din) * sizeof(float);
-    return b;
-}
-
-}  // namespace
+// cm_mlp_critic.hip -- cm_critic_fwd_bwd (a8/a9, critic side); schedules in cm_mlp_split.h
+#include "cm_mlp_split.h"
 
 extern "C" size_t cm_critic_workspace_bytes(int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers) {
     const long rows = per_agent ? (long)E * A * T : (long)E * T;
-    return critic_ws_bytes(rows, din, hidden, n_hidden_layers);
+    return split_ws_bytes(rows, din, hidden, n_hidden_layers, 1);
 }
 
 extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,
@@ -101,48 +14,9 @@ extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_critic_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
     const long rows = per_agent ? (long)E * A * T : (long)E * T;
     if (int rc = check_rows("cm_critic_fwd_bwd", rows)) return rc;
-    const size_t need = critic_ws_bytes(rows, din, hidden, n_hidden_layers);
-    CM_REQUIRE(ws && ws_bytes >= need, "cm_critic_fwd_bwd: workspace too small (%zu < %zu; see cm_critic_workspace_bytes)", ws_bytes, need);
-    const int64_t P = cm_mlp_param_count(din, hidden, n_hidden_layers, 1);
-    hipStream_t s = (hipStream_t)stream;
     MlpArgs a = {};
     a.x = x; a.x_stride = din; a.rows = rows;
     a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = 1;
     a.params = params; a.ret = ret; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = per_agent ? 1 : 0;
-    a.partial = (float*)ws; a.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
-#ifdef CM_PHASE_PROF
-    a.prof = g_prof;
-#endif
-    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
-    if (!use_split(din)) {
-        const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
-        if (int rc = launch_train<M_CRITIC>(a, grid, lds_bytes, s)) return rc;
-        CM_CHECK_LAUNCH("cm_critic_fwd_bwd");
-        return finish_train(a, grid, P, grad_and_stats, s, "cm_critic_fwd_bwd");
-    }
-    // ---- split schedule: fused kernel without dW0 (two workgroups per CU) ...
-    a.dz0 = (float*)ws + (size_t)MAX_GRID * a.PS;
-    float* part2 = a.dz0 + (size_t)rows * HP;
-    const int grid = grid_for(a.rows, 0);
-    launch_variant<0, M_CRITIC>(a, grid, lds_bytes, s);
-    CM_CHECK_LAUNCH("cm_critic_fwd_bwd/fused");
-    if (int rc = finish_train(a, grid, P, grad_and_stats, s, "cm_critic_fwd_bwd", hidden * din)) return rc;  // all but W0
-    // ---- ... then the streaming layer-0 weight gradient
-    long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
-    rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
-    const int grid2 = (int)((rows + rpw - 1) / rpw);
-    const int PS2 = hidden * din;
-    for (int col0 = 0; col0 < din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
-        const int nkt = (min(512, din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
-        switch (ktw) {
-            case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
-            case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
-            case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
-            default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, x, rows, din, hidden, rpw, part2, PS2, col0); break;
-        }
-    }
-    CM_CHECK_LAUNCH("cm_critic_fwd_bwd/dw0");
-    hipLaunchKernelGGL(k_reduce_partials, dim3((PS2 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part2, grid2, PS2, 0, PS2, grad_and_stats);
-    CM_CHECK_LAUNCH("cm_critic_fwd_bwd/dw0-reduce");
-    return 0;
+    return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
 }

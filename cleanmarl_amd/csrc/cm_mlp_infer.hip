@@ -30,6 +30,24 @@ extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t
     return 0;
 }
 
+/* COMA's Actor.act (cleanmarl/coma_multienvs.py:177-186): sample from (1 - eps) * softmax + eps * uniform over the
+ * available actions.  Same Philox keying as cm_policy_act; logp = log of the MIXED probability of the sampled action. */
+extern "C" int cm_policy_act_eps(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                                 int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
+                                 const float* params, double eps, uint64_t seed, int64_t row_offset, int t,
+                                 int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_policy_act_eps", din, hidden, n_hidden_layers, n_actions)) return rc;
+    CM_REQUIRE(eps >= 0.0 && eps <= 1.0, "cm_policy_act_eps: eps=%g outside [0, 1]", eps);
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = x_row_stride; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = params; a.avail = avail; a.avail_stride = avail_row_stride; a.act_eps = (float)eps;
+    a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
+    CM_CHECK_LAUNCH("cm_policy_act_eps");
+    return 0;
+}
 
 /* Act for EVERY step of an episode in one launch when the observations do not depend on the actions (e.g. the shape
  * env): x is [n_seq][T][din] contiguous, avail [n_seq][T][K]; row (s, t) draws Philox(seed, row_offset + s, t), i.e.

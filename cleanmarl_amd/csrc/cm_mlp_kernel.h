@@ -40,7 +40,9 @@ constexpr int NTHREADS = 256;
 #endif
 constexpr int wgs_per_cu(int nch) { return nch <= CM_WG2_MAX_NCH ? 2 : 1; }
 
-enum Mode { M_FWD = 0, M_ACT = 1, M_ACTOR = 2, M_CRITIC = 3 };
+// COMA (cleanmarl/coma_multienvs.py): M_QCRITIC = MSE on the Q of the TAKEN action of a K-output critic (:620-631),
+// M_COMA_ACTOR = counterfactual policy gradient -log(pi_a + 1e-8) * adv - c * mean_k entropy (:649-676)
+enum Mode { M_FWD = 0, M_ACT = 1, M_ACTOR = 2, M_CRITIC = 3, M_QCRITIC = 4, M_COMA_ACTOR = 5 };
 
 struct MlpArgs {
     const float* x; long x_stride; long rows;
@@ -50,6 +52,7 @@ struct MlpArgs {
     const uint8_t* avail; long avail_stride; float* y;
     // M_ACT
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_policy_act_eps)
     int t_decode;  // > 0: rows are (sequence, t) pairs with t = row % t_decode (whole-episode act pass), else a.t
     // training
     const int* action; const float* logp_old; const float* adv; const float* ret; const int* ep_len;
@@ -338,7 +341,7 @@ template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e,
 template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
 __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool TRAIN = (MODE == M_ACTOR || MODE == M_CRITIC);
+    constexpr bool TRAIN = (MODE >= M_ACTOR);
     constexpr int NC = (NCH > 0 ? NCH : 1);
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
     const Lds lds = make_lds(a.L, a.dout, (a.din + KC - 1) / KC);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
             if (c == 0) {
                 // per-row head inputs: issued here, consumed (raw) only in the head phases after the MFMA layers
-                const bool use_avail = (MODE == M_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr);
+                const bool use_avail = (MODE == M_ACTOR || MODE == M_COMA_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr);
                 if (rvalid && use_avail) {
                     const uint8_t* ap = a.avail + (long)grow * a.avail_stride;
 #pragma unroll
@@ -453,6 +456,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     ri.ag = seq - ri.e * Aseq;
                     ri.eplen = a.ep_len[ri.e];
                     if (MODE == M_ACTOR) { ri.act = a.action[grow]; ri.lpo = a.logp_old[grow]; ri.adv = a.adv[grow]; }
+                    else if (MODE == M_COMA_ACTOR) { ri.act = a.action[grow]; ri.adv = a.adv[grow]; }
+                    else if (MODE == M_QCRITIC) { ri.act = a.action[grow]; ri.ret = a.ret[grow]; }
                     else if (a.per_agent) ri.ret = a.ret[grow];
                 }
             }
@@ -540,7 +545,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)tt, CM_STREAM_ACT,
                                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
                 int chosen; float lp;
-                cm_categorical_sample(ls + hrow * lstride, dout, cm_u01(rnd.x), &chosen, &lp);
+                if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + hrow * lstride, dout, cm_u01(rnd.x), a.act_eps, &chosen, &lp);
+                else cm_categorical_sample(ls + hrow * lstride, dout, cm_u01(rnd.x), &chosen, &lp);
                 a.action_out[(long)grow * a.out_stride] = chosen;
                 a.logp_out[(long)grow * a.out_stride] = lp;
             }
@@ -607,6 +613,82 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         if (!valid || zreg[j] <= -5e8f) d = 0.0f;  // padded rows; masked_fill blocks the gradient
                         ls[hrow * lstride + k] = d;
                     }
+                }
+            } else if (MODE == M_COMA_ACTOR) {
+                // pi = softmax(masked logits) (eps = 0 in the update, coma_multienvs.py:650); log_pi = log(pi + 1e-8);
+                // row loss = -log_pi[a] * adv - c * (-(pi * log_pi).mean_k); rows of all agents are SUMMED (no agent-mean)
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < dout) m = fmaxf(m, zreg[j]);
+                m = quad_max(m);
+                float s = 0.0f;
+                float pj[KJ], lq[KJ];
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    pj[j] = 0.0f;
+                    if (4 * j + hq < dout) { pj[j] = expf(zreg[j] - m); s += pj[j]; }
+                }
+                s = quad_sum(s);
+                const float rs = 1.0f / s;
+                const float invK = 1.0f / (float)dout;
+                float ent = 0.0f, lpa = 0.0f, pa = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    lq[j] = 0.0f;
+                    if (4 * j + hq < dout) {
+                        const float p = pj[j] * rs;
+                        pj[j] = p;
+                        lq[j] = logf(p + 1e-8f);
+                        ent -= p * lq[j];
+                        if (4 * j + hq == ri.act) { lpa = lq[j]; pa = p; }
+                    }
+                }
+                ent = quad_sum(ent) * invK;
+                lpa = quad_sum(lpa);
+                pa = quad_sum(pa);
+                const float advv = ri.adv;
+                if (valid && hq == 0) {
+                    st_pg += lpa * advv;
+                    st_ent += ent;
+                    if (ri.ag == 0) st_cnt += 1.0f;
+                }
+                // dL/dpi_k, then through the softmax: dz_j = pi_j * (g_j - sum_k g_k pi_k)
+                float gj[KJ], gbar = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    gj[j] = 0.0f;
+                    const int k = 4 * j + hq;
+                    if (k < dout) {
+                        gj[j] = a.ent_coef * invK * (lq[j] + pj[j] / (pj[j] + 1e-8f));
+                        if (k == ri.act) gj[j] -= advv / (pa + 1e-8f);
+                        gbar += gj[j] * pj[j];
+                    }
+                }
+                gbar = quad_sum(gbar);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int k = 4 * j + hq;
+                    if (k < dout) {
+                        float d = pj[j] * (gj[j] - gbar);
+                        if (!valid || zreg[j] <= -5e8f) d = 0.0f;
+                        ls[hrow * lstride + k] = d;
+                    }
+                }
+            } else if (MODE == M_QCRITIC) {
+                // Q of the taken action vs the target (F.mse_loss over alive envs x agents, x n_alive: agent-MEAN, env-SUM)
+                float qa = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq == ri.act) qa = zreg[j];
+                qa = quad_sum(qa);
+                const float df = qa - ri.ret;
+                if (valid && hq == 0) {
+                    st_vl += invA * df * df;
+                    if (ri.ag == 0) st_cnt += 1.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int k = 4 * j + hq;
+                    if (k < dout) ls[hrow * lstride + k] = (valid && k == ri.act) ? 2.0f * invA * df : 0.0f;
                 }
             } else if (hq == 0) {  // M_CRITIC: one output per row, owned by lane hq == 0
                 float d = 0.0f;
@@ -897,6 +979,18 @@ inline int launch_train(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_
         case 7: launch_variant<7, MODE>(a, grid, lds_bytes, s); break;
         case 8: launch_variant<8, MODE>(a, grid, lds_bytes, s); break;
         default: CM_FAIL(-1, "input width %d > %d is not supported by the fused training kernels", a.din, 8 * KC);
+    }
+    return 0;
+}
+
+// COMA modes: fused kernels for din <= 128 only (wider inputs take the split schedule of cm_mlp_split.h)
+template <int MODE>
+inline int launch_train_small(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+    const int nch = (a.din + KC - 1) / KC;
+    switch (nch) {
+        case 1: launch_variant<1, MODE>(a, grid, lds_bytes, s); break;
+        case 2: launch_variant<2, MODE>(a, grid, lds_bytes, s); break;
+        default: CM_FAIL(-1, "input width %d > %d needs the split schedule", a.din, 2 * KC);
     }
     return 0;
 }

@@ -191,6 +191,53 @@ int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint
                       int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
                       float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
 
+/* ---- COMA  (cleanmarl/coma_multienvs.py, cleanmarl/coma.py) -----------------------------------
+ * Device layouts as above: obs [E][A][T][Do], state [E][T][Ds], action [E][A][T] int32, avail [E][A][T][K] u8,
+ * reward [E][T], ep_len [E]; K-output tensors are [E][A][T][K]. */
+/* Actor.act with exploration (coma_multienvs.py:177-186): probs = (1-eps) softmax(masked logits) + eps * avail / n_avail;
+ * same Philox keying as cm_policy_act; logp = log(probs[action]). */
+int cm_policy_act_eps(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                      int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
+                      const float* params, double eps, uint64_t seed, int64_t row_offset, int t,
+                      int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
+/* Critic.coma_inputs (coma_multienvs.py:222-240): out [E][A][T][Ds + Do + (A-1)K] = state | own obs | one-hot actions of
+ * the other agents in agent order.  The Q network itself is cm_mlp_forward on these rows (dout = K; pass avail to get
+ * the masked_fill(~avail, -1e9) of the TARGET-critic calls at :565-570 / :590-595). */
+int cm_coma_build_inputs(const float* state, const float* obs, const int32_t* action, int E, int A, int T, int Ds, int Do,
+                         int n_actions, float* out, cm_stream_t stream);
+/* torch.gather(q, -1, action) (coma_multienvs.py:571-575, 596-600): out[row] = q[row][action[row]]. */
+int cm_gather_taken(const float* q, const int32_t* action, int64_t rows, int n_actions, float* out, cm_stream_t stream);
+/* n-step targets (coma_multienvs.py:581-613): sum_{i<n} gamma^i r_{t+i} + gamma^n qtaken[t+n] if t < len-n, else the
+ * discounted reward-to-go; 0 on padded steps.  (The TD(lambda) targets of :556-580 are cm_td_lambda_scan with
+ * values := qtaken, Av = A.) */
+int cm_nstep_returns(const float* reward, const float* qtaken, const int32_t* ep_len, int E, int A, int T, double gamma,
+                     int nsteps, float* ret, cm_stream_t stream);
+/* Workspace of the two-schedule fused training passes below (fused for din <= 128, else fused + streaming dW0). */
+size_t cm_mlp_split_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout);
+/* Critic step (coma_multienvs.py:620-631): MSE between Q[taken action] and target over valid rows, agent-mean /
+ * env-sum like a8; x = cm_coma_build_inputs rows.  grad_and_stats[P + 8]: un-normalised gradient + CM_STAT_VLOSS/COUNT. */
+int cm_qcritic_fwd_bwd(const float* x, const int32_t* action, const float* target, const int32_t* ep_len, int E, int A, int T,
+                       int din, int hidden, int n_hidden_layers, int n_actions, const float* params, float* grad_and_stats,
+                       void* ws, size_t ws_bytes, cm_stream_t stream);
+/* Counterfactual advantage (coma_multienvs.py:657-663): adv = q[a] - sum_k softmax(logits)_k q_k from the actor's masked
+ * logits and the critic's Q (both [E][A][T][K], via cm_mlp_forward), plus per-time-step raw sums
+ * tstats[T][4] = {n valid rows, sum adv, sum adv^2, sum of action indices over ALL rows} in float64 (all-reduce(sum) them
+ * across ranks); cm_coma_normalize_adv then applies (adv - mean_t) / (std_t + 1e-8) (unbiased std) on the steps where the
+ * reference's condition `b_actions[:, t].sum() > n_agents` (:664) holds. */
+size_t cm_coma_advantage_workspace_bytes(int E, int A, int T);
+int cm_coma_advantage(const float* logits, const float* q, const int32_t* action, const int32_t* ep_len, int E, int A, int T,
+                      int n_actions, float* adv, double* tstats, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_coma_normalize_adv(float* adv, const double* tstats, int E, int A, int T, cm_stream_t stream);
+/* Actor step (coma_multienvs.py:649-676, eps = 0): row loss -log(pi_a + 1e-8) * adv - c * (-(pi log(pi + 1e-8)).mean_k),
+ * summed over valid rows of ALL agents.  Stats: CM_STAT_PG = sum log(pi_a + 1e-8) * adv, CM_STAT_ENT = sum of the K-mean
+ * entropies, CM_STAT_COUNT = N. */
+int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action, const float* adv,
+                          const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                          const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
+                          cm_stream_t stream);
+/* soft_update (coma_multienvs.py:266-270): target = polyak * src + (1 - polyak) * target. */
+int cm_polyak_update(float* target, const float* src, int64_t n, double polyak, cm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,3 +33,26 @@ def act(logits, avail, seed, row_offset, t):
     lse = (m[:, 0] + np.log(ssum)).astype(np.float32)
     logp = logits[np.arange(R), action] - lse
     return action, logp.astype(np.float32), u
+
+
+def act_eps(logits, avail, eps, seed, row_offset, t):
+    """COMA's Actor.act (cleanmarl/coma_multienvs.py:177-186) with the build's RNG: probs = (1-eps) softmax + eps avail/n_avail,
+    inverse CDF over the available actions.  -> (action[R], log prob of the sampled action [R], u[R])"""
+    logits = np.asarray(logits, dtype=np.float32)
+    avail = np.asarray(avail, dtype=bool)
+    R, K = logits.shape
+    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row_offset))
+    k0, k1 = split_seed(seed)
+    x, _, _, _ = philox4x32((rows & np.uint64(0xFFFFFFFF)).astype(np.uint32), (rows >> np.uint64(32)).astype(np.uint32),
+                            np.uint32(t), np.uint32(STREAM_ACT), k0, k1)
+    u = u01(x)
+    m = logits.max(1, keepdims=True)
+    e = np.exp(logits - m).astype(np.float64)
+    probs = (1.0 - eps) * e / e.sum(1, keepdims=True) + eps * avail / np.maximum(avail.sum(1, keepdims=True), 1)
+    probs = np.where(avail, probs, 0.0)
+    cum = np.cumsum(probs, axis=1)
+    action = np.zeros(R, np.int64)
+    for r in range(R):
+        idx = np.nonzero(avail[r] & (u[r] < cum[r]))[0]
+        action[r] = idx[0] if idx.size else np.nonzero(avail[r])[0][-1]
+    return action, np.log(probs[np.arange(R), action]).astype(np.float32), u

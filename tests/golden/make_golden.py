@@ -286,7 +286,7 @@ CASES = {
                       dict(batch_size=6, actor_hidden_dim=64, critic_hidden_dim=64, clip_gradients=0.5, normalize_return=True),
                       dict(A=3, obs_raw=6, K=5, horizon=15, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
     "coma_nstep": ("coma_multienvs.py",
-                   dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=128, use_tdlamda=False, nsteps=3,
+                   dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=64, use_tdlamda=False, nsteps=3,
                         normalize_advantage=False, normalize_reward=True),
                    dict(A=4, obs_raw=9, K=6, horizon=12, ragged=True, avail_p=1.0, state_dim=14, done_mode="truncate")),
 }

@@ -1,0 +1,165 @@
+"""GPU parity of the COMA path: HIP kernels through the C-ABI vs goldens captured from the unmodified
+cleanmarl/coma_multienvs.py and vs the CPU oracle (oracle/coma.py) on seeded inputs.  Tolerance 1e-4 (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+
+
+def _learner(batch, ap, cp, hp, dev, reward=None, target=None):
+    from cleanmarl_amd.coma import COMAHParams, COMALearner
+    from cleanmarl_amd.learner import DeviceBatch, NetSpec, flatten_params
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), 
+                                          batch["reward"] if reward is None else reward, batch["states"], batch["avail"],
+                                          batch["mask"], dev)
+    H = COMAHParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                    normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                    target_network_update_freq=int(hp["target_network_update_freq"]), polyak=hp["polyak"],
+                    entropy_coef=hp["entropy_coef"], use_tdlamda=bool(hp["use_tdlamda"]), nsteps=int(hp["nsteps"]),
+                    clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], learning_rate_actor=hp["learning_rate_actor"],
+                    learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, cp[-1].shape[0])
+    L = COMALearner(aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp)
+    if target is not None:
+        L.target.copy_(flatten_params(target, dev))
+    return L, b
+
+
+@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep"])
+def test_coma_update_matches_reference_golden(golden_dir, name):
+    from oracle import coma as C
+    batch, ap, cp, hp, z = C.load_golden(os.path.join(golden_dir, name + ".npz"))
+    dev = torch.device("cuda:0")
+    raw = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else None
+    L, b = _learner(batch, ap, cp, hp, dev, reward=raw)
+    rec = L.train_iteration(b, keep_grads=True)
+    if raw is not None:
+        assert _err(b.reward.cpu().numpy(), z["b_reward"]) <= TOL
+    assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), z["return_lambda"]) <= TOL
+    assert _err(rec["critic_loss"], float(z["cr_loss"])) <= TOL
+    assert _err(rec["actor_loss"], float(z["ac_loss"])) <= TOL
+    assert _err(rec["entropy"], float(z["entropies"])) <= TOL
+    assert _err(rec["critic_gnorm"], float(z["critic_gradients"])) <= TOL
+    assert _err(rec["actor_gnorm"], float(z["actor_gradients"])) <= TOL
+    assert _err(rec["critic_grads"].cpu().numpy(), z["critic_grads"][0]) <= TOL
+    assert _err(rec["actor_grads"].cpu().numpy(), z["actor_grads"][0]) <= TOL
+    assert _err(L.critic.cpu().numpy(), z["critic_after"][0]) <= TOL
+    assert _err(L.actor.cpu().numpy(), z["actor_after"][0]) <= TOL
+    assert _err(L.target.cpu().numpy(), z["target_after"]) <= 1e-6
+
+
+def _seeded(seed, E, A, T, Do, Ds, K, Ha, Hc, La, Lc, ragged=True, avail_p=0.7):
+    from cleanmarl_amd.coma import coma_critic_input_dim
+    from cleanmarl_amd.learner import NetSpec, init_params_like_torch
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(E, T, A, Do, generator=g)
+    states = torch.randn(E, T, Ds, generator=g)
+    avail = torch.rand(E, T, A, K, generator=g) < avail_p
+    avail[..., 0] = True
+    probs = avail.float() / avail.float().sum(-1, keepdim=True)
+    actions = torch.multinomial(probs.reshape(-1, K), 1, generator=g).reshape(E, T, A)
+    reward = torch.randn(E, T, generator=g)
+    lens = torch.randint(max(1, T // 2), T + 1, (E,), generator=g) if ragged else torch.full((E,), T)
+    lens[0] = T
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    m = mask[..., None]
+    batch = dict(obs=obs * m[..., None], states=states * m, avail=avail & m[..., None], actions=actions * m, reward=reward * mask,
+                 mask=mask)
+    torch.manual_seed(seed + 1)
+    ap = init_params_like_torch(NetSpec(Do, Ha, La, K))
+    cp = init_params_like_torch(NetSpec(coma_critic_input_dim(Do, Ds, A, K), Hc, Lc, K))
+    tp = [p + 0.05 * torch.randn(p.shape, generator=g) for p in cp]  # target != critic
+    return batch, ap, cp, tp
+
+
+@pytest.mark.parametrize("E,A,T,Do,Ds,K,Ha,Hc,La,Lc,tdl,nadv", [
+    (9, 3, 11, 10, 14, 5, 64, 64, 1, 1, True, True),        # critic input 34: fused schedule, 1 chunk
+    (7, 4, 13, 30, 70, 6, 32, 64, 1, 1, False, True),       # critic input 118: fused, 2 chunks; n-step targets
+    (6, 5, 9, 40, 200, 12, 64, 64, 0, 2, True, False),      # critic input 288: split schedule, K > 8, 2 hidden layers
+    (40, 8, 16, 56, 384, 5, 64, 64, 1, 1, True, True),      # config-3 shapes (critic input 475)
+])
+def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, tdl, nadv):
+    """Two consecutive iterations on the same batch (Adam state, polyak-averaged target != critic) vs oracle/coma.py."""
+    from oracle import coma as C
+    from oracle import restatement as R
+    batch, ap, cp, tp = _seeded(E * 7 + K, E, A, T, Do, Ds, K, Ha, Hc, La, Lc)
+    hp = dict(gamma=0.99, td_lambda=0.8, normalize_reward=0.0, normalize_advantage=float(nadv), normalize_return=1.0,
+              target_network_update_freq=1.0, polyak=0.1, entropy_coef=0.01, use_tdlamda=float(tdl), nsteps=3.0, clip_gradients=0.5,
+              optimizer="Adam", learning_rate_actor=5e-4, learning_rate_critic=5e-4)
+    dev = torch.device("cuda:0")
+    L, b = _learner(batch, ap, cp, hp, dev, target=tp)
+    oa, oc = R.AdamState(ap, 5e-4, "Adam"), R.AdamState(cp, 5e-4, "Adam")
+    ts = 0
+    for it in range(2):
+        rec = L.train_iteration(b, keep_grads=True)
+        ref = C.update(ap, cp, tp, batch, hp, oa, oc, ts)
+        ts = ref["training_step"]
+        assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ref["ret"].numpy()) <= TOL, it
+        m = batch["mask"][..., None].numpy()
+        assert _err(b.adv.permute(0, 2, 1).cpu().numpy() * m, ref["adv"].numpy() * m) <= TOL, it
+        assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, it
+        assert _err(rec["entropy"], ref["entropy"]) <= TOL, it
+        assert _err(rec["critic_gnorm"], ref["critic_gnorm"]) <= TOL and _err(rec["actor_gnorm"], ref["actor_gnorm"]) <= TOL, it
+        assert _err(rec["critic_grads"].cpu().numpy(), ref["critic_grads"].numpy()) <= TOL, it
+        assert _err(rec["actor_grads"].cpu().numpy(), ref["actor_grads"].numpy()) <= TOL, it
+        assert _err(L.critic.cpu().numpy(), R.flat(cp).numpy()) <= TOL and _err(L.actor.cpu().numpy(), R.flat(ap).numpy()) <= TOL, it
+        assert _err(L.target.cpu().numpy(), R.flat(tp).numpy()) <= TOL, it
+
+
+def test_coma_inputs_and_gather_are_exact():
+    from oracle import coma as C
+    from cleanmarl_amd import _native as N
+    lib, dev = N.load(), torch.device("cuda:0")
+    batch, _, _, _ = _seeded(3, 5, 4, 7, 6, 9, 5, 32, 32, 1, 1)
+    E, T, A, Do = batch["obs"].shape
+    Ds, K = batch["states"].shape[-1], 5
+    ref = C.coma_inputs(batch["states"], batch["obs"], batch["actions"], K).permute(0, 2, 1, 3).contiguous()
+    obs = batch["obs"].permute(0, 2, 1, 3).contiguous().to(dev); st = batch["states"].contiguous().to(dev)
+    act = batch["actions"].permute(0, 2, 1).contiguous().int().to(dev)
+    out = torch.empty(E, A, T, ref.shape[-1], device=dev)
+    N.check(lib.cm_coma_build_inputs(N.ptr(st), N.ptr(obs), N.ptr(act), E, A, T, Ds, Do, K, N.ptr(out), N.stream_ptr()), "build")
+    assert torch.equal(out.cpu(), ref)
+    q = torch.randn(E, A, T, K, device=dev)
+    taken = torch.empty(E, A, T, device=dev)
+    N.check(lib.cm_gather_taken(N.ptr(q), N.ptr(act), E * A * T, K, N.ptr(taken), N.stream_ptr()), "gather")
+    assert torch.equal(taken, q.gather(-1, act.long()[..., None])[..., 0])
+
+
+def test_policy_act_eps_matches_cpu_sampler():
+    from oracle import restatement as R
+    from oracle import sampling
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    torch.manual_seed(11)
+    rows, Do, K, eps = 4000, 24, 7, 0.3
+    spec = NetSpec(Do, 64, 1, K)
+    p = init_params_like_torch(spec)
+    obs = torch.randn(rows, Do)
+    avail = torch.rand(rows, K) < 0.6
+    avail[:, 3] = True
+    action = torch.empty(rows, dtype=torch.int32, device=dev); logp = torch.empty(rows, device=dev)
+    d_obs, d_av, d_p = obs.to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
+    N.check(lib.cm_policy_act_eps(N.ptr(d_obs), Do, N.ptr(d_av), K, rows, Do, 64, 1, K, N.ptr(d_p), eps, 17, 500, 4, N.ptr(action),
+                                  N.ptr(logp), 1, N.stream_ptr()), "act_eps")
+    logits = R.actor_logits(p, obs, avail).numpy()
+    a_ref, lp_ref, u = sampling.act_eps(logits, avail.numpy(), eps, 17, 500, 4)
+    a_gpu, lp_gpu = action.cpu().numpy(), logp.cpu().numpy()
+    same = a_gpu == a_ref
+    assert same.mean() >= 0.99
+    assert np.abs(lp_gpu[same] - lp_ref[same]).max() <= TOL
+    assert avail.numpy()[np.arange(rows), a_gpu].all()
+    # exploration really mixes in the uniform: empirical frequency of the LEAST likely available action is >= eps / n_avail - noise
+    probs = (1 - eps) * torch.softmax(torch.from_numpy(logits), -1).numpy() + eps * avail.numpy() / avail.numpy().sum(1, keepdims=True)
+    assert abs(np.mean(np.log(probs[np.arange(rows), a_gpu])) - np.mean((probs * np.log(np.where(probs > 0, probs, 1))).sum(1))) < 0.05
