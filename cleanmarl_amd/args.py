@@ -102,6 +102,92 @@ class Args:
     """ [build] evaluate with argmax actions instead of sampling (MLP actors; the reference always samples)"""
 
 
+@dataclass
+class ComaArgs:
+    """cleanmarl/coma_multienvs.py:19-89 (coma.py differs only in eval_steps / num_eval_ep, see SCRIPT_DEFAULTS)."""
+    env_type: str = "smaclite"
+    """ Pettingzoo, SMAClite ... (build adds: synthetic, synthetic_cpu, synthetic_shape, synthetic_shape_cpu) """
+    env_name: str = "3m"
+    """ Name of the environment"""
+    env_family: str = "mpe"
+    """ Env family when using pz"""
+    agent_ids: bool = True
+    """ Include id (one-hot vector) at the agent of the observations"""
+    batch_size: int = 3
+    """ Number of episodes to collect in each rollout"""
+    actor_hidden_dim: int = 32
+    """ Hidden dimension of actor network"""
+    actor_num_layers: int = 1
+    """ Number of hidden layers of actor network"""
+    critic_hidden_dim: int = 128
+    """ Hidden dimension of critic network (this build's kernels support <= 64: pass --critic_hidden_dim=64)"""
+    critic_num_layers: int = 1
+    """ Number of hidden layers of critic network"""
+    optimizer: str = "Adam"
+    """ The optimizer"""
+    learning_rate_actor: float = 0.0005
+    """ Learning rate for the actor"""
+    learning_rate_critic: float = 0.0005
+    """ Learning rate for the critic"""
+    total_timesteps: int = 1000000
+    """ Total steps in the environment during training"""
+    gamma: float = 0.99
+    """ Discount factor"""
+    td_lambda: float = 0.8
+    """ TD(lambda) discount factor"""
+    normalize_reward: bool = False
+    """ Normalize the rewards if True"""
+    normalize_advantage: bool = True
+    """ Normalize the advantage if True"""
+    normalize_return: bool = False
+    """ Normalize the returns if True"""
+    target_network_update_freq: int = 1
+    """ Update the target network each target_network_update_freq step in the environment"""
+    polyak: float = 0.005
+    """ Polyak coefficient when using polyak averaging for target network update"""
+    entropy_coef: float = 0.001
+    """ Entropy coefficient """
+    use_tdlamda: bool = True
+    """ Use TD(lambda) as a target for the critic, if False use n-step returns (n=nsteps) """
+    nsteps: int = 1
+    """ number of stpes when using n-step returns as a target for the critic"""
+    start_e: float = 0.5
+    """ The starting value of epsilon. See Architecture & Training in COMA's paper Sec. 5"""
+    end_e: float = 0.002
+    """ The end value of epsilon. See Architecture & Training in COMA's paper Sec. 5"""
+    exploration_fraction: float = 750
+    """ The number of training steps it takes from to go from start_e to  end_e"""
+    clip_gradients: float = -1
+    """ 0< for no clipping and 0> if clipping at clip_gradients"""
+    log_every: int = 10
+    """ Log rollout stats every log_every episode"""
+    eval_steps: int = 10
+    """ Evaluate the policy each eval_steps training steps"""
+    num_eval_ep: int = 10
+    """ Number of evaluation episodes"""
+    use_wnb: bool = False
+    """ Logging to Weights & Biases if True"""
+    wnb_project: str = ""
+    """ Weights & Biases project name"""
+    wnb_entity: str = ""
+    """ Weights & Biases entity name"""
+    device: str = "cuda"
+    """ Device (this build: cuda only; the reference defaults to cpu)"""
+    seed: int = 1
+    """ Random seed"""
+    # ---- build-only flags (same meaning as in Args)
+    synthetic_agents: int = 3
+    synthetic_steps: int = 25
+    synthetic_obs: int = 105
+    synthetic_state: int = 243
+    synthetic_actions: int = 17
+    synthetic_avail_p: float = 0.7
+    vector_env: str = "shm"
+    env_workers: int = 0
+    checkpoint: str = ""
+    checkpoint_every: int = 0
+
+
 # per-script default overrides (SURVEY.md Appendix B)
 SCRIPT_DEFAULTS = {
     "mappo_multienvs": dict(),
@@ -113,7 +199,14 @@ SCRIPT_DEFAULTS = {
     "ippo": dict(critic_hidden_dim=32),
     "mappo_lstm": dict(num_eval_ep=5, tbptt=10),
     "ippo_lstm": dict(critic_hidden_dim=32, tbptt=5),
+    # COMA (cleanmarl/coma_multienvs.py:77-80, coma.py:76-79)
+    "coma_multienvs": dict(),
+    "coma": dict(eval_steps=50, num_eval_ep=5),
 }
+
+
+def args_class(script):
+    return ComaArgs if script.startswith("coma") else Args
 
 
 def _str2bool(v):
@@ -129,7 +222,7 @@ def _str2bool(v):
 def build_parser(script):
     defaults = dict(SCRIPT_DEFAULTS[script])
     p = argparse.ArgumentParser(prog=script + ".py", description=f"MI355X-native {script} (cleanmarl CLI surface)")
-    for f in fields(Args):
+    for f in fields(args_class(script)):
         default = defaults.get(f.name, f.default)
         names = ["--" + f.name]
         if "_" in f.name:
@@ -145,4 +238,4 @@ def build_parser(script):
 
 def parse_args(script, argv=None):
     ns = build_parser(script).parse_args(argv)
-    return Args(**vars(ns))
+    return args_class(script)(**vars(ns))

@@ -1,0 +1,181 @@
+"""Training driver behind coma_multienvs.py and coma.py.  Control flow follows the reference's ``__main__`` block
+(cleanmarl/coma_multienvs.py:352-737; coma.py for the single-environment front-end): per iteration epsilon =
+linear_schedule(training_step), rollout with the epsilon-mixed policy, targets from the target critic, one critic step,
+polyak update, one actor step, logging, periodic eval (sampled with eps = 0).  All numerics run in libcleanmarl_hip.so.
+Multi-GPU: env-sharded like driver.py (one all-reduce per optimiser step + the [T][4] advantage-moment sums).
+"""
+import datetime
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .args import parse_args
+from .coma_learner import COMAHParams, COMALearner, coma_critic_input_dim
+from .driver import HostActor, host_rollout, host_rollout_shm, host_rollout_single
+from .env.shm_vector import ShmVectorEnv
+from .env.vector import PipeVectorEnv, environment
+from .learner import NetSpec, init_params_like_torch, pad_time
+from .logger import ScalarWriter
+from .rollout import SyntheticShapeRollout, SyntheticSpreadRollout
+
+RUN_PREFIX = {"coma_multienvs": "COMA-multienvs", "coma": "COMA"}  # coma_multienvs.py:424, coma.py:348
+
+
+def linear_schedule(start_e, end_e, duration, t):
+    """cleanmarl/coma_multienvs.py:243-245."""
+    slope = (end_e - start_e) / duration
+    return max(slope * t + start_e, end_e)
+
+
+def run(script, argv=None):
+    args = parse_args(script, argv)
+    single_env = script == "coma"
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not str(args.device).startswith("cuda"):
+        raise N.NativeError(f"--device={args.device}: this build computes on MI355X only (cuda / cuda:N); there is no CPU path")
+    random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        pg = torch.distributed.group.WORLD
+    E_glob = args.batch_size
+    E = E_glob // world + (1 if rank < E_glob % world else 0)
+    env_offset = rank * (E_glob // world) + min(rank, E_glob % world)
+    synth = dict(agents=args.synthetic_agents, steps=args.synthetic_steps, obs=args.synthetic_obs, state=args.synthetic_state,
+                 actions=args.synthetic_actions, avail_p=args.synthetic_avail_p)
+    fac = dict(env_type=args.env_type, env_name=args.env_name, env_family=args.env_family, agent_ids=args.agent_ids,
+               kwargs={}, seed=args.seed, synthetic=synth)
+    eval_env = environment(**dict(fac, index=10 ** 6))
+    A, Do, Ds, K = eval_env.n_agents, eval_env.get_obs_size(), eval_env.get_state_size(), eval_env.get_action_size()
+
+    # construction order actor -> critic (coma_multienvs.py:391-405); the target starts as a copy of the critic (:406)
+    actor_spec = NetSpec(Do, args.actor_hidden_dim, args.actor_num_layers, K)
+    critic_spec = NetSpec(coma_critic_input_dim(Do, Ds, A, K), args.critic_hidden_dim, args.critic_num_layers, K)
+    a_init, c_init = init_params_like_torch(actor_spec), init_params_like_torch(critic_spec)
+    learner = COMALearner(actor_spec, critic_spec, A, COMAHParams.from_args(args), device, a_init, c_init, pg, world)
+
+    device_env = args.env_type in ("synthetic", "synthetic_shape")
+    venv = roll = the_env = None
+    if args.env_type == "synthetic_shape":
+        roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
+                                     n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
+                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset)
+    elif device_env:
+        roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
+                                      env_offset=env_offset)
+    elif single_env:
+        the_env = environment(**dict(fac, index=env_offset))
+    elif args.vector_env == "pipe":
+        venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
+    else:
+        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None)
+    host_actor = HostActor(learner, A, False, device)
+
+    time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+    run_name = f"{RUN_PREFIX[script]}-{args.env_type}__{args.env_name}__{time_token}"
+    writer = None
+    if rank == 0:
+        if args.use_wnb:
+            import wandb
+            wandb.init(project=args.wnb_project, entity=args.wnb_entity, sync_tensorboard=True, config=vars(args), name=run_name)
+        writer = ScalarWriter(f"runs/{run_name}")
+        writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % "\n".join(f"|{k}|{v}|" for k, v in vars(args).items()))
+
+    ep_rewards, ep_lengths, ep_stats = [], [], []
+    step = 0
+    if args.checkpoint and os.path.exists(args.checkpoint):
+        ck = torch.load(args.checkpoint, map_location="cpu")
+        learner.load_state_dict(ck["learner"])
+        step = ck["step"]
+        if roll is not None:
+            roll.episode = ck.get("episode", 0)
+
+    def save_checkpoint():
+        if args.checkpoint and rank == 0:
+            torch.save(dict(learner=learner.state_dict(), step=step, episode=roll.episode if roll is not None else 0), args.checkpoint)
+
+    iteration = 0
+    while step < args.total_timesteps:
+        training_step = learner.training_step
+        epsilon = linear_schedule(args.start_e, args.end_e, args.exploration_fraction, training_step)  # :449-451
+        if device_env:
+            b = roll.collect(learner.actor, actor_spec, eps=epsilon)
+            stats = dict(ep_reward=b.reward.sum(1).cpu().tolist(), ep_len=[b.T] * E, infos=[None] * E)
+        elif single_env:
+            b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, False, device, explore=epsilon)
+        else:
+            collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
+            b, stats = collect(venv, host_actor, E, A, args.seed + training_step, False, device, explore=epsilon)
+        n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
+        if world > 1:
+            torch.distributed.all_reduce(n_steps, group=pg)
+            if not device_env:
+                t_max = torch.tensor([b.T], device=device)
+                torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX, group=pg)
+                b = pad_time(b, int(t_max.item()))
+        step += int(n_steps.item())
+        ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
+        if args.env_type == "smaclite":
+            ep_stats.extend([i["battle_won"] for i in stats["infos"]])
+        # rollout logging cadence and the (sic) episode counters of the two scripts: coma_multienvs.py:530-545, coma.py:419-434
+        log_now = (len(ep_rewards) > args.log_every) if single_env else (training_step % args.log_every == 0)
+        if log_now:
+            if writer:
+                writer.add_scalar("rollout/ep_reward", np.mean(ep_rewards), step)
+                writer.add_scalar("rollout/ep_length", np.mean(ep_lengths), step)
+                writer.add_scalar("rollout/epsilon", epsilon, step)
+                writer.add_scalar("rollout/num_episodes", ((training_step + 1) if single_env else training_step) * E_glob, step)
+                if args.env_type == "smaclite":
+                    writer.add_scalar("rollout/battle_won", np.mean(ep_stats), step)
+            ep_rewards, ep_lengths, ep_stats = [], [], []
+
+        rec = learner.train_iteration(b)
+        iteration += 1
+        if args.checkpoint_every and iteration % args.checkpoint_every == 0:
+            save_checkpoint()
+        if writer:  # :678-684
+            writer.add_scalar("train/critic_loss", rec["critic_loss"], step)
+            writer.add_scalar("train/actor_loss", rec["actor_loss"], step)
+            writer.add_scalar("train/entropy", rec["entropy"], step)
+            writer.add_scalar("train/actor_gradients", rec["actor_gnorm"], step)
+            writer.add_scalar("train/critic_gradients", rec["critic_gnorm"], step)
+            writer.add_scalar("train/epsilon", epsilon, step)
+            writer.add_scalar("train/num_updates", learner.training_step, step)
+
+        if rank == 0 and learner.training_step % args.eval_steps == 0:  # :692-727 (actions sampled with eps = 0)
+            eval_obs, _ = eval_env.reset()
+            rets, lens, infos_l, cur_r, cur_l = [], [], [], 0.0, 0
+            while len(rets) < args.num_eval_ep:
+                act, _, _ = host_actor.act(eval_obs[None], np.asarray(eval_env.get_avail_actions())[None], seed=args.seed + 7919)
+                eval_obs, r, done, trunc, info = eval_env.step(act.reshape(-1))
+                cur_r += r; cur_l += 1
+                if done or trunc:
+                    eval_obs, _ = eval_env.reset()
+                    rets.append(cur_r); lens.append(cur_l); infos_l.append(info); cur_r, cur_l = 0.0, 0
+            writer.add_scalar("eval/ep_reward", np.mean(rets), step)
+            writer.add_scalar("eval/std_ep_reward", np.std(rets), step)
+            writer.add_scalar("eval/ep_length", np.mean(lens), step)
+            if args.env_type == "smaclite":
+                writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
+
+    save_checkpoint()
+    if writer:
+        writer.close()
+    if args.use_wnb and rank == 0:
+        import wandb
+        wandb.finish()
+    eval_env.close()
+    if venv:
+        venv.close()
+    if the_env is not None:
+        the_env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return dict(step=step, training_step=learner.training_step, history=writer.history if writer else [], learner=learner)

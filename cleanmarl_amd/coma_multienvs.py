@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""MI355X-native drop-in for the reference script cleanmarl/coma_multienvs.py (same flags, defaults and TensorBoard tags; the
+reference's default --critic_hidden_dim=128 exceeds this build's 64-wide kernels: pass --critic_hidden_dim=64).
+
+    python cleanmarl_amd/coma_multienvs.py --env_type=pz --env_family=mpe --env_name=simple_spread_v3 --batch_size=4 --critic_hidden_dim=64
+    python cleanmarl_amd/coma_multienvs.py --env_type=synthetic --synthetic_agents=8 --synthetic_steps=128 --batch_size=1024 --critic_hidden_dim=64
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from cleanmarl_amd.coma_driver import run  # noqa: E402
+
+if __name__ == "__main__":
+    run("coma_multienvs")

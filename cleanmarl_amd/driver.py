@@ -38,7 +38,7 @@ class HostActor:
         self.lib = N.load()
         self.calls = 0
 
-    def act(self, obs, avail, h=None, seed=0, greedy=False):
+    def act(self, obs, avail, h=None, seed=0, greedy=False, eps=0.0):
         spec = self.L.actor_spec
         x = torch.as_tensor(np.ascontiguousarray(obs), dtype=torch.float32).reshape(-1, spec.din).to(self.dev)
         av = torch.as_tensor(np.ascontiguousarray(avail)).reshape(-1, spec.dout).to(torch.uint8).to(self.dev)
@@ -59,6 +59,10 @@ class HostActor:
             N.check(self.lib.cm_gru_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
                                                N.ptr(self.L.actor), N.ptr(h), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
                                                N.stream_ptr()), "cm_gru_policy_act")
+        elif eps > 0.0:  # COMA exploration
+            N.check(self.lib.cm_policy_act_eps(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
+                                               spec.dout, N.ptr(self.L.actor), float(eps), seed, 0, self.calls, N.ptr(action),
+                                               N.ptr(logp), 1, N.stream_ptr()), "cm_policy_act_eps")
         else:
             N.check(self.lib.cm_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
                                            spec.dout, N.ptr(self.L.actor), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
@@ -66,7 +70,7 @@ class HostActor:
         return action.cpu().numpy(), logp.cpu().numpy(), h
 
 
-def host_rollout(venv, actor, E, A, seed, recurrent, device):
+def host_rollout(venv, actor, E, A, seed, recurrent, device, explore=0.0):
     """One episode per env over the pipe protocol (cleanmarl/mappo_multienvs.py:393-453; GRU: hidden state
     carried for alive envs only, cleanmarl/mappo_lstm_multienvs.py:406-433).  Returns (DeviceBatch, stats)."""
     cont = venv.reset_all()
@@ -81,7 +85,7 @@ def host_rollout(venv, actor, E, A, seed, recurrent, device):
         if recurrent and h_all is not None:
             idx = torch.as_tensor(alive, device=device)
             h_in = h_all.reshape(E, A, -1)[idx].reshape(len(alive) * A, -1).contiguous()
-        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed)
+        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed, eps=explore)
         if recurrent:
             if h_all is None:
                 h_all = h_out
@@ -121,7 +125,7 @@ def _collate(eps, ep_len, E, A, device):
     return DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device)
 
 
-def host_rollout_single(env, actor, E, A, seed, recurrent, device):
+def host_rollout_single(env, actor, E, A, seed, recurrent, device, explore=0.0):
     """The single-environment front-ends (cleanmarl/mappo.py:302-343, ippo.py, mappo_lstm.py, ippo_lstm.py): ``batch_size``
     episodes collected ONE AFTER THE OTHER from one in-process env (no worker processes); the GRU hidden state starts at
     zero with every episode (mappo_lstm.py:306-318).  Returns the same (DeviceBatch, stats) as the vectorised collectors."""
@@ -133,7 +137,7 @@ def host_rollout_single(env, actor, E, A, seed, recurrent, device):
         tot, n, h, info = 0.0, 0, None, None
         while not (done or trunc):
             avail, state = np.asarray(env.get_avail_actions()), np.asarray(env.get_state())
-            act, logp, h = actor.act(np.asarray(obs)[None], avail[None], h=h, seed=seed)
+            act, logp, h = actor.act(np.asarray(obs)[None], avail[None], h=h, seed=seed, eps=explore)
             nobs, r, done, trunc, info = env.step(act.reshape(-1))
             e["obs"].append(np.asarray(obs, np.float32)); e["actions"].append(act.reshape(A)); e["logp"].append(logp.reshape(A))
             e["reward"].append(r); e["state"].append(state); e["avail"].append(avail)
@@ -143,7 +147,7 @@ def host_rollout_single(env, actor, E, A, seed, recurrent, device):
     return _collate(eps, ep_len, E, A, device), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
 
 
-def host_rollout_shm(venv, actor, E, A, seed, recurrent, device):
+def host_rollout_shm(venv, actor, E, A, seed, recurrent, device, explore=0.0):
     """Same episode collection through the shared-memory batched-step vector env: one token per
     WORKER per step instead of one pickled round trip per ENV.  Returns the same (DeviceBatch, stats)."""
     hstate = {"h": None}
@@ -153,7 +157,7 @@ def host_rollout_shm(venv, actor, E, A, seed, recurrent, device):
         if recurrent and hstate["h"] is not None:
             idx = torch.as_tensor(alive, device=device)
             h_in = hstate["h"].reshape(E, A, -1)[idx].reshape(len(alive) * A, -1).contiguous()
-        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed)
+        act, logp, h_out = actor.act(obs, avail, h=h_in, seed=seed, eps=explore)
         if recurrent:
             if hstate["h"] is None:
                 hstate["h"] = h_out

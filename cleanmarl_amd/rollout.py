@@ -32,7 +32,7 @@ class SyntheticSpreadRollout:
         self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
         self.episode = 0
 
-    def collect(self, actor_flat, actor_spec, fused=None):
+    def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
         """One episode per env (reference outer loop body, :393-453).  Everything is enqueued on the
         current stream; returns the filled DeviceBatch without synchronising.
         fused=None picks the single-launch persistent kernel (cm_rollout_spread) whenever the shape allows,
@@ -41,6 +41,8 @@ class SyntheticSpreadRollout:
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         can_fuse = actor_spec.kind == "mlp" and bool(lib.cm_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden,
                                                                                  actor_spec.n_layers))
+        if eps > 0.0:  # COMA's epsilon-mixed exploration (coma_multienvs.py:477-484): per-step launches
+            fused = False
         if fused is None:
             fused = can_fuse
         if fused:
@@ -57,10 +59,16 @@ class SyntheticSpreadRollout:
                                        self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
         for t in range(T):
-            N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
-                                      actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat),
-                                      act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
-                    "cm_policy_act")
+            if eps > 0.0:
+                N.check(lib.cm_policy_act_eps(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
+                                              actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps),
+                                              act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
+                        "cm_policy_act_eps")
+            else:
+                N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
+                                          actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat),
+                                          act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
+                        "cm_policy_act")
             N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,
                                           N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
         self.episode += 1
@@ -83,9 +91,11 @@ class SyntheticShapeRollout:
         self.h = None
         self.episode = 0
 
-    def collect(self, actor_flat, actor_spec, fused=None):
+    def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        if eps > 0.0:
+            fused = False
         N.check(lib.cm_shape_env_fill(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
                                       self.episode, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.avail), s), "cm_shape_env_fill")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
@@ -107,6 +117,10 @@ class SyntheticShapeRollout:
                 N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                               actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
                                               _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
+            elif eps > 0.0:
+                N.check(lib.cm_policy_act_eps(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                              actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps), act_seed,
+                                              self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_policy_act_eps")
             else:
                 N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                           actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A, t,

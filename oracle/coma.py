@@ -135,7 +135,7 @@ def update(actor_params, critic_params, target_params, batch, hp, actor_opt=None
         R.clip_grads_(ag, hp["clip_gradients"])
     with torch.no_grad():
         actor_opt.step(actor_params, ag)
-    return dict(ret=ret, adv=at["adv"], critic_loss=float(cl), actor_loss=float(al), entropy=float(at["ent"] / N),
+    return dict(ret=ret, adv=at["adv"], critic_loss=float(cl.detach()), actor_loss=float(al.detach()), entropy=float(at["ent"].detach() / N),
                 critic_gnorm=float(cnorm), actor_gnorm=float(anorm), critic_grads=R.flat(cg), actor_grads=R.flat(ag),
                 training_step=training_step)  # grads as the optimiser consumed them (post-clip), like the goldens
 

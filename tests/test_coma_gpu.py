@@ -17,7 +17,7 @@ def _err(a, b):
 
 
 def _learner(batch, ap, cp, hp, dev, reward=None, target=None):
-    from cleanmarl_amd.coma import COMAHParams, COMALearner
+    from cleanmarl_amd.coma_learner import COMAHParams, COMALearner
     from cleanmarl_amd.learner import DeviceBatch, NetSpec, flatten_params
     b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), 
                                           batch["reward"] if reward is None else reward, batch["states"], batch["avail"],
@@ -60,7 +60,7 @@ def test_coma_update_matches_reference_golden(golden_dir, name):
 
 
 def _seeded(seed, E, A, T, Do, Ds, K, Ha, Hc, La, Lc, ragged=True, avail_p=0.7):
-    from cleanmarl_amd.coma import coma_critic_input_dim
+    from cleanmarl_amd.coma_learner import coma_critic_input_dim
     from cleanmarl_amd.learner import NetSpec, init_params_like_torch
     g = torch.Generator().manual_seed(seed)
     obs = torch.randn(E, T, A, Do, generator=g)
@@ -163,3 +163,30 @@ def test_policy_act_eps_matches_cpu_sampler():
     # exploration really mixes in the uniform: empirical frequency of the LEAST likely available action is >= eps / n_avail - noise
     probs = (1 - eps) * torch.softmax(torch.from_numpy(logits), -1).numpy() + eps * avail.numpy() / avail.numpy().sum(1, keepdims=True)
     assert abs(np.mean(np.log(probs[np.arange(rows), a_gpu])) - np.mean((probs * np.log(np.where(probs > 0, probs, 1))).sum(1))) < 0.05
+
+
+@pytest.mark.parametrize("script,env_type", [("coma_multienvs", "synthetic"), ("coma_multienvs", "synthetic_cpu"),
+                                             ("coma_multienvs", "synthetic_shape"), ("coma", "synthetic_cpu")])
+def test_coma_scripts_run_and_log_reference_tags(script, env_type, tmp_path, monkeypatch):
+    import math
+    from cleanmarl_amd.coma_driver import run
+    monkeypatch.chdir(tmp_path)
+    out = run(script, [f"--env_type={env_type}", "--batch_size=4", "--synthetic_agents=3", "--synthetic_steps=20", "--synthetic_obs=20",
+                       "--synthetic_state=30", "--synthetic_actions=9", "--total_timesteps=240", "--eval_steps=1", "--num_eval_ep=2",
+                       "--log_every=1", "--critic_hidden_dim=64"])
+    tags = {t for t, _, _ in out["history"]}
+    assert {"train/critic_loss", "train/actor_loss", "train/entropy", "train/actor_gradients", "train/critic_gradients",
+            "train/epsilon", "train/num_updates", "rollout/ep_reward", "rollout/ep_length", "rollout/epsilon", "rollout/num_episodes",
+            "eval/ep_reward", "eval/std_ep_reward", "eval/ep_length"} <= tags
+    assert all(math.isfinite(v) for _, v, _ in out["history"])
+    assert out["step"] == 240 and out["training_step"] == 3
+    eps = [v for t, v, _ in out["history"] if t == "train/epsilon"]
+    assert eps[0] == 0.5 and eps == sorted(eps, reverse=True) and abs(eps[1] - (0.5 + (0.002 - 0.5) / 750)) < 1e-12
+
+
+def test_coma_default_critic_width_fails_loudly(tmp_path, monkeypatch):
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.coma_driver import run
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(N.NativeError, match="hidden_dim=128"):
+        run("coma_multienvs", ["--env_type=synthetic", "--batch_size=2", "--synthetic_steps=5", "--total_timesteps=10"])

@@ -32,6 +32,12 @@ def test_cli_defaults_match_reference_scripts():
     assert (ml.tbptt, ml.num_eval_ep, ml.eval_steps, ml.optimizer) == (10, 5, 50, "Adam")
     il = parse_args("ippo_lstm", [])
     assert (il.tbptt, il.num_eval_ep, il.optimizer, il.critic_hidden_dim) == (5, 10, "Adam", 32)
+    # COMA: cleanmarl/coma_multienvs.py:19-89, coma.py:76-79
+    c = parse_args("coma_multienvs", [])
+    assert (c.critic_hidden_dim, c.learning_rate_actor, c.td_lambda, c.normalize_advantage, c.polyak, c.use_tdlamda, c.nsteps,
+            c.start_e, c.end_e, c.exploration_fraction, c.target_network_update_freq, c.eval_steps, c.num_eval_ep) == \
+        (128, 0.0005, 0.8, True, 0.005, True, 1, 0.5, 0.002, 750, 1, 10, 10)
+    assert (parse_args("coma", []).eval_steps, parse_args("coma", []).num_eval_ep) == (50, 5)
     b = parse_args("mappo_multienvs", ["--env_type=pz", "--env-name", "simple_spread_v3", "--batch_size", "4",
                                        "--normalize_reward", "--no-agent_ids", "--clip_gradients=0.5", "--use_wnb=False"])
     assert (b.env_type, b.env_name, b.batch_size, b.normalize_reward, b.agent_ids, b.clip_gradients) == \
