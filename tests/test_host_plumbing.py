@@ -59,7 +59,7 @@ def test_pipe_vector_env_and_collation():
     class Stub:  # stands in for the on-device actor: deterministic scripted actions
         t = 0
 
-        def act(self, obs, avail, h=None, seed=0):
+        def act(self, obs, avail, h=None, seed=0, eps=0.0):
             a = script[self.t][:obs.shape[0] * A]
             self.t += 1
             return a.astype(np.int32), np.full(a.shape, -1.5, np.float32), None
@@ -94,7 +94,7 @@ def test_shm_vector_env_matches_pipe_protocol_and_is_faster():
                synthetic=dict(agents=A, steps=T, ragged=True))
 
     class Stub:  # deterministic actor: the action is a function of the observation only
-        def act(self, obs, avail, h=None, seed=0):
+        def act(self, obs, avail, h=None, seed=0, eps=0.0):
             a = (np.abs(obs[..., :4]).sum(-1) * 1000).astype(np.int64) % 5
             return a.reshape(-1).astype(np.int32), np.full(a.size, -0.7, np.float32), None
 
