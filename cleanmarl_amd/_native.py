@@ -40,6 +40,9 @@ SIGNATURES = {
     "cm_coma_advantage": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_coma_normalize_adv": (_i, [_p, _p, _i, _i, _i, _p]),
     "cm_coma_actor_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _p, _p, _sz, _p]),
+    "cm_coma_critic_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "cm_coma_q_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_coma_critic_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_polyak_update": (_i, [_p, _p, _l, _d, _p]),
     "cm_policy_act_episode": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p]),
     "cm_td_lambda_scan": (_i, [_p, _p, _p, _i, _i, _i, _i, _d, _d, _p, _p, _p]),
@@ -61,6 +64,7 @@ SIGNATURES = {
     "cm_shape_env_reward": (_i, [_i, _i, _i, _i, _u64, _l, _l, _p, _p, _p]),
     "cm_rollout_spread_supported": (_i, [_i, _i, _i, _i]),
     "cm_rollout_spread": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "cm_rollout_spread_eps": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

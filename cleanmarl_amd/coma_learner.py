@@ -1,6 +1,6 @@
 """COMA learner on the HIP kernels: the update of cleanmarl/coma_multienvs.py:553-684 (identical in
 cleanmarl/coma.py) on a DeviceBatch -- targets from the TARGET critic (TD(lambda) via cm_td_lambda_scan with
-V := Q_target[taken action], or cm_nstep_returns), ONE critic step (cm_qcritic_fwd_bwd), polyak target update, ONE actor
+V := Q_target[taken action], or cm_nstep_returns), ONE critic step (cm_coma_critic_fwd_bwd: factored critic input, never materialised), polyak target update, ONE actor
 step with the counterfactual baseline (cm_coma_advantage / cm_coma_normalize_adv / cm_coma_actor_fwd_bwd).
 
 Env-sharded data parallelism as in learner.py: per optimiser step one all-reduce(sum) of the un-normalised flat gradient
@@ -74,14 +74,13 @@ class COMALearner:
         cs, a, dev, lib = self.critic_spec, self.actor_spec, self.device, self.lib
         f32 = dict(dtype=torch.float32, device=dev)
         assert cs.din == coma_critic_input_dim(b.Do, b.Ds, A, K), (cs.din, b.Do, b.Ds, A, K)
-        self.cin = torch.empty(E, A, T, cs.din, **f32)        # Critic.coma_inputs rows
         self.q = torch.empty(E, A, T, K, **f32)
         self.logits = torch.empty(E, A, T, K, **f32)
         self.qtaken = torch.empty(E, A, T, **f32)
         self.scratch = torch.empty(E, A, T, **f32)            # the scan's unused advantage output
         self.tstats = torch.zeros(T, 4, dtype=torch.float64, device=dev)
         rows = E * A * T
-        need = max(lib.cm_mlp_split_workspace_bytes(rows, cs.din, cs.hidden, cs.n_layers, K),
+        need = max(lib.cm_coma_critic_workspace_bytes(E, A, T, b.Ds, b.Do, K, cs.hidden, cs.n_layers, 1),
                    lib.cm_mlp_split_workspace_bytes(rows, a.din, a.hidden, a.n_layers, K),
                    lib.cm_coma_advantage_workspace_bytes(E, A, T), lib.cm_masked_moments_workspace_bytes(E, A, T))
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -99,9 +98,11 @@ class COMALearner:
                                                 N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
 
     def _q(self, params, avail, out, b, s):
+        """Q[E,A,T,K] of Critic(state, obs, actions) without materialising coma_inputs (factored layer 0, csrc/cm_coma.hip)."""
         cs = self.critic_spec
-        N.check(self.lib.cm_mlp_forward(N.ptr(self.cin), b.E * b.A * b.T, cs.din, cs.hidden, cs.n_layers, b.K, N.ptr(params),
-                                        N.ptr(avail) if avail is not None else None, N.ptr(out), s), "cm_mlp_forward")
+        N.check(self.lib.cm_coma_q_forward(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(avail) if avail is not None else None,
+                                           b.E, b.A, b.T, b.Ds, b.Do, b.K, cs.hidden, cs.n_layers, N.ptr(params), N.ptr(out),
+                                           N.ptr(self.ws), self.ws.numel(), s), "cm_coma_q_forward")
 
     # ------------------------------------------------------------------ :553-618
     def compute_targets(self, b):
@@ -111,8 +112,6 @@ class COMALearner:
         if hp.normalize_reward:  # RolloutBuffer.get_batch, :151-154
             self._moments(b.reward, b.ep_len, E, 1, T, s)
             N.check(lib.cm_normalize(N.ptr(b.reward), N.ptr(b.ep_len), E, 1, T, N.ptr(self.moments), 1e-6, 1, s), "cm_normalize")
-        N.check(lib.cm_coma_build_inputs(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), E, A, T, b.Ds, b.Do, K, N.ptr(self.cin), s),
-                "cm_coma_build_inputs")
         self._q(self.target, b.avail, self.q, b, s)                                 # target critic, masked (:565-570)
         N.check(lib.cm_gather_taken(N.ptr(self.q), N.ptr(b.action), E * A * T, K, N.ptr(self.qtaken), s), "cm_gather_taken")
         if hp.use_tdlamda:
@@ -133,9 +132,9 @@ class COMALearner:
         cs, a = self.critic_spec, self.actor_spec
         Pa, Pc = self.actor.numel(), self.critic.numel()
         # ---- critic step
-        N.check(lib.cm_qcritic_fwd_bwd(N.ptr(self.cin), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, cs.din, cs.hidden,
-                                       cs.n_layers, K, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws), self.ws.numel(), s),
-                "cm_qcritic_fwd_bwd")
+        N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, b.Ds,
+                                           b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws),
+                                           self.ws.numel(), s), "cm_coma_critic_fwd_bwd")
         dist.allreduce_sum_(self.g_critic, self.pg, self.world)
         self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
         self.training_step += 1

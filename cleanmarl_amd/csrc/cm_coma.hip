@@ -128,6 +128,208 @@ __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, cons
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) target[i] = tau * src[i] + keep * target[i];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Factored critic input.  The reference materialises x = [state | obs | one-hot(other agents' actions)] per (e, a, t)
+// (coma_multienvs.py:222-240; 475 floats per row at config-3 shapes, 8 GB per batch) and multiplies it by W0.  The state
+// block is the same for the A agents of a step and the action block is one-hot, so
+//     W0 x + b0 = W0o obs[e,a,t] + ( W0s state[e,t] + sum_{j != a} W0a[:, slot(j) K + u_j] ) + b0
+// : the fused MLP kernel runs on the OBS block only (din = Do) with a per-row addend z0_add[rows][64] =
+// S[e,t] + gathered columns, where S = state W0s^T is one [E T x Ds] x [Ds x 64] GEMM (A times fewer rows).
+// Backward: dW0o falls out of the fused kernel; one pass over dZ0[rows][64] yields dS = sum_a dZ0 (then dW0s = dS^T state,
+// a streaming MFMA GEMM, k_dw0_stream) and the action block dW0a by prefix-sum gather-adds (k_coma_bwd_gather).  ~7x fewer layer-0 FLOPs and no 8 GB tensor.
+// ------------------------------------------------------------------------------------------------------------------
+
+// pc = [W0o (H x Do) | everything after W0 (b0, hidden layers, head)] from the torch-order buffer [W0 (H x Dc) | ...]
+__global__ __launch_bounds__(256) void k_coma_compact_params(const float* __restrict__ full, int H, int Dc, int Ds, int Do, int rest,
+                                                             float* __restrict__ pc) {
+    const int n = H * Do + rest;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (i < H * Do) { const int h = i / Do, c = i - h * Do; pc[i] = full[h * Dc + Ds + c]; }
+        else pc[i] = full[H * Dc + (i - H * Do)];
+    }
+}
+
+// out[rows][HP] = X[rows][ncols] * W[H][ncols]^T (W row stride w_stride); columns >= H are zero
+__global__ __launch_bounds__(NTHREADS, 2) void k_linear_nt(const float* __restrict__ x, long rows, long x_stride, int ncols,
+                                                           const float* __restrict__ W, long w_stride, int H, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float Xs[TM * LDT];
+    __shared__ __attribute__((aligned(16))) float Wsm[HP * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const long ntiles = (rows + TM - 1) / TM;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * TM;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+        for (int c0 = 0; c0 < ncols; c0 += KC) {
+            __syncthreads();
+            stage_rows(Xs, x, row0, rows, x_stride, c0, min(KC, ncols - c0));
+            stage_rows(Wsm, W, 0, H, w_stride, c0, min(KC, ncols - c0));
+            __syncthreads();
+            rowpar_nt(acc, Xs + 32 * wm * LDT, Wsm + 32 * wn * LDT, KC / 8);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const long row = row0 + 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (row < rows) out[row * HP + 32 * wn + lc] = acc[g];
+        }
+    }
+}
+
+// z0_add[(e,a,t)][h] = S[e,t][h] + sum_{j != a} W0a[h][slot(j,a) K + u_j].  One wave per (e,t), lane = hidden unit: the A
+// actions of the step are fetched once (lane j holds u_j, broadcast by readlane), S once, then the A rows are produced from
+// the transposed action block of W0 in LDS ([(A-1)K][64], conflict-free across lanes).
+__global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S, const int* __restrict__ action,
+                                                     const float* __restrict__ W0, int E, int A, int T, int H, int Dc, int Ds, int Do,
+                                                     int K, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const int Da = (A - 1) * K;
+    for (int i = threadIdx.x; i < Da * HP; i += 256) {
+        const int c = i / HP, hh = i - c * HP;
+        tab[i] = hh < H ? W0[(long)hh * Dc + Ds + Do + c] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long net = (long)E * T;
+    for (long et = (long)blockIdx.x * 4 + w; et < net; et += (long)gridDim.x * 4) {
+        const long e = et / T;
+        const int t = (int)(et - e * T);
+        const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
+        const float sv = S[et * HP + lane];
+        for (int a = 0; a < A; ++a) {
+            float v = sv;
+            for (int slot = 0; slot < A - 1; ++slot) {
+                const int j = slot < a ? slot : slot + 1;
+                v += tab[(slot * K + __shfl(u, j, 64)) * HP + lane];
+            }
+            out[((e * A + a) * T + t) * HP + lane] = v;
+        }
+    }
+}
+
+// Backward of the factored input, one wave per (e,t), lane = hidden unit:
+//   dS[e,t][h]  = sum_a dZ0[e,a,t][h]                                   (feeds dW0s = dS^T state)
+//   dW0a[h][c] += dZ0[e,a,t][h] for every (a, j != a) with c = slot(j,a) K + u_j.  Agent j's action lands in column block
+//   j-1 for the agents a < j and in block j for the agents a > j, so with prefix sums over a this is 2 adds per j:
+//       tab[(j-1) K + u_j] += sum_{a<j} dZ0[e,a,t]     tab[j K + u_j] += sum_{a>j} dZ0[e,a,t]
+//   accumulated in a PRIVATE per-wave LDS table (fixed (e,t) -> wave assignment, sequential adds: deterministic), written as
+//   per-wave partials [nwaves][Da][HP] and reduced in a fixed order by k_reduce_partials.
+constexpr int OH_MAXA = 32;
+constexpr int OH_NWAVES = 8192;  // upper bound of gather waves (= partial tables)
+__global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict__ dz0, const int* __restrict__ action, int E, int A, int T,
+                                                         int K, int waves_per_block, float* __restrict__ dS, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const int Da = (A - 1) * K;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool active = w < waves_per_block;
+    float* mine = tab + (size_t)(active ? w : 0) * Da * HP;
+    if (active)
+        for (int i = lane; i < Da * HP; i += 64) mine[i] = 0.0f;
+    const long net = (long)E * T;
+    const long nw = (long)gridDim.x * waves_per_block;
+    if (active) {
+        for (long et = (long)blockIdx.x * waves_per_block + w; et < net; et += nw) {
+            const long e = et / T;
+            const int t = (int)(et - e * T);
+            const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
+            float z[OH_MAXA];
+            float tot = 0.0f;
+#pragma unroll
+            for (int a = 0; a < OH_MAXA; ++a) {
+                z[a] = 0.0f;
+                if (a < A) { z[a] = dz0[((e * A + a) * T + t) * HP + lane]; tot += z[a]; }
+            }
+            dS[et * HP + lane] = tot;
+            float pre = 0.0f;  // sum_{a<j}
+#pragma unroll
+            for (int j = 0; j < OH_MAXA; ++j) {
+                if (j < A) {
+                    const int uj = __shfl(u, j, 64);
+                    if (j > 0) mine[((j - 1) * K + uj) * HP + lane] += pre;
+                    const float suf = tot - pre - z[j];  // sum_{a>j}
+                    if (j < A - 1) mine[(j * K + uj) * HP + lane] += suf;
+                    pre += z[j];
+                }
+            }
+        }
+        float* o = part + ((size_t)blockIdx.x * waves_per_block + w) * Da * HP;
+        for (int i = lane; i < Da * HP; i += 64) o[i] = mine[i];
+    }
+}
+
+// ga[h][c] = reduced[c][h] (H x Da, torch order) from the [Da][HP] layout of the gather kernel
+__global__ __launch_bounds__(256) void k_transpose_ga(const float* __restrict__ red, int H, int Da, float* __restrict__ ga) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * Da; i += gridDim.x * 256) {
+        const int hh = i / Da, c = i - hh * Da;
+        ga[i] = red[c * HP + hh];
+    }
+}
+
+// full-layout gradient + stats from the pieces: W0 = [gs (H x Ds) | gc's W0o (H x Do) | ga (H x Da)], rest (+ 8 stats) from gc
+__global__ __launch_bounds__(256) void k_coma_scatter_grads(const float* __restrict__ gc, const float* __restrict__ gs,
+                                                            const float* __restrict__ ga, int H, int Dc, int Ds, int Do, int rest,
+                                                            float* __restrict__ out) {
+    const int Da = Dc - Ds - Do;
+    const int n = H * Dc + rest;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float v;
+        if (i < H * Dc) {
+            const int hh = i / Dc, c = i - hh * Dc;
+            v = c < Ds ? gs[hh * Ds + c] : (c < Ds + Do ? gc[hh * Do + (c - Ds)] : ga[hh * Da + (c - Ds - Do)]);
+        } else v = gc[H * Do + (i - H * Dc)];
+        out[i] = v;
+    }
+}
+
+struct ComaWs {  // float offsets into the caller's workspace
+    size_t pc, S, z0, dz0, dS, gc, gs, ga, part, train, total;
+};
+inline size_t al64(size_t x) { return (x + 63) & ~(size_t)63; }
+inline ComaWs coma_ws(int E, int A, int T, int Ds, int Do, int K, int H, int L, bool train) {
+    const long rows = (long)E * A * T, et = (long)E * T;
+    const int Da = (A - 1) * K;
+    const size_t Pc = (size_t)cm_mlp_param_count(Do, H, L, K);
+    ComaWs w; size_t p = 0;
+    w.pc = p; p += al64(Pc);
+    w.S = p; p += al64((size_t)et * HP);
+    w.z0 = p; p += al64((size_t)rows * HP);
+    w.dz0 = w.dS = w.gc = w.gs = w.ga = w.part = w.train = p;
+    if (train) {
+        w.dz0 = p; p += al64((size_t)rows * HP);
+        w.dS = p; p += al64((size_t)et * HP);
+        w.gc = p; p += al64(Pc + CM_NUM_STATS);
+        w.gs = p; p += al64((size_t)H * Ds);
+        w.ga = p; p += al64((size_t)H * (Da > 0 ? Da : 1));
+        w.part = p; p += al64(stream_dw_ws_floats(H, Ds) > (size_t)(OH_NWAVES + 1) * (Da > 0 ? Da : 1) * HP ? stream_dw_ws_floats(H, Ds)
+                                                                                              : (size_t)(OH_NWAVES + 1) * (Da > 0 ? Da : 1) * HP);
+        w.train = p; p += al64(split_ws_bytes(rows, Do, H, L, K) / sizeof(float) + 1);
+    }
+    w.total = p;
+    return w;
+}
+
+// steps a-c shared by the forward and the training entry points: compact params, S, z0_add
+inline int coma_prepare(const float* state, const float* obs, const int32_t* action, int E, int A, int T, int Ds, int Do, int K, int H,
+                        int L, const float* params, float* wsf, const ComaWs& w, hipStream_t s, const char* who) {
+    (void)obs;
+    const int Dc = Ds + Do + (A - 1) * K;
+    const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc);
+    hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
+    CM_CHECK_LAUNCH(who);
+    const long et = (long)E * T;
+    const long nt = (et + TM - 1) / TM;
+    hipLaunchKernelGGL(k_linear_nt, dim3((int)(nt < 512 ? nt : 512)), dim3(NTHREADS), 0, s, state, et, (long)Ds, Ds, params, (long)Dc, H, wsf + w.S);
+    CM_CHECK_LAUNCH(who);
+    const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
+    CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
+    CM_REQUIRE(A <= 64, "%s: n_agents=%d > 64 is not supported by the factored critic input", who, A);
+    const long g = (et + 3) / 4;
+    hipLaunchKernelGGL(k_coma_z0_add, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E, A, T, H,
+                       Dc, Ds, Do, K, wsf + w.z0);
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+
 inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 }  // namespace
@@ -221,4 +423,80 @@ extern "C" int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, con
     a.params = params; a.avail = avail; a.avail_stride = n_actions; a.action = action; a.adv = adv; a.ep_len = ep_len;
     a.A = A; a.T = T; a.per_agent = 1; a.ent_coef = (float)entropy_coef;
     return run_train<M_COMA_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_coma_actor_fwd_bwd");
+}
+
+extern "C" size_t cm_coma_critic_workspace_bytes(int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
+                                                 int train) {
+    return coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, train != 0).total * sizeof(float);
+}
+
+extern "C" int cm_coma_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
+                                 int Ds, int Do, int n_actions, int hidden, int n_hidden_layers, const float* params, float* q, void* ws,
+                                 size_t ws_bytes, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_coma_q_forward", Do, hidden, n_hidden_layers, n_actions)) return rc;
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_q_forward: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    const ComaWs w = coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, false);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "cm_coma_q_forward: workspace too small (%zu < %zu)", ws_bytes, w.total * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, wsf, w, s, "cm_coma_q_forward")) return rc;
+    MlpArgs a = {};
+    a.x = obs; a.x_stride = Do; a.rows = (long)E * A * T; a.din = Do; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = wsf + w.pc; a.avail = avail; a.avail_stride = n_actions; a.y = q; a.z0_add = wsf + w.z0;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    launch_infer<M_FWD>(a, grid_for(a.rows), lds_bytes, s);
+    CM_CHECK_LAUNCH("cm_coma_q_forward");
+    return 0;
+}
+
+extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, const int32_t* action, const float* target,
+                                      const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
+                                      int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                      cm_stream_t stream) {
+    const char* who = "cm_coma_critic_fwd_bwd";
+    if (int rc = check_shapes(who, Do, hidden, n_hidden_layers, n_actions)) return rc;
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_critic_fwd_bwd: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    const long rows = (long)E * A * T;
+    if (int rc = check_rows(who, rows)) return rc;
+    const ComaWs w = coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, true);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "cm_coma_critic_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    const int K = n_actions, H = hidden, Da = (A - 1) * K, Dc = Ds + Do + Da;
+    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, K, H, n_hidden_layers, params, wsf, w, s, who)) return rc;
+    MlpArgs a = {};
+    a.x = obs; a.x_stride = Do; a.rows = rows; a.din = Do; a.H = H; a.L = n_hidden_layers; a.dout = K;
+    a.params = wsf + w.pc; a.action = action; a.ret = target; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
+    a.z0_add = wsf + w.z0; a.dz0 = wsf + w.dz0;
+    if (int rc = run_train<M_QCRITIC>(a, wsf + w.gc, wsf + w.train, (w.total - w.train) * sizeof(float), s, who)) return rc;
+    // one pass over dZ0: dS = sum_a dZ0 and the action block dW0a (per-wave LDS tables -> partials -> fixed-order reduce)
+    const long et = (long)E * T;
+    CM_REQUIRE(A <= OH_MAXA, "%s: n_agents=%d > %d is not supported by the factored critic input", who, A, OH_MAXA);
+    {
+        const int DaP = Da > 0 ? Da : 1;
+        const size_t per_wave = (size_t)DaP * HP * sizeof(float);
+        CM_REQUIRE(per_wave <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the LDS table", who, Da);
+        int wpb = (int)((64 * 1024) / per_wave);  // waves (= private tables) per block within 64 KB of LDS
+        wpb = wpb > 4 ? 4 : wpb;
+        long blocks = (et + wpb - 1) / wpb;
+        const long cap = OH_NWAVES / wpb;
+        if (blocks > cap) blocks = cap;
+        float* gpart = wsf + w.part;                       // [blocks * wpb][Da][HP]
+        float* gred = gpart + (size_t)blocks * wpb * DaP * HP;  // [Da][HP]
+        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart);
+        CM_CHECK_LAUNCH(who);
+        if (Da > 0) {
+            const int n = Da * HP;
+            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks * wpb), n, 0, n, gred);
+            CM_CHECK_LAUNCH(who);
+            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, H, Da, wsf + w.ga);
+            CM_CHECK_LAUNCH(who);
+        }
+    }
+    // state block: dW0s = dS^T state
+    if (int rc = stream_dw(wsf + w.dS, state, et, Ds, H, wsf + w.part, wsf + w.gs, s, who)) return rc;
+    const int rest = (int)(cm_mlp_param_count(Dc, H, n_hidden_layers, K) - (int64_t)H * Dc) + CM_NUM_STATS;
+    hipLaunchKernelGGL(k_coma_scatter_grads, dim3(128), dim3(256), 0, s, wsf + w.gc, wsf + w.gs, wsf + w.ga, H, Dc, Ds, Do, rest, grad_and_stats);
+    CM_CHECK_LAUNCH(who);
+    return 0;
 }

@@ -52,6 +52,7 @@ struct MlpArgs {
     const uint8_t* avail; long avail_stride; float* y;
     // M_ACT
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+    const float* z0_add;  // M_FWD / M_QCRITIC: optional [rows][HP] addend of the layer-0 pre-activation (COMA's factored critic input)
     float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_policy_act_eps)
     int t_decode;  // > 0: rows are (sequence, t) pairs with t = row % t_decode (whole-episode act pass), else a.t
     // training
@@ -423,6 +424,17 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         ri.act = 0; ri.lpo = 0.f; ri.adv = 0.f; ri.ret = 0.f; ri.eplen = 0; ri.ag = 0; ri.e = 0; ri.t = 0;
 #pragma unroll
         for (int j = 0; j < KJ; ++j) ri.avb[j] = 1;
+        // COMA's factored critic input: the layer-0 addend of this tile, requested now, consumed in the layer-0 epilogue
+        constexpr bool ADD_OK = (MODE == M_FWD || MODE == M_QCRITIC);
+        float zadd[ADD_OK ? 16 : 1];
+        const bool has_add = ADD_OK && a.z0_add != nullptr;
+        if (ADD_OK) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long row = row0 + 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                zadd[g] = (has_add && row < a.rows) ? a.z0_add[row * HP + 32 * wn + lc] : 0.0f;
+            }
+        }
         const int grow = (int)row0 + hrow;  // this lane-group's global row (host guarantees rows < 2^31)
         const bool rvalid = grow < (int)a.rows;
         for (int c = 0; c < nch; ++c) {
@@ -472,7 +484,9 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
-                H0[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                float z = acc[g] + bias;
+                if (ADD_OK) z += zadd[g];
+                H0[row * LDT + 32 * wn + lc] = fmaxf(z, 0.0f);
             }
         }
         __syncthreads();
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     for (int r = 0; r < TM / 4; ++r) s += Z0[(part * (TM / 4) + r) * LDT + c];
                     dbh[0] += s;
                 }
-                if (NCH == 0) {  // external layer-0 weight gradient: hand dZ0 to k_dw0_stream (coalesced 16-byte stores)
+                if (NCH == 0 || (MODE == M_QCRITIC && a.dz0 != nullptr)) {  // external layer-0 weight gradient: hand dZ0 to k_dw0_stream (coalesced 16-byte stores)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int idx = tid + NTHREADS * i;

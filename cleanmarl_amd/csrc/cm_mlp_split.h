@@ -81,6 +81,28 @@ constexpr int DW0_GRID = 512;
 
 inline bool use_split(int din) { return (din + KC - 1) / KC > CM_WG2_MAX_NCH; }
 
+// dW[H x din] = dz0[rows][HP]^T X[rows][din]: per-workgroup partials -> out[H * din]
+inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H, float* part2, float* out, hipStream_t s, const char* who) {
+    long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
+    rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
+    const int grid2 = (int)((rows + rpw - 1) / rpw);
+    const int PS2 = H * din;
+    for (int col0 = 0; col0 < din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
+        const int nkt = (min(512, din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
+        switch (ktw) {
+            case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
+            case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
+            case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
+            default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
+        }
+    }
+    CM_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((PS2 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part2, grid2, PS2, 0, PS2, out);
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+inline size_t stream_dw_ws_floats(int H, int din) { return (size_t)DW0_GRID * H * din; }
+
 inline size_t split_ws_bytes(long rows, int din, int hidden, int L, int dout) {
     size_t b = train_ws_bytes(din, hidden, L, dout);
     if (use_split(din)) b += ((size_t)rows * HP + (size_t)DW0_GRID * hidden * din) * sizeof(float);
@@ -106,30 +128,15 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
         return finish_train(a, grid, P, grad_and_stats, s, who);
     }
     // ---- split schedule: fused kernel without dW0 (two workgroups per CU) ...
-    a.dz0 = (float*)ws + (size_t)MAX_GRID * a.PS;
-    float* part2 = a.dz0 + (size_t)a.rows * HP;
+    float* own = (float*)ws + (size_t)MAX_GRID * a.PS;
+    if (!a.dz0) a.dz0 = own;  // the caller may want dZ0 for its own use (COMA's factored critic input)
+    float* part2 = own + (size_t)a.rows * HP;
     const int grid = grid_for(a.rows, 0);
     launch_variant<0, MODE>(a, grid, lds_bytes, s);
     CM_CHECK_LAUNCH(who);
     if (int rc = finish_train(a, grid, P, grad_and_stats, s, who, a.H * a.din)) return rc;  // all but W0
     // ---- ... then the streaming layer-0 weight gradient
-    long rpw = (a.rows + DW0_GRID - 1) / DW0_GRID;
-    rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
-    const int grid2 = (int)((a.rows + rpw - 1) / rpw);
-    const int PS2 = a.H * a.din;
-    for (int col0 = 0; col0 < a.din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
-        const int nkt = (min(512, a.din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
-        switch (ktw) {
-            case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, a.x, a.rows, a.din, a.H, rpw, part2, PS2, col0); break;
-            case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, a.x, a.rows, a.din, a.H, rpw, part2, PS2, col0); break;
-            case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, a.x, a.rows, a.din, a.H, rpw, part2, PS2, col0); break;
-            default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, a.dz0, a.x, a.rows, a.din, a.H, rpw, part2, PS2, col0); break;
-        }
-    }
-    CM_CHECK_LAUNCH(who);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((PS2 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part2, grid2, PS2, 0, PS2, grad_and_stats);
-    CM_CHECK_LAUNCH(who);
-    return 0;
+    return stream_dw(a.dz0, a.x, a.rows, a.din, a.H, part2, grad_and_stats, s, who);
 }
 
 }  // namespace

@@ -23,6 +23,7 @@ struct RolloutArgs {
     float* env_state;  // [E][6A]: pos(2A) vel(2A) landmarks(2A) -- written at the end (state after step T-1)
     int E, A, T, agent_ids;
     unsigned long long seed, act_seed;
+    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_rollout_spread_eps)
     long env_offset, episode;
     const float* params; int din, H, L, K;
     float* obs; float* state; int* action; float* logp; float* reward;
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 const long e = e0 + el;
                 if (e < a.E) {
                     int chosen; float lpv;
-                    cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
+                    if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + tid * 8, K, u_row, a.act_eps, &chosen, &lpv);
+                    else cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
                     const long o = (e * A + i) * (long)T + t;
                     a.action[o] = chosen;
                     a.logp[o] = lpv;
@@ -297,14 +299,14 @@ extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int
     return (A >= 1 && din <= KC && hidden <= HP && n_hidden_layers <= 1) ? 1 : 0;
 }
 
-extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
-                                 int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
-                                 float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                          int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, float eps,
+                          float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
     CM_REQUIRE(E > 0 && T > 0, "cm_rollout_spread: bad dims E=%d T=%d", E, T);
     CM_REQUIRE(cm_rollout_spread_supported(A, agent_ids, hidden, n_hidden_layers),
                "cm_rollout_spread: unsupported shape A=%d hidden=%d layers=%d (use cm_policy_act + cm_synth_env_step)", A, hidden, n_hidden_layers);
     RolloutArgs a = {};
-    a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed;
+    a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed; a.act_eps = eps;
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0);
     a.H = hidden; a.L = n_hidden_layers; a.K = 5;
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
@@ -320,4 +322,21 @@ extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agen
     hipLaunchKernelGGL(k_rollout_spread, dim3(grid), dim3(NTHREADS), lds_bytes, (hipStream_t)stream, a);
     CM_CHECK_LAUNCH("cm_rollout_spread");
     return 0;
+}
+
+extern "C" int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                 int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
+                                 float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+    return rollout_spread(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, n_hidden_layers, 0.0f, obs,
+                          state, action, logp, reward, stream);
+}
+
+/* the same fused rollout with COMA's epsilon-mixed policy (coma_multienvs.py:177-186, 477-484) */
+extern "C" int cm_rollout_spread_eps(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                     int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
+                                     double eps, float* obs, float* state, int32_t* action, float* logp, float* reward,
+                                     cm_stream_t stream) {
+    CM_REQUIRE(eps >= 0.0 && eps <= 1.0, "cm_rollout_spread_eps: eps=%g outside [0, 1]", eps);
+    return rollout_spread(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, n_hidden_layers, (float)eps,
+                          obs, state, action, logp, reward, stream);
 }

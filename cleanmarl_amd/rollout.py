@@ -41,18 +41,22 @@ class SyntheticSpreadRollout:
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         can_fuse = actor_spec.kind == "mlp" and bool(lib.cm_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden,
                                                                                  actor_spec.n_layers))
-        if eps > 0.0:  # COMA's epsilon-mixed exploration (coma_multienvs.py:477-484): per-step launches
-            fused = False
         if fused is None:
             fused = can_fuse
         if fused:
             if not can_fuse:
                 raise N.NativeError("fused rollout requested for an unsupported shape")
             act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
-            N.check(lib.cm_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
-                                          self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
-                                          actor_spec.n_layers, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action), N.ptr(b.logp),
-                                          N.ptr(b.reward), s), "cm_rollout_spread")
+            if eps > 0.0:  # COMA's epsilon-mixed exploration (coma_multienvs.py:477-484)
+                N.check(lib.cm_rollout_spread_eps(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
+                                                  self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
+                                                  actor_spec.n_layers, float(eps), N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action),
+                                                  N.ptr(b.logp), N.ptr(b.reward), s), "cm_rollout_spread_eps")
+            else:
+                N.check(lib.cm_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
+                                              self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
+                                              actor_spec.n_layers, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action), N.ptr(b.logp),
+                                              N.ptr(b.reward), s), "cm_rollout_spread")
             self.episode += 1
             return b
         N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,

@@ -200,6 +200,10 @@ int cm_policy_act_eps(const float* x, int64_t x_row_stride, const uint8_t* avail
                       int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
                       const float* params, double eps, uint64_t seed, int64_t row_offset, int t,
                       int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
+/* cm_rollout_spread with the epsilon-mixed policy (whole COMA rollout of the synthetic env in one persistent launch). */
+int cm_rollout_spread_eps(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                          int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
+                          double eps, float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
 /* Critic.coma_inputs (coma_multienvs.py:222-240): out [E][A][T][Ds + Do + (A-1)K] = state | own obs | one-hot actions of
  * the other agents in agent order.  The Q network itself is cm_mlp_forward on these rows (dout = K; pass avail to get
  * the masked_fill(~avail, -1e9) of the TARGET-critic calls at :565-570 / :590-595). */
@@ -235,6 +239,19 @@ int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t*
                           const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                           const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
                           cm_stream_t stream);
+/* The same Q network WITHOUT materialising the critic input: W0 x = W0o obs + (W0s state[e,t] + gathered action columns),
+ * so the fused kernel runs on the obs block with a per-row addend and the state / action blocks of dW0 come from two
+ * streaming GEMMs over dZ0 (see csrc/cm_coma.hip).  params / grad_and_stats use the torch parameter order of
+ * Critic(input_dim = Ds + Do + (A-1)K) (coma_multienvs.py:194-208), exactly like cm_mlp_forward / cm_qcritic_fwd_bwd. */
+size_t cm_coma_critic_workspace_bytes(int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
+                                      int train);
+int cm_coma_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
+                      int Ds, int Do, int n_actions, int hidden, int n_hidden_layers, const float* params, float* q, void* ws,
+                      size_t ws_bytes, cm_stream_t stream);
+int cm_coma_critic_fwd_bwd(const float* state, const float* obs, const int32_t* action, const float* target,
+                           const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
+                           int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                           cm_stream_t stream);
 /* soft_update (coma_multienvs.py:266-270): target = polyak * src + (1 - polyak) * target. */
 int cm_polyak_update(float* target, const float* src, int64_t n, double polyak, cm_stream_t stream);
 

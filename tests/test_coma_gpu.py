@@ -190,3 +190,48 @@ def test_coma_default_critic_width_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     with pytest.raises(N.NativeError, match="hidden_dim=128"):
         run("coma_multienvs", ["--env_type=synthetic", "--batch_size=2", "--synthetic_steps=5", "--total_timesteps=10"])
+
+
+@pytest.mark.parametrize("E,A,T,Do,Ds,K,H,L", [(9, 3, 11, 10, 14, 5, 64, 1), (6, 5, 9, 40, 200, 12, 48, 2), (40, 8, 16, 56, 384, 5, 64, 1),
+                                                  (5, 1, 7, 12, 12, 4, 32, 0), (4, 10, 6, 115, 243, 17, 64, 1)])
+def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
+    """cm_coma_q_forward / cm_coma_critic_fwd_bwd (W0 x = W0o obs + state GEMM + gathered action columns) vs the literal
+    path cm_coma_build_inputs -> cm_mlp_forward / cm_qcritic_fwd_bwd, and vs oracle/coma.py."""
+    from oracle import coma as C
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import DeviceBatch, flatten_params
+    lib, dev = N.load(), torch.device("cuda:0")
+    batch, _, cp, _ = _seeded(E + 3 * K, E, A, T, Do, Ds, K, 32, H, 1, L)
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), batch["reward"],
+                                          batch["states"], batch["avail"], batch["mask"], dev)
+    p = flatten_params(cp, dev)
+    Dc, rows, s = Ds + Do + (A - 1) * K, E * A * T, N.stream_ptr()
+    cin = torch.empty(E, A, T, Dc, device=dev)
+    N.check(lib.cm_coma_build_inputs(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), E, A, T, Ds, Do, K, N.ptr(cin), s), "build")
+    q_lit, q_fac = torch.empty(E, A, T, K, device=dev), torch.empty(E, A, T, K, device=dev)
+    ws = torch.empty(max(lib.cm_coma_critic_workspace_bytes(E, A, T, Ds, Do, K, H, L, 1),
+                         lib.cm_mlp_split_workspace_bytes(rows, Dc, H, L, K)), dtype=torch.uint8, device=dev)
+    for avail in (None, b.avail):
+        N.check(lib.cm_mlp_forward(N.ptr(cin), rows, Dc, H, L, K, N.ptr(p), N.ptr(avail) if avail is not None else None, N.ptr(q_lit), s), "fwd")
+        N.check(lib.cm_coma_q_forward(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(avail) if avail is not None else None, E, A, T,
+                                      Ds, Do, K, H, L, N.ptr(p), N.ptr(q_fac), N.ptr(ws), ws.numel(), s), "qfwd")
+        ref = C.q_values(cp, batch, K, batch["avail"] if avail is not None else None).permute(0, 2, 1, 3)
+        m = batch["mask"][:, None, :, None].numpy()
+        assert _err(q_fac.cpu().numpy() * m, ref.numpy() * m) <= TOL
+        assert _err(q_fac.cpu().numpy(), q_lit.cpu().numpy()) <= TOL
+    target = torch.randn(E, A, T, device=dev)
+    P = p.numel()
+    g_lit, g_fac = torch.zeros(P + 8, device=dev), torch.zeros(P + 8, device=dev)
+    N.check(lib.cm_qcritic_fwd_bwd(N.ptr(cin), N.ptr(b.action), N.ptr(target), N.ptr(b.ep_len), E, A, T, Dc, H, L, K, N.ptr(p),
+                                   N.ptr(g_lit), N.ptr(ws), ws.numel(), s), "lit")
+    N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(target), N.ptr(b.ep_len), E, A, T, Ds, Do, K,
+                                       H, L, N.ptr(p), N.ptr(g_fac), N.ptr(ws), ws.numel(), s), "fac")
+    cpr = [x.clone().requires_grad_(True) for x in cp]
+    loss = C.critic_loss_sum(cpr, batch, target.permute(0, 2, 1).cpu(), K)
+    gref = R.flat(torch.autograd.grad(loss, cpr)).numpy()
+    scale = 1.0 + np.abs(gref).max()
+    assert np.abs(g_fac[:P].cpu().numpy() - gref).max() / scale <= TOL
+    assert np.abs(g_lit[:P].cpu().numpy() - gref).max() / scale <= TOL
+    assert _err(g_fac[P:].cpu().numpy(), g_lit[P:].cpu().numpy()) <= TOL
+    assert abs(float(g_fac[P + N.STAT_VLOSS]) - float(loss)) <= TOL * (1 + abs(float(loss)))
