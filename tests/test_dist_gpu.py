@@ -108,3 +108,50 @@ def test_bench_two_rank_launch_on_one_gpu():
     assert out["value"] > 0 and abs(out["value"] - 2 * 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert out["roofline"]["frac"] > 0
+
+
+def _coma_worker(rank, world, port, gold, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import coma as C
+    from cleanmarl_amd import dist
+    from cleanmarl_amd.coma_learner import COMAHParams, COMALearner
+    from cleanmarl_amd.learner import DeviceBatch, NetSpec
+    batch, ap, cp, hp, z = C.load_golden(gold)
+    dev = torch.device("cuda:0")
+    lo, n = dist.shard(batch["obs"].shape[0], rank, world)
+    sl = slice(lo, lo + n)
+    b = DeviceBatch.from_reference_layout(batch["obs"][sl], batch["actions"][sl], torch.zeros(batch["actions"][sl].shape), batch["reward"][sl],
+                                          batch["states"][sl], batch["avail"][sl], batch["mask"][sl], dev)
+    H = COMAHParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=False, normalize_advantage=bool(hp["normalize_advantage"]),
+                    normalize_return=bool(hp["normalize_return"]), target_network_update_freq=int(hp["target_network_update_freq"]),
+                    polyak=hp["polyak"], entropy_coef=hp["entropy_coef"], use_tdlamda=bool(hp["use_tdlamda"]), nsteps=int(hp["nsteps"]),
+                    clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], learning_rate_actor=hp["learning_rate_actor"],
+                    learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, cp[-1].shape[0])
+    L = COMALearner(aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
+                    process_group=torch.distributed.group.WORLD, world_size=world)
+    rec = L.train_iteration(b)
+    torch.save(dict(rec=rec, actor=L.actor.cpu(), critic=L.critic.cpu(), target=L.target.cpu()), f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_single_process_coma_reference(golden_dir, tmp_path):
+    """COMA: per-time-step advantage moments and the return normalisation need cross-rank sums; two env shards must land on
+    the unmodified single-process coma_multienvs.py result (tests/golden/coma_tdlambda.npz: ragged, normalisations on, clip)."""
+    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+    gold = os.path.join(golden_dir, "coma_tdlambda.npz")
+    mp.spawn(_coma_worker, args=(world, port, gold, out), nprocs=world, join=True)
+    z = np.load(gold)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    for g in got:
+        assert _err(g["rec"]["critic_loss"], float(z["cr_loss"])) <= TOL and _err(g["rec"]["actor_loss"], float(z["ac_loss"])) <= TOL
+        assert _err(g["rec"]["entropy"], float(z["entropies"])) <= TOL
+        assert _err(g["rec"]["critic_gnorm"], float(z["critic_gradients"])) <= TOL
+        assert _err(g["rec"]["actor_gnorm"], float(z["actor_gradients"])) <= TOL
+        assert _err(g["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(g["actor"].numpy(), z["actor_after"][0]) <= TOL
+        assert _err(g["target"].numpy(), z["target_after"]) <= 1e-6
+    assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
