@@ -15,7 +15,7 @@ root = sys.argv[1]
 
 def agg(sub, counter):
     d = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(root, sub, "*_counter_collection.csv")):
+    for path in glob.glob(os.path.join(root, sub, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
