@@ -78,6 +78,17 @@ __device__ __forceinline__ void cm_categorical_sample(const float* z, int K, flo
     *logp = z[chosen] - (m + logf(s));
 }
 
+// greedy evaluation (build option --greedy_eval; the reference always samples): first maximal available logit
+__device__ __forceinline__ void cm_categorical_greedy(const float* z, int K, int* action, float* logp) {
+    float m = -INFINITY;
+    int best = 0;
+    for (int k = 0; k < K; ++k) if (z[k] > m) { m = z[k]; best = k; }
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+    *action = best;
+    *logp = -logf(s);
+}
+
 // COMA exploration (cleanmarl/coma_multienvs.py:177-186): probs = (1 - eps) * softmax(z) + eps * avail / n_avail, inverse CDF
 // over the available actions in index order; *logp = log(probs[action]).
 __device__ __forceinline__ void cm_categorical_sample_eps(const float* z, int K, float u, float eps, int* action, float* logp) {

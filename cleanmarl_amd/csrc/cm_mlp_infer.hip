@@ -49,6 +49,22 @@ extern "C" int cm_policy_act_eps(const float* x, int64_t x_row_stride, const uin
     return 0;
 }
 
+/* Greedy action (argmax of the masked logits, first maximum) + its log-probability: the build's --greedy_eval option. */
+extern "C" int cm_policy_act_greedy(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                                    int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions, const float* params,
+                                    int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream) {
+    if (int rc = check_shapes("cm_policy_act_greedy", din, hidden, n_hidden_layers, n_actions)) return rc;
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = x_row_stride; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = params; a.avail = avail; a.avail_stride = avail_row_stride; a.act_eps = -1.0f;
+    a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
+    const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
+    CM_CHECK_LAUNCH("cm_policy_act_greedy");
+    return 0;
+}
+
 /* Act for EVERY step of an episode in one launch when the observations do not depend on the actions (e.g. the shape
  * env): x is [n_seq][T][din] contiguous, avail [n_seq][T][K]; row (s, t) draws Philox(seed, row_offset + s, t), i.e.
  * exactly what T calls of cm_policy_act with t = 0..T-1 draw.  Outputs action / logp [n_seq][T]. */

@@ -53,7 +53,7 @@ struct MlpArgs {
     // M_ACT
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
     const float* z0_add;  // M_FWD / M_QCRITIC: optional [rows][HP] addend of the layer-0 pre-activation (COMA's factored critic input)
-    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_policy_act_eps)
+    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_policy_act_eps); < 0: greedy (cm_policy_act_greedy)
     int t_decode;  // > 0: rows are (sequence, t) pairs with t = row % t_decode (whole-episode act pass), else a.t
     // training
     const int* action; const float* logp_old; const float* adv; const float* ret; const int* ep_len;
@@ -559,7 +559,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)tt, CM_STREAM_ACT,
                                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
                 int chosen; float lp;
-                if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + hrow * lstride, dout, cm_u01(rnd.x), a.act_eps, &chosen, &lp);
+                if (a.act_eps < 0.0f) cm_categorical_greedy(ls + hrow * lstride, dout, &chosen, &lp);
+                else if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + hrow * lstride, dout, cm_u01(rnd.x), a.act_eps, &chosen, &lp);
                 else cm_categorical_sample(ls + hrow * lstride, dout, cm_u01(rnd.x), &chosen, &lp);
                 a.action_out[(long)grow * a.out_stride] = chosen;
                 a.logp_out[(long)grow * a.out_stride] = lp;

@@ -46,13 +46,11 @@ class HostActor:
         action = torch.empty(rows, dtype=torch.int32, device=self.dev)
         logp = torch.empty(rows, dtype=torch.float32, device=self.dev)
         self.calls += 1
-        if greedy and not self.recurrent:  # argmax of the masked logits (eval only; a few rows)
-            logits = torch.empty(rows, spec.dout, dtype=torch.float32, device=self.dev)
-            N.check(self.lib.cm_mlp_forward(N.ptr(x), rows, spec.din, spec.hidden, spec.n_layers, spec.dout, N.ptr(self.L.actor),
-                                            N.ptr(av), N.ptr(logits), N.stream_ptr()), "cm_mlp_forward")
-            a = logits.argmax(-1)
-            lp = torch.log_softmax(logits, -1).gather(-1, a[:, None])[:, 0]
-            return a.int().cpu().numpy(), lp.cpu().numpy(), h
+        if greedy and not self.recurrent:  # argmax of the masked logits (build option; the reference always samples)
+            N.check(self.lib.cm_policy_act_greedy(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
+                                                  spec.dout, N.ptr(self.L.actor), N.ptr(action), N.ptr(logp), 1, N.stream_ptr()),
+                    "cm_policy_act_greedy")
+            return action.cpu().numpy(), logp.cpu().numpy(), h
         if self.recurrent:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)

@@ -77,6 +77,11 @@ int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, in
                   const float* params, uint64_t seed, int64_t row_offset, int t,
                   int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
 
+/* Greedy variant (argmax of the masked logits, first maximum; logp of that action): the build's --greedy_eval option --
+ * the reference's eval loop (cleanmarl/mappo_multienvs.py:614-650) always samples. */
+int cm_policy_act_greedy(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                         int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions, const float* params,
+                         int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
 /* a4, whole episode in one launch: for envs whose observations do not depend on the actions (shape env) every step
  * can be sampled at once.  x [n_seq][T][din], avail [n_seq][T][n_actions] contiguous; row (s, t) uses the Philox key
  * (seed, row_offset + s, t), i.e. the draws of T calls of cm_policy_act with t = 0..T-1.  action / logp [n_seq][T]. */

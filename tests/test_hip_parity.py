@@ -544,3 +544,28 @@ def test_episode_act_equals_per_step_act():
     ba, bb = ra.collect(p, spec, fused=True), rb.collect(p, spec, fused=False)
     torch.cuda.synchronize()
     assert torch.equal(ba.action, bb.action) and torch.equal(ba.logp, bb.logp) and torch.equal(ba.reward, bb.reward)
+
+
+def test_policy_act_greedy_is_the_argmax_of_the_masked_logits():
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    torch.manual_seed(3)
+    for rows, Do, K, L in [(777, 30, 9, 1), (65, 70, 5, 2)]:
+        spec = NetSpec(Do, 64, L, K)
+        p = init_params_like_torch(spec)
+        obs = torch.randn(rows, Do)
+        avail = torch.rand(rows, K) < 0.5
+        avail[:, 1] = True
+        action = torch.empty(rows, dtype=torch.int32, device=dev); logp = torch.empty(rows, device=dev)
+        d_obs, d_av, d_p = obs.to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
+        N.check(lib.cm_policy_act_greedy(N.ptr(d_obs), Do, N.ptr(d_av), K, rows, Do, 64, L, K, N.ptr(d_p), N.ptr(action), N.ptr(logp), 1,
+                                         N.stream_ptr()), "greedy")
+        logits = R.actor_logits(p, obs, avail)
+        lp_all = torch.log_softmax(logits, -1)
+        a = action.cpu().long()
+        top = logits.max(-1).values
+        assert (logits.gather(-1, a[:, None])[:, 0] >= top - 1e-5).all()  # a maximiser (ties within round-off allowed)
+        assert avail[torch.arange(rows), a].all()
+        assert _err(logp.cpu().numpy(), lp_all.gather(-1, a[:, None])[:, 0].numpy()) <= TOL
