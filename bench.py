@@ -19,7 +19,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it for N > 1)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -69,6 +71,7 @@ def main():
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
 
+    from cleanmarl_amd import _native as N
     from cleanmarl_amd.gru import GRUPPOLearner, GRUSyntheticRollout
     from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch
     from cleanmarl_amd.rollout import SyntheticShapeRollout, SyntheticSpreadRollout
@@ -151,7 +154,8 @@ def main():
             "metric": "env-steps/sec (agents x envs x steps), MAPPO full iteration", "value": units / dt,
             "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if N.load().cm_mfma_mode() == 0 else "bf16x3 (opt-in CM_MFMA=bf16x3: error-compensated bf16 MFMA products, fp32 accumulate and storage)",
+            "data": "synthetic",
             "config": {"workload": desc if not args.envs else f"{desc} [envs/GPU overridden to {E}]",
                        "envs_per_gpu": E, "agents": A, "steps": T, "epochs": hp.epochs, "parallelism": f"env-sharded x{world}"},
             "ppo_update_ms": phases[2], "ppo_update_ms_per_epoch": phases[2] / hp.epochs,

@@ -26,6 +26,7 @@ _sz = C.c_size_t
 SIGNATURES = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (_i, []),
+    "cm_mfma_mode": (_i, []),
     "cm_mlp_param_count": (_l, [_i, _i, _i, _i]),
     "cm_gru_param_count": (_l, [_i, _i, _i]),
     "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -14,6 +14,12 @@ void cm_set_error(const char* fmt, ...) {
 extern "C" const char* cm_last_error(void) { return g_err; }
 extern "C" int cm_version(void) { return 100; }
 
+// 0 = exact fp32 MFMA (default), 1 = CM_MFMA=bf16x3 (error-compensated bf16 GEMM loops in the PPO training passes)
+extern "C" int cm_mfma_mode(void) {
+    static const int mode = [] { const char* e = getenv("CM_MFMA"); return (e && strcmp(e, "bf16x3") == 0) ? 1 : 0; }();
+    return mode;
+}
+
 extern "C" int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout) {
     return (int64_t)din * hidden + hidden + (int64_t)n_hidden_layers * ((int64_t)hidden * hidden + hidden) +
            (int64_t)hidden * dout + dout;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/cleanmarl_hip.h"
 
 #define CM_WAVE 64

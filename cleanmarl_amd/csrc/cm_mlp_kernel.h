@@ -194,6 +194,92 @@ __device__ __forceinline__ void colred(f32x16& acc, const float* Zs_n0, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Error-compensated bf16 MFMA (opt-in, CM_MFMA=bf16x3).  Every fp32 value that lives in an LDS operand
+// tile is stored as a SPLIT WORD  bf16(x) << 16 | bf16(x - bf16(x))  (same 32-bit footprint, same layouts); the three GEMM
+// forms read 8 split words per operand fragment, separate them into a hi and a lo bf16x8 fragment with v_perm_b32 and issue
+// lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, small terms first).  ~17x fp32 round-off per product
+// (2.7e-6 of sum|a b|), 2.95x the fp32 MFMA loop (profiles/r01_h_mfma_split_probe.txt).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+union FragBF { u32x4 u; bf16x8 b; };
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+template <bool BF> __device__ __forceinline__ float enc(float x) {  // value -> LDS word (bit pattern carried in a float)
+    if (!BF) return x;
+    const unsigned hi = bf16_rne(x);
+    const float r = x - __uint_as_float(hi << 16);
+    return __uint_as_float((hi << 16) | bf16_rne(r));
+}
+template <bool BF> __device__ __forceinline__ float dec(float w) {  // LDS word -> value
+    if (!BF) return w;
+    const unsigned u = __float_as_uint(w);
+    return __uint_as_float(u & 0xFFFF0000u) + __uint_as_float(u << 16);
+}
+__device__ __forceinline__ void frag_split(const unsigned (&w)[8], FragBF& hi, FragBF& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi.u[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x07060302u);
+        lo.u[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x05040100u);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf3(const unsigned (&aw)[8], const unsigned (&bw)[8], f32x16 acc) {
+    FragBF ahi, alo, bhi, blo;
+    frag_split(aw, ahi, alo);
+    frag_split(bw, bhi, blo);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo.b, bhi.b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi.b, blo.b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi.b, bhi.b, acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void ld8(unsigned (&w)[8], const float* p) {  // 8 consecutive words (two b128)
+    *reinterpret_cast<u32x4*>(w) = *reinterpret_cast<const u32x4*>(p);
+    *reinterpret_cast<u32x4*>(w + 4) = *reinterpret_cast<const u32x4*>(p + 4);
+}
+__device__ __forceinline__ void ld8s(unsigned (&w)[8], const float* p, int stride) {  // 8 words down a column
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(p[e * stride]);
+}
+// split-word twins of rowpar_nt / rowpar_tn / colred: k (or the contracted row index) is consumed 16 at a time, lane half h
+// owning elements [16j + 8h, 16j + 8h + 8) of BOTH operands
+__device__ __forceinline__ void rowpar_nt_bf(f32x16& acc, const float* As, const float* Bs, int k16) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = As + r * LDT + 8 * h;
+    const float* bp = Bs + r * LDT + 8 * h;
+    for (int j = 0; j < k16; ++j) {
+        unsigned aw[8], bw[8];
+        ld8(aw, ap + 16 * j);
+        ld8(bw, bp + 16 * j);
+        acc = mfma_bf3(aw, bw, acc);
+    }
+}
+__device__ __forceinline__ void rowpar_tn_bf(f32x16& acc, const float* As, const float* Ws_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = As + r * LDT + 8 * h;
+    const float* bp = Ws_c0 + (8 * h) * LDT + r;
+#pragma unroll
+    for (int j = 0; j < HP / 16; ++j) {
+        unsigned aw[8], bw[8];
+        ld8(aw, ap + 16 * j);
+        ld8s(bw, bp + 16 * j * LDT, LDT);
+        acc = mfma_bf3(aw, bw, acc);
+    }
+}
+__device__ __forceinline__ void colred_bf(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = Zs_n0 + (8 * h) * LDT + r;
+    const float* bp = Xs_k0 + (8 * h) * LDT + r;
+#pragma unroll
+    for (int j = 0; j < TM / 16; ++j) {
+        unsigned aw[8], bw[8];
+        ld8s(aw, ap + 16 * j * LDT, LDT);
+        ld8s(bw, bp + 16 * j * LDT, LDT);
+        acc = mfma_bf3(aw, bw, acc);
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -201,6 +287,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // logits[16 rows of this wave][16 head outputs] = H_L[rows][64] * Wout[16][64]^T on v_mfma_f32_16x16x4_f32
 // (32-cycle issue; 16 of them per tile).  k is consumed in the permuted order {16j + 4g + i}: lane group g = lane>>4
 // reads floats [16j + 4g, 16j + 4g + 4) of its row as one b128.  Result: lane (n = lane & 15, g) holds rows 4g..4g+3.
+template <bool BF = false>
 __device__ __forceinline__ f32x4 head_logits_mfma(const float* HLw /* H_L + 16*wave*LDT */, const float* wts /* wouts + 16*ct*WLD */) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const float4* ap = reinterpret_cast<const float4*>(HLw + n * LDT + 4 * g);
@@ -209,10 +296,10 @@ __device__ __forceinline__ f32x4 head_logits_mfma(const float* HLw /* H_L + 16*w
 #pragma unroll
     for (int j = 0; j < HP / 16; ++j) {
         const float4 a = ap[4 * j], b = bp[4 * j];
-        acc = mfma16(a.x, b.x, acc);
-        acc = mfma16(a.y, b.y, acc);
-        acc = mfma16(a.z, b.z, acc);
-        acc = mfma16(a.w, b.w, acc);
+        acc = mfma16(dec<BF>(a.x), b.x, acc);
+        acc = mfma16(dec<BF>(a.y), b.y, acc);
+        acc = mfma16(dec<BF>(a.z), b.z, acc);
+        acc = mfma16(dec<BF>(a.w), b.w, acc);
     }
     return acc;
 }
@@ -221,7 +308,7 @@ __device__ __forceinline__ f32x4 head_logits_mfma(const float* HLw /* H_L + 16*w
 // dlogits[row][k0 + k] * H[row][c0 + c].  One wave owns one 16-column slice of the hidden units for ALL rows, so no
 // cross-wave combine is needed and the accumulator is 4 registers (the 32x32 form spent 16 MFMAs x 64 cycles on a
 // K = 5 head; this spends 16 x 32).
-template <int KP>
+template <int KP, bool BF = false>
 __device__ __forceinline__ void colred_head16(f32x4& acc, const float* ls, int k0, const float* Hs_c0) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const bool kok = (k0 + n) < KP;
@@ -230,7 +317,7 @@ __device__ __forceinline__ void colred_head16(f32x4& acc, const float* ls, int k
 #pragma unroll
     for (int kk = 0; kk < TM / 4; ++kk) {
         const float av = kok ? ap[4 * kk * KP] : 0.0f;
-        acc = mfma16(av, bp[4 * kk * LDT], acc);
+        acc = mfma16(av, dec<BF>(bp[4 * kk * LDT]), acc);
     }
 }
 
@@ -258,6 +345,7 @@ __device__ __forceinline__ void colred_head(f32x16& acc, const float* ls_r0, con
     for (int kk = 0; kk < 16; ++kk) acc = mfma32(ap[2 * kk * LSP], bp[2 * kk * LDT], acc);
 }
 
+template <bool BF = false>
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, long row0, long nrows, long stride,
                                            int col0, int ncols) {
     // dst[r][k] = src[(row0+r)*stride + col0 + k]  for r < TM, k < KC; zero outside [nrows) x [ncols)
@@ -273,7 +361,7 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ro
         p += step;
     }
 #pragma unroll
-    for (int i = 0; i < TM / 4; ++i) dst[(r0 + 4 * i) * LDT + k] = v[i];
+    for (int i = 0; i < TM / 4; ++i) dst[(r0 + 4 * i) * LDT + k] = enc<BF>(v[i]);
 }
 
 // ---- register-staged tile prefetch (T14 "issue early / write late"): a 64x64 fp32 tile = 16 floats per thread.
@@ -307,21 +395,23 @@ __device__ __forceinline__ void tile_load(Tile16& t, const float* src, long row0
     }
 }
 
-template <bool VEC>
+template <bool VEC, bool BF = false>
 __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
     if (VEC) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = threadIdx.x + NTHREADS * i;
             const int r = idx >> 4, c4 = (idx & 15) * 4;
-            *reinterpret_cast<float4*>(dst + r * LDT + c4) = t.v[i];
+            float4 v = t.v[i];
+            if (BF) v = make_float4(enc<true>(v.x), enc<true>(v.y), enc<true>(v.z), enc<true>(v.w));
+            *reinterpret_cast<float4*>(dst + r * LDT + c4) = v;
         }
     } else {
         const float* f = reinterpret_cast<const float*>(t.v);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = threadIdx.x + NTHREADS * i;
-            dst[(idx >> 6) * LDT + (idx & 63)] = f[i];
+            dst[(idx >> 6) * LDT + (idx & 63)] = enc<BF>(f[i]);
         }
     }
 }
@@ -339,7 +429,7 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
 // per-row inputs of the loss heads, fetched at the top of a tile so their HBM latency hides under the MFMA phases
 template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
 
-template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
+template <int NCH, int MODE, bool VEC, int LCAP, int KJ, bool BF = false>
 __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool TRAIN = (MODE >= M_ACTOR);
@@ -374,8 +464,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             if (l < L) smem[lds.bl(l) + i] = (i < H) ? a.params[off.bl(l) + i] : 0.0f;
     }
     for (int i = tid; i < KMAX; i += NTHREADS) smem[lds.bout + i] = (i < dout) ? a.params[off.bout + i] : 0.0f;
-    if (w0_resident) stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
-    if (ws_resident && L >= 1) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+    if (w0_resident) stage_rows<BF>(W0s, a.params + off.W0, 0, H, din, 0, din);
+    if (ws_resident && L >= 1) stage_rows<BF>(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
 
     // ---- persistent accumulators (training)
     f32x16 accW0[NC];
@@ -439,8 +529,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         const bool rvalid = grow < (int)a.rows;
         for (int c = 0; c < nch; ++c) {
             __syncthreads();  // previous readers of Xs / W0s are done
-            tile_store<VEC>(Xs, px);
-            if (!w0_resident) tile_store<VEC>(W0s, pw);
+            tile_store<VEC, BF>(Xs, px);
+            if (!w0_resident) tile_store<VEC, BF>(W0s, pw);
             // issue the next chunk's loads now; they land while the MFMAs below (and, for the last chunk,
             // the whole rest of the tile) execute
             {
@@ -476,7 +566,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             __syncthreads();
             PH(0);
             const int w = min(KC, din - c * KC);
-            rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
+            if (BF) rowpar_nt_bf(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);
+            else rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
         }
         {
             float* H0 = smem + lds.Hs(0);
@@ -486,7 +577,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
                 float z = acc[g] + bias;
                 if (ADD_OK) z += zadd[g];
-                H0[row * LDT + 32 * wn + lc] = fmaxf(z, 0.0f);
+                H0[row * LDT + 32 * wn + lc] = enc<BF>(fmaxf(z, 0.0f));
             }
         }
         __syncthreads();
@@ -496,18 +587,19 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         for (int l = 1; l <= LCAP; ++l) {
             if (l <= L) {
                 if (!ws_resident) {
-                    stage_rows(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
+                    stage_rows<BF>(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
                     __syncthreads();
                 }
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-                rowpar_nt(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                if (BF) rowpar_nt_bf(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 16);
+                else rowpar_nt(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
                 float* Hl = smem + lds.Hs(l);
                 const float bias = smem[lds.bl(l - 1) + 32 * wn + lc];
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    Hl[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                    Hl[row * LDT + 32 * wn + lc] = enc<BF>(fmaxf(acc[g] + bias, 0.0f));
                 }
                 __syncthreads();
             }
@@ -520,7 +612,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
             for (int ct = 0; ct < WR / 16; ++ct) {
-                const f32x4 lg = head_logits_mfma(HL + 16 * wave * LDT, wouts + 16 * ct * WLD);
+                const f32x4 lg = head_logits_mfma<BF>(HL + 16 * wave * LDT, wouts + 16 * ct * WLD);
                 const int k = 16 * ct + n;
                 if (k < KP) {
                     const float bias = smem[lds.bout + k];
@@ -732,7 +824,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             // ---- dWout, dbout (contraction over the tile's rows; reads HL before it is overwritten)
             // wave (wm, wn): rows 32wm..32wm+31 of the tile, hidden columns 32wn..32wn+31, all 32 (padded) head rows
 #pragma unroll
-            for (int q = 0; q < WR / 16; ++q) colred_head16<KP>(accWo[q], ls, 16 * q, HL + 16 * wave);
+            for (int q = 0; q < WR / 16; ++q) colred_head16<KP, BF>(accWo[q], ls, 16 * q, HL + 16 * wave);
             {
                 const int k = tid & 31, part = tid >> 5;
                 float sb = 0.0f;
@@ -752,7 +844,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             for (int g = 0; g < 16; ++g) {
                 const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
                 float* p = HL + row * LDT + 32 * wn + lc;
-                *p = (*p > 0.0f) ? acc[g] : 0.0f;
+                *p = enc<BF>((dec<BF>(*p) > 0.0f) ? acc[g] : 0.0f);
             }
             __syncthreads();
             PH(6);
@@ -763,27 +855,29 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     float* Zl = smem + lds.Hs(l);       // holds dZ_l
                     float* Hm = smem + lds.Hs(l - 1);   // holds H_{l-1}
                     if (!ws_resident) {
-                        stage_rows(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
+                        stage_rows<BF>(Ws, a.params + off.Wl(l - 1), 0, H, H, 0, H);
                         __syncthreads();
                     }
                     {   // bias gradient: column sums
                         const int c = tid & 63, part = tid >> 6;
                         float s = 0.0f;
 #pragma unroll
-                        for (int r = 0; r < TM / 4; ++r) s += Zl[(part * (TM / 4) + r) * LDT + c];
+                        for (int r = 0; r < TM / 4; ++r) s += dec<BF>(Zl[(part * (TM / 4) + r) * LDT + c]);
                         dbh[l] += s;
                     }
-                    colred(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
+                    if (BF) colred_bf(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
+                    else colred(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-                    rowpar_tn(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
+                    if (BF) rowpar_tn_bf(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
+                    else rowpar_tn(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
                     __syncthreads();
                     PH(7);
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
                         float* p = Hm + row * LDT + 32 * wn + lc;
-                        *p = (*p > 0.0f) ? acc[g] : 0.0f;
+                        *p = enc<BF>((dec<BF>(*p) > 0.0f) ? acc[g] : 0.0f);
                     }
                     __syncthreads();
                     PH(8);
@@ -796,7 +890,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     const int c = tid & 63, part = tid >> 6;
                     float s = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < TM / 4; ++r) s += Z0[(part * (TM / 4) + r) * LDT + c];
+                    for (int r = 0; r < TM / 4; ++r) s += dec<BF>(Z0[(part * (TM / 4) + r) * LDT + c]);
                     dbh[0] += s;
                 }
                 if (NCH == 0 || (MODE == M_QCRITIC && a.dz0 != nullptr)) {  // external layer-0 weight gradient: hand dZ0 to k_dw0_stream (coalesced 16-byte stores)
@@ -805,14 +899,18 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         const int idx = tid + NTHREADS * i;
                         const int r = idx >> 4, c4 = (idx & 15) * 4;
                         if (row0 + r < a.rows)
-                            *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
+                        {
+                            float4 v = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
+                            if (BF) v = make_float4(dec<true>(v.x), dec<true>(v.y), dec<true>(v.z), dec<true>(v.w));
+                            *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = v;
+                        }
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < (NCH > 0 ? NCH : 0); ++c) {
                     if (NCH > 1 || L >= 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
                         __syncthreads();
-                        tile_store<VEC>(Xs, px);
+                        tile_store<VEC, BF>(Xs, px);
                         const bool last = (c + 1 == NCH);
                         const int cn = last ? 0 : c + 1;
                         if (EARLY_NEXT) px = pn;  // already in flight since the head phase
@@ -820,7 +918,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         if (last && !w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
                         __syncthreads();
                     }
-                    colred(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
+                    if (BF) colred_bf(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
+                    else colred(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
                 }
             }
             PH(9);
@@ -955,17 +1054,23 @@ inline bool can_vec(const MlpArgs& a) {
            ((reinterpret_cast<uintptr_t>(a.params) & 15) == 0);
 }
 
-template <int NCH, int MODE, bool VEC, int LCAP, int KJ>
+template <int NCH, int MODE, bool VEC, int LCAP, int KJ, bool BF = false>
 inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
 }
+
+// CM_MFMA=bf16x3 opts the PPO training passes into the compensated-bf16 GEMM loops (default: exact fp32 MFMA)
+inline bool mfma_bf16x3() { return cm_mfma_mode() == 1; }
 
 // runtime (vec, L <= 1, dout <= 8) -> compile-time (VEC, LCAP, KJ)
 template <int NCH, int MODE>
 inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
     const bool vec = can_vec(a), l1 = a.L <= 1, k8 = a.dout <= 8;
+    if constexpr ((MODE == M_ACTOR || MODE == M_CRITIC) && NCH <= 2) {
+        if (vec && l1 && k8 && mfma_bf16x3()) { launch_one<NCH, MODE, true, 1, 2, true>(a, grid, lds_bytes, s); return; }
+    }
     if (vec) {
         if (l1) { if (k8) launch_one<NCH, MODE, true, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 1, 8>(a, grid, lds_bytes, s); }
         else    { if (k8) launch_one<NCH, MODE, true, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 2, 8>(a, grid, lds_bytes, s); }

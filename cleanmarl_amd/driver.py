@@ -11,8 +11,10 @@ import datetime
 import os
 import random
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it for world > 1)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from . import _native as N
 from .args import parse_args

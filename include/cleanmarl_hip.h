@@ -55,6 +55,9 @@ enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1 };
 
 const char* cm_last_error(void);
 int cm_version(void);
+/* GEMM arithmetic of the PPO training passes: 0 = exact fp32 MFMA (default), 1 = error-compensated bf16 (environment variable
+ * CM_MFMA=bf16x3, read once per process; ~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8). */
+int cm_mfma_mode(void);
 /* number of floats in a flat MLP parameter buffer */
 int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout);
 int64_t cm_gru_param_count(int din, int hidden, int dout);
