@@ -203,15 +203,11 @@ __device__ __forceinline__ void colred(f32x16& acc, const float* Zs_n0, const fl
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 union FragBF { u32x4 u; bf16x8 b; };
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
 template <bool BF> __device__ __forceinline__ float enc(float x) {  // value -> LDS word (bit pattern carried in a float)
     if (!BF) return x;
-    const unsigned hi = bf16_rne(x);
-    const float r = x - __uint_as_float(hi << 16);
-    return __uint_as_float((hi << 16) | bf16_rne(r));
+    const __bf16 hb = (__bf16)x;  // v_cvt_pk_bf16_f32 (round to nearest even)
+    const __bf16 lb = (__bf16)(x - (float)hb);
+    return __uint_as_float(((unsigned)__builtin_bit_cast(unsigned short, hb) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lb));
 }
 template <bool BF> __device__ __forceinline__ float dec(float w) {  // LDS word -> value
     if (!BF) return w;
