@@ -29,7 +29,10 @@ def environment(env_type, env_name, env_family, agent_ids, kwargs=None, index=0,
     if env_type == "smaclite":
         mod = importlib.import_module("cleanmarl_amd.env.smaclite_wrapper")
         return mod.SMACliteWrapper(map_name=env_name, agent_ids=agent_ids, **kwargs)
-    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, synthetic[_cpu], synthetic_shape[_cpu])")
+    if env_type == "lbf":  # the COMA scripts' third env type (cleanmarl/coma_multienvs.py:248-258)
+        mod = importlib.import_module("cleanmarl_amd.env.lbf_wrapper")
+        return mod.LBFWrapper(map_name=env_name, agent_ids=agent_ids, **kwargs)
+    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, lbf, synthetic[_cpu], synthetic_shape[_cpu])")
 
 
 def env_worker(conn, factory_args):
