@@ -339,6 +339,255 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
     }
 }
 
+// ============================================================================================ 32-row, weights-stationary forward
+// Small batches (cfg 5: 5120 sequences) give the 64-row kernels only 80 workgroups for 256 CUs and every step re-stages its
+// seven weight blocks through LDS.  k_gru32_chunk_fwd walks the same chunk with 32-row tiles (twice the workgroups) and ALL
+// weight blocks resident in LDS for the whole chunk (7 x 17 KB + three 32-row activation buffers = 152 KB): no staging and six
+// barriers per step instead of fourteen.  The four waves split every phase between them: wn = column half, role g:
+//   F1  g0: x1 = relu(fc1(obs))            (g1 idle; the next step's obs tile is already in flight in registers)
+//   F2  g0: r = sigma(..)   g1: z = sigma(..)   in parallel, results stay in the registers of their wave
+//   F3  g0: W_in x1         g1: W_hn h + b_hn -> LDS;  g0: n = tanh(.. + r * ghn) -> LDS;  g1: h' = (1 - z) n + z h -> LDS
+// Same workspace format and statistics as k_gru_chunk_fwd, so k_gru_chunk_bwd consumes it unchanged.  K <= 8 heads only.
+constexpr int T32 = 32;
+constexpr int G32_LDS_FLOATS = 7 * HP * LDT + 3 * T32 * LDT + 8 * HP + HP + 6 * HP + KMAX + 64;
+inline size_t gru32_lds_bytes() { return (size_t)G32_LDS_FLOATS * sizeof(float); }
+
+template <bool SAVE>
+__device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* hp, float* hn, const float* b1, const float* bih,
+                                           const float* bhh, int din, int H, long row0, long nrows, float* wsrow) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, g = wave >> 1, h = lane >> 5, lc = lane & 31;
+    const int col = 32 * wn + lc;
+    f32x16 acc;
+    // ---- F1
+    cm_lds_barrier();  // obs tile in XA, h_{t-1} in hp
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        rowpar_nt(acc, XA, Wt[0] + 32 * wn * LDT, (din + 7) >> 3);
+    }
+    cm_lds_barrier();  // every read of the obs tile is done: x1 may overwrite it
+    if (g == 0) {
+        const float bias = b1[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float v = fmaxf(acc[i] + bias, 0.0f);
+            XA[row * LDT + col] = v;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 0 * HP + col] = v;
+        }
+    }
+    cm_lds_barrier();
+    // ---- F2: gate g (0 = r, 1 = z) on wave group g
+    float gate[16];
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        rowpar_nt(acc, XA, Wt[1 + g] + 32 * wn * LDT, HP / 8);
+        rowpar_nt(acc, hp, Wt[4 + g] + 32 * wn * LDT, HP / 8);
+        const float bias = bih[g * HP + col] + bhh[g * HP + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            gate[i] = sigmoidf_(acc[i] + bias);
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + (1 + g) * HP + col] = gate[i];
+        }
+    }
+    // ---- F3: g0 = W_in x1, g1 = W_hn h
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (g == 0) rowpar_nt(acc, XA, Wt[3] + 32 * wn * LDT, HP / 8);
+    else rowpar_nt(acc, hp, Wt[6] + 32 * wn * LDT, HP / 8);
+    if (g == 1) {
+        const float bh = bhh[2 * HP + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float ghn = acc[i] + bh;
+            hn[row * LDT + col] = ghn;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 4 * HP + col] = ghn;
+        }
+    }
+    cm_lds_barrier();
+    if (g == 0) {
+        const float bi = bih[2 * HP + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float n = tanhf_(acc[i] + bi + gate[i] * hn[row * LDT + col]);
+            hn[row * LDT + col] = n;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 3 * HP + col] = n;
+        }
+    }
+    cm_lds_barrier();
+    if (g == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float n = hn[row * LDT + col], hprev = hp[row * LDT + col];
+            const float hv = (col < H) ? (1.0f - gate[i]) * n + gate[i] * hprev : 0.0f;
+            hn[row * LDT + col] = hv;
+            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 5 * HP + col] = hv;
+        }
+    }
+    cm_lds_barrier();  // hn = h'
+}
+
+// obs tile of 32 rows x din (<= 64) columns: 8 lanes per row, 8 columns each, register-staged one step ahead
+struct X32 { float v[8]; };
+__device__ __forceinline__ void x32_load(X32& x, const float* src, long row0, long nrows, long stride, int ncols) {
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
+    const bool rok = row0 + r < nrows;
+    const float* p = src + (row0 + r) * stride + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.v[i] = (rok && c0 + i < ncols) ? p[i] : 0.0f;
+}
+__device__ __forceinline__ void x32_store(float* XA, const X32& x) {
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
+    *reinterpret_cast<float4*>(XA + r * LDT + c0) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    *reinterpret_cast<float4*>(XA + r * LDT + c0 + 4) = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_fwd(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KJ = 2, KP = 8;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* Wt[7];
+    float* p = smem;
+    for (int i = 0; i < 7; ++i) { Wt[i] = p; p += HP * LDT; }
+    float* XA = p; p += T32 * LDT;
+    float* hp = p; p += T32 * LDT;
+    float* hn = p; p += T32 * LDT;
+    GruLds L = {};
+    L.wouts = p; p += KP * HP;
+    L.b1 = p; p += HP; L.bih = p; p += 3 * HP; L.bhh = p; p += 3 * HP; L.b2 = p; p += KMAX;
+    L.red = p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hrow = tid >> 2, hq = tid & 3;  // head mapping: 4 lanes per row -> threads 0..127 own the 32 rows
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    // ---- one-time staging: every weight block, head weights, biases
+    stage_rows(Wt[0], a.params + off.W1, 0, H, din, 0, din);
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        stage_rows(Wt[1 + q], a.params + off.Wih + q * H * H, 0, H, H, 0, H);
+        stage_rows(Wt[4 + q], a.params + off.Whh + q * H * H, 0, H, H, 0, H);
+    }
+    for (int i = tid; i < KP * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) L.b1[i] = (i < H) ? a.params[off.b1 + i] : 0.0f;
+    for (int i = tid; i < 3 * HP; i += NTHREADS) {
+        const int gg = i / HP, c = i % HP;
+        L.bih[i] = (c < H) ? a.params[off.bih + gg * H + c] : 0.0f;
+        L.bhh[i] = (c < H) ? a.params[off.bhh + gg * H + c] : 0.0f;
+    }
+    for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
+    const long ntiles = (R + T32 - 1) / T32;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * T32;
+        const int grow = (int)row0 + hrow;
+        const bool hlane = hrow < T32;            // this thread takes part in the head
+        const bool rvalid = hlane && grow < R;
+        const int e_row = rvalid ? grow / a.A : 0;
+        const int ag = grow - e_row * a.A;
+        const int eplen = rvalid ? a.ep_len[e_row] : 0;
+        __syncthreads();
+        for (int i = tid; i < T32 * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+        }
+        X32 xr;
+        x32_load(xr, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
+        x32_store(XA, xr);
+        for (int s = 0; s < CL; ++s) {
+            const int t = a.t0 + s;
+            if (s + 1 < CL) x32_load(xr, a.obs + (long)(t + 1) * din, row0, R, (long)T * din, din);  // lands under this step
+            // per-row head inputs of this step: requested now, consumed after the step (their latency hides under its MFMAs)
+            unsigned char avb[KJ];
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                avb[j] = 1;
+                if (rvalid && 4 * j + hq < K) avb[j] = a.avail[((long)grow * T + t) * K + 4 * j + hq];
+            }
+            const long o = (long)grow * T + t;
+            const int act = rvalid ? a.action[o] : 0;
+            const float lpo = rvalid ? a.logp_old[o] : 0.f, advv = rvalid ? a.adv[o] : 0.f;
+            gru32_step<true>(Wt, XA, hp, hn, L.b1, L.bih, L.bhh, din, H, row0, R, a.ws_act + (s * R + row0) * WS_ACT);
+            if (s + 1 < CL) x32_store(XA, xr);  // x1 is dead (the step's last barrier is behind us); visible after the next step's first barrier
+            if (hlane) {
+                // ---- PPO head on relu(h'): statistics + dlogits (saved for the backward sweep); same arithmetic as k_gru_chunk_fwd
+                float zreg[KJ];
+                gru_head_logits<KJ>(L, hn, K, avb, zreg);
+                const bool valid = rvalid && t < eplen;
+                const float invA = 1.0f / (float)a.A;
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
+                m = quad_max(m);
+                float ssum = 0.0f, pj[KJ];
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
+                ssum = quad_sum(ssum);
+                const float lse = m + logf(ssum), rs = 1.0f / ssum;
+                float ent = 0.f, lpa = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) {
+                    const float lp = zreg[j] - lse;
+                    pj[j] *= rs; ent -= pj[j] * lp;
+                    if (4 * j + hq == act) lpa = lp;
+                }
+                ent = quad_sum(ent); lpa = quad_sum(lpa);
+                const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
+                const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                float gsel;
+                if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
+                if (valid && hq == 0) {
+                    st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
+                    st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
+                    if (ag == 0) st_cnt += 1.f;
+                }
+                const float gr = gsel * ratio;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int k = 4 * j + hq;
+                    if (k < K && rvalid) {
+                        const float lp = zreg[j] - lse;
+                        float d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
+                        if (!valid || zreg[j] <= -5e8f) d = 0.f;
+                        a.ws_dl[(s * R + grow) * WS_DL + k] = d;
+                    }
+                }
+            }
+            float* tmp = hp; hp = hn; hn = tmp;
+        }
+        __syncthreads();
+        if (a.h_out)
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+            }
+    }
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = cm_wave_sum(sv6[q]);
+        if (lane == 0) L.red[q * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < CM_NUM_STATS) {
+        float v = 0.f;
+        if (tid < 6) v = L.red[tid * 4] + L.red[tid * 4 + 1] + L.red[tid * 4 + 2] + L.red[tid * 4 + 3];
+        out[off.P + tid] = v;
+    }
+}
+
 template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -660,13 +909,34 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_fwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
+    // forward sweep: the 32-row weights-stationary kernel for K <= 8 heads (its statistics land in grid32 partial rows), else
+    // the 64-row streaming kernel; the backward sweep is the 64-row kernel in both cases (same workspace format)
+    const bool fwd32 = n_actions <= 8 && din <= KC;
+    const long nt32 = ((long)R + T32 - 1) / T32;
+    const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
+    if (fwd32) {
+        const size_t lds32 = gru32_lds_bytes();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+        hipLaunchKernelGGL(k_gru32_chunk_fwd, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
+    }
+#define CM_GRU_LAUNCH_B(KJ_, WV_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
+    if (fwd32) { if (wv) CM_GRU_LAUNCH_B(2, true); else CM_GRU_LAUNCH_B(2, false); }
+    else if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
     else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }
+#undef CM_GRU_LAUNCH_B
 #undef CM_GRU_LAUNCH2
     CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
+    const int64_t P = cm_gru_param_count(din, hidden, n_actions);
     MlpArgs m = {};
     m.partial = a.partial; m.PS = a.PS;
-    return finish_train(m, grid, cm_gru_param_count(din, hidden, n_actions), grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
+    if (!fwd32) return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
+    // gradients: `grid` partial rows (backward kernel); statistics: `grid32` partial rows (forward kernel)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(((int)P + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, (hipStream_t)stream, a.partial, grid, a.PS, 0, (int)P, grad_and_stats);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(RED_COLS * RED_GROUPS), 0, (hipStream_t)stream, a.partial, grid32, a.PS, (int)P, (int)P + CM_NUM_STATS, grad_and_stats);
+    CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd/reduce");
+    return 0;
 }
 
 extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
