@@ -115,14 +115,6 @@ __device__ __forceinline__ void cm_categorical_sample_eps(const float* z, int K,
     *logp = logf(pc);
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope FENCE + barrier: on gfx9 it waits for
-// vmcnt(0), i.e. for every global store the wave has in flight to be acknowledged (~1-2 us to HBM) -- pure waste when the stores
-// are write-once outputs (activation workspace, rollout buffers) that nobody in the workgroup reads back.  This variant waits
-// for the LDS / scalar counter only and leaves global stores in flight.
-__device__ __forceinline__ void cm_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float cm_wave_sum(float v) {
 #pragma unroll

@@ -360,13 +360,13 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
     const int col = 32 * wn + lc;
     f32x16 acc;
     // ---- F1
-    cm_lds_barrier();  // obs tile in XA, h_{t-1} in hp
+    __syncthreads();  // obs tile in XA, h_{t-1} in hp
     if (g == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         rowpar_nt(acc, XA, Wt[0] + 32 * wn * LDT, (din + 7) >> 3);
     }
-    cm_lds_barrier();  // every read of the obs tile is done: x1 may overwrite it
+    __syncthreads();  // every read of the obs tile is done: x1 may overwrite it
     if (g == 0) {
         const float bias = b1[col];
 #pragma unroll
@@ -377,7 +377,7 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 0 * HP + col] = v;
         }
     }
-    cm_lds_barrier();
+    __syncthreads();
     // ---- F2: gate g (0 = r, 1 = z) on wave group g
     float gate[16];
     {
@@ -408,7 +408,7 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 4 * HP + col] = ghn;
         }
     }
-    cm_lds_barrier();
+    __syncthreads();
     if (g == 0) {
         const float bi = bih[2 * HP + col];
 #pragma unroll
@@ -419,7 +419,7 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 3 * HP + col] = n;
         }
     }
-    cm_lds_barrier();
+    __syncthreads();
     if (g == 1) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -430,7 +430,7 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 5 * HP + col] = hv;
         }
     }
-    cm_lds_barrier();  // hn = h'
+    __syncthreads();  // hn = h'
 }
 
 // obs tile of 32 rows x din (<= 64) columns: 8 lanes per row, 8 columns each, register-staged one step ahead
