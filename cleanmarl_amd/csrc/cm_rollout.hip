@@ -174,15 +174,17 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                             *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
                     }
                 }
-            } else {
-#pragma unroll 4
-                for (int r = wave; r < TM; r += 4) {  // wave-uniform row; lane = feature column
+            } else {  // 4-byte stores, flat (row, column) enumeration: consecutive threads -> consecutive addresses of a row
+                const float inv_din = 1.0f / (float)din, inv_sw = 1.0f / (float)(6 * A);
+                for (int idx = tid; idx < RT * din; idx += NTHREADS) {
+                    const int r = (int)(((float)idx + 0.5f) * inv_din), c = idx - r * din;  // exact for idx < 2^22
                     const long ob = obase[r];
-                    if (ob >= 0) {
-                        const float v = Xs[r * LDT + lane];
-                        if (lane < din) a.obs[ob + (long)t * din + lane] = v;
-                        if (lane < 6 * A) a.state[sbase[r] + (long)t * Ds + lane] = v;
-                    }
+                    if (ob >= 0) a.obs[ob + (long)t * din + c] = Xs[r * LDT + c];
+                }
+                for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
+                    const int r = (int)(((float)idx + 0.5f) * inv_sw), c = idx - r * 6 * A;
+                    const long sb = sbase[r];
+                    if (sb >= 0) a.state[sb + (long)t * Ds + c] = Xs[r * LDT + c];
                 }
             }
             // team reward of step t-1 (its partials were produced in the obs phase from the post-physics positions)

@@ -16,6 +16,8 @@ lib = N.load()
 lib.cm_prof_set_buffer.argtypes = [C.c_void_p]
 which = sys.argv[1] if len(sys.argv) > 1 else "actor"
 E, A, T, K = 4096, 8, 128, 5
+if len(sys.argv) > 3:  # python tools/phase_prof.py rollout 1024 3
+    E, A = int(sys.argv[2]), int(sys.argv[3])
 Do, Ds = 7 * A, 6 * A * A
 dev = torch.device("cuda:0")
 from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch  # noqa: E402
