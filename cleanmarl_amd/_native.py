@@ -66,6 +66,8 @@ SIGNATURES = {
     "cm_shape_env_reward": (_i, [_i, _i, _i, _i, _u64, _l, _l, _p, _p, _p]),
     "cm_rollout_spread_supported": (_i, [_i, _i, _i, _i]),
     "cm_rollout_spread": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "cm_gru_rollout_spread_supported": (_i, [_i, _i, _i]),
+    "cm_gru_rollout_spread": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
     "cm_rollout_spread_eps": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -588,6 +588,211 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_fwd(const GruArgs a) {
     }
 }
 
+// ============================================================================================ fused GRU rollout
+// The whole episode of the synthetic MPE-like env with the GRU actor in ONE persistent launch (replaces T x (cm_gru_policy_act +
+// cm_synth_env_step), cleanmarl/mappo_lstm_multienvs.py:392-479 on the synthetic configs): a workgroup keeps floor(32 / A) envs
+// (positions, velocities, landmarks) and their agents' hidden states in LDS for all T steps, the seven weight blocks stay
+// resident (gru32_step), observations / states / actions / log-probs / rewards are written straight into the [E,A,T,F] buffers.
+// Same Philox keys and the same arithmetic as the per-step kernels, so both paths produce the same rollout.
+struct GruRollArgs {
+    float* env_state; int E, A, T, agent_ids;
+    unsigned long long seed, act_seed; long env_offset, episode;
+    const float* params; int din, H, K;
+    float* obs; float* state; int* action; float* logp; float* reward;
+};
+constexpr float GR_DAMP = 0.25f, GR_DT = 0.1f, GR_ACCEL = 5.0f, GR_COLLIDE = 0.3f;  // cm_env.hip / cm_rollout.hip constants
+constexpr int G32R_EXTRA_FLOATS = T32 * 8 + 3 * T32 * 2 + 2 * T32 + 4 * T32 + 16;  // ls, pos/vel/landmarks, reward partials, 2 x long[32]
+
+__global__ __launch_bounds__(NTHREADS) void k_gru32_rollout(const GruRollArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KJ = 2, KP = 8;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* Wt[7];
+    float* p = smem;
+    for (int i = 0; i < 7; ++i) { Wt[i] = p; p += HP * LDT; }
+    float* XA = p; p += T32 * LDT;
+    float* hp = p; p += T32 * LDT;
+    float* hn = p; p += T32 * LDT;
+    GruLds L = {};
+    L.wouts = p; p += KP * HP;
+    L.b1 = p; p += HP; L.bih = p; p += 3 * HP; L.bhh = p; p += 3 * HP; L.b2 = p; p += KMAX;
+    L.red = p; p += 64;
+    float* ls = p; p += T32 * 8;
+    float* epos = p; p += T32 * 2;
+    float* evel = p; p += T32 * 2;
+    float* elm = p; p += T32 * 2;
+    float* rscr = p; p += 2 * T32;
+    long* obase = reinterpret_cast<long*>(p);  // 8-byte aligned: every carve above is a multiple of 2 floats
+    long* sbase = obase + T32;
+    const int tid = threadIdx.x;
+    const int hrow = tid >> 2, hq = tid & 3;
+    const int A = a.A, T = a.T, K = a.K, H = a.H, din = a.din;
+    const int EPT = T32 / A, RT = EPT * A, Ds = 6 * A * A;
+    stage_rows(Wt[0], a.params + off.W1, 0, H, din, 0, din);
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        stage_rows(Wt[1 + q], a.params + off.Wih + q * H * H, 0, H, H, 0, H);
+        stage_rows(Wt[4 + q], a.params + off.Whh + q * H * H, 0, H, H, 0, H);
+    }
+    for (int i = tid; i < KP * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) L.b1[i] = (i < H) ? a.params[off.b1 + i] : 0.0f;
+    for (int i = tid; i < 3 * HP; i += NTHREADS) {
+        const int gg = i / HP, c = i % HP;
+        L.bih[i] = (c < H) ? a.params[off.bih + gg * H + c] : 0.0f;
+        L.bhh[i] = (c < H) ? a.params[off.bhh + gg * H + c] : 0.0f;
+    }
+    for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const float inv_din = 1.0f / (float)din, inv_sw = 1.0f / (float)(6 * A);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();
+        // ---- reset (cm_env.hip k_env_reset): thread per (env, agent) row; h = 0 at the start of the episode
+        if (tid < T32) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
+            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            if (live) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+        for (int i = tid; i < T32 * LDT; i += NTHREADS) hp[i] = 0.0f;
+        auto reward_partials = [&]() {  // nearest-agent distance per landmark, collisions per agent (current positions)
+            if (tid < RT) {
+                const int el = tid / A, l = tid - el * A;
+                const float* pos = epos + el * 2 * A;
+                const float lx = elm[2 * tid], ly = elm[2 * tid + 1];
+                const float qx = pos[2 * l], qy = pos[2 * l + 1];
+                float best = 3.0e38f, col = 0.0f;
+                for (int j = 0; j < A; ++j) {
+                    const float dx = pos[2 * j] - lx, dy = pos[2 * j + 1] - ly;
+                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
+                    if (j > l) {
+                        const float cx = qx - pos[2 * j], cy = qy - pos[2 * j + 1];
+                        if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < GR_COLLIDE) col += 1.0f;
+                    }
+                }
+                rscr[tid] = best; rscr[T32 + tid] = col;
+            }
+        };
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            if (t > 0) reward_partials();  // reward of step t-1 from the positions after its physics update
+            // ---- observations of step t -> XA: 4 lanes per row (threads 0..127), lane hq handles entities j = hq, hq+4, ...
+            if (hrow < T32) {
+                const int el = hrow / A, i = hrow - el * A;
+                const bool live = hrow < RT && (e0 + el) < a.E;
+                float* xr = XA + hrow * LDT;
+                if (live) {
+                    const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
+                    const float px = pos[2 * i], py = pos[2 * i + 1];
+                    if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
+                    for (int j = hq; j < A; j += 4) {
+                        xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                        if (j != i) {
+                            const int jj = j < i ? j : j - 1;
+                            xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
+                            xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                        }
+                        if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
+                    }
+                    for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
+                }
+            }
+            __syncthreads();
+            // ---- rollout-buffer writes: flat (row, column) enumeration, consecutive threads -> consecutive addresses
+            for (int idx = tid; idx < RT * din; idx += NTHREADS) {
+                const int r = (int)(((float)idx + 0.5f) * inv_din), c = idx - r * din;
+                const long ob = obase[r];
+                if (ob >= 0) a.obs[ob + (long)t * din + c] = XA[r * LDT + c];
+            }
+            for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
+                const int r = (int)(((float)idx + 0.5f) * inv_sw), c = idx - r * 6 * A;
+                const long sb = sbase[r];
+                if (sb >= 0) a.state[sb + (long)t * Ds + c] = XA[r * LDT + c];
+            }
+            if (t > 0 && tid < EPT && e0 + tid < a.E) {
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+                for (int l = 0; l < A; ++l) r -= rscr[T32 + tid * A + l];
+                a.reward[(long)(e0 + tid) * T + (t - 1)] = r;
+            }
+            float u_row = 0.0f;  // the step's uniform does not depend on the logits: Philox rounds overlap the GRU step
+            if (tid < RT) {
+                const int el = tid / A, i = tid - el * A;
+                const unsigned long long gr = (unsigned long long)((a.env_offset + e0 + el) * A + i);
+                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
+                                                (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                u_row = cm_u01(rnd.x);
+            }
+            // ---- GRU step (its first barrier orders the obs tile and the buffer-write reads before x1 overwrites XA)
+            gru32_step<false>(Wt, XA, hp, hn, L.b1, L.bih, L.bhh, din, H, 0, T32, nullptr);
+            if (hrow < T32) {
+                unsigned char avb[KJ] = {1, 1};
+                float zreg[KJ];
+                gru_head_logits<KJ>(L, hn, K, avb, zreg);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j)
+                    if (4 * j + hq < K) ls[hrow * 8 + 4 * j + hq] = zreg[j];
+            }
+            __syncthreads();
+            if (tid < RT) {
+                const int el = tid / A, i = tid - el * A;
+                const long e = e0 + el;
+                if (e < a.E) {
+                    int chosen; float lpv;
+                    cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
+                    const long o = (e * A + i) * (long)T + t;
+                    a.action[o] = chosen;
+                    a.logp[o] = lpv;
+                    const float ux = (chosen == 1) ? -GR_ACCEL : (chosen == 2 ? GR_ACCEL : 0.0f);
+                    const float uy = (chosen == 3) ? -GR_ACCEL : (chosen == 4 ? GR_ACCEL : 0.0f);
+                    const float vx = evel[2 * tid] * (1.0f - GR_DAMP) + ux * GR_DT;
+                    const float vy = evel[2 * tid + 1] * (1.0f - GR_DAMP) + uy * GR_DT;
+                    evel[2 * tid] = vx; evel[2 * tid + 1] = vy;
+                    epos[2 * tid] += vx * GR_DT; epos[2 * tid + 1] += vy * GR_DT;
+                }
+            }
+            float* tmp = hp; hp = hn; hn = tmp;
+        }
+        __syncthreads();
+        reward_partials();
+        __syncthreads();
+        if (tid < EPT && e0 + tid < a.E) {
+            float r = 0.0f;
+            for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+            for (int l = 0; l < A; ++l) r -= rscr[T32 + tid * A + l];
+            a.reward[(long)(e0 + tid) * T + (T - 1)] = r;
+        }
+        if (tid < RT) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            if (e < a.E) {
+                float* es = a.env_state + e * 6 * A;
+                es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+            }
+        }
+    }
+}
+
 template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -960,5 +1165,29 @@ extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uin
     else { if (wv) CM_GRU_LAUNCH1(8, true); else CM_GRU_LAUNCH1(8, false); }
 #undef CM_GRU_LAUNCH1
     CM_CHECK_LAUNCH("cm_gru_policy_act");
+    return 0;
+}
+
+extern "C" int cm_gru_rollout_spread_supported(int A, int agent_ids, int hidden) {
+    const int din = 6 * A + (agent_ids ? A : 0);
+    return (A >= 1 && A <= T32 && din <= KC && hidden <= HP) ? 1 : 0;
+}
+
+extern "C" int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                     int64_t env_offset, int64_t episode, const float* params, int hidden,
+                                     float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && T > 0, "cm_gru_rollout_spread: bad dims E=%d T=%d", E, T);
+    CM_REQUIRE(cm_gru_rollout_spread_supported(A, agent_ids, hidden),
+               "cm_gru_rollout_spread: unsupported shape A=%d hidden=%d (use cm_gru_policy_act + cm_synth_env_step)", A, hidden);
+    GruRollArgs a = {};
+    a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed;
+    a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0); a.H = hidden; a.K = 5;
+    a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+    const int EPT = T32 / A;
+    const int ntiles = (E + EPT - 1) / EPT;
+    const size_t lds = (size_t)(G32_LDS_FLOATS + G32R_EXTRA_FLOATS) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_gru32_rollout, dim3(ntiles < 256 ? ntiles : 256), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    CM_CHECK_LAUNCH("cm_gru_rollout_spread");
     return 0;
 }

@@ -107,6 +107,18 @@ class GRUSyntheticRollout:
     def collect(self, actor_flat, actor_spec, fused=None):
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
+        can_fuse = bool(lib.cm_gru_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden))
+        if fused is None:
+            fused = can_fuse
+        if fused:  # the whole episode in one persistent launch (same seeds => same rollout as the per-step path below)
+            if not can_fuse:
+                raise N.NativeError("fused GRU rollout requested for an unsupported shape")
+            act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+            N.check(lib.cm_gru_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed, self.env_offset,
+                                              self.episode, N.ptr(actor_flat), actor_spec.hidden, N.ptr(b.obs), N.ptr(b.state),
+                                              N.ptr(b.action), N.ptr(b.logp), N.ptr(b.reward), s), "cm_gru_rollout_spread")
+            self.episode += 1
+            return b
         if self.h is None:
             self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)
         self.h.zero_()

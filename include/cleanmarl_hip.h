@@ -199,6 +199,14 @@ int cm_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint
                       int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers,
                       float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
 
+/* The same fused rollout for the GRU actor (cleanmarl/mappo_lstm_multienvs.py:392-479 on the synthetic configs): equivalent to
+ * cm_synth_env_reset + T x (cm_gru_policy_act with h = 0 at t = 0; cm_synth_env_step) with the same seeds; 32-row tiles,
+ * all GRU weight blocks LDS-resident for the whole episode.  Supported when A <= 32, 6A(+A) <= 64, hidden <= 64. */
+int cm_gru_rollout_spread_supported(int A, int agent_ids, int hidden);
+int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                          int64_t env_offset, int64_t episode, const float* params, int hidden,
+                          float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
+
 /* ---- COMA  (cleanmarl/coma_multienvs.py, cleanmarl/coma.py) -----------------------------------
  * Device layouts as above: obs [E][A][T][Do], state [E][T][Ds], action [E][A][T] int32, avail [E][A][T][K] u8,
  * reward [E][T], ep_len [E]; K-output tensors are [E][A][T][K]. */

@@ -297,6 +297,35 @@ def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L):
     assert (ra.env_state[env_ok] - rb.env_state[env_ok]).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("E,A,T,H", [(37, 5, 12, 64), (50, 3, 9, 32), (9, 8, 7, 64), (3, 1, 5, 48)])
+def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H):
+    """cm_gru_rollout_spread (one persistent launch, 32-row tiles, weights LDS-resident) ==
+    reset + T x (cm_gru_policy_act, cm_synth_env_step) with the same seeds."""
+    from cleanmarl_amd.gru import GRUSyntheticRollout
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    ra = GRUSyntheticRollout(E, A, T, seed=5, device=dev, env_offset=77)
+    rb = GRUSyntheticRollout(E, A, T, seed=5, device=dev, env_offset=77)
+    spec = NetSpec(ra.Do, H, 0, 5, "gru")
+    p = flatten_params(init_params_like_torch(spec), dev)
+    for _ in range(2):
+        ba = ra.collect(p, spec, fused=True)
+        bb = rb.collect(p, spec, fused=False)
+    torch.cuda.synchronize()
+    same_act = (ba.action == bb.action)
+    assert torch.equal(ba.obs[:, :, 0], bb.obs[:, :, 0]) and torch.equal(ba.state[:, 0], bb.state[:, 0])
+    assert same_act[:, :, 0].all()
+    assert same_act.float().mean().item() >= 0.99
+    env_ok = same_act.all(dim=2).all(dim=1)
+    assert env_ok.float().mean().item() >= 0.9
+    assert (ba.obs[env_ok] - bb.obs[env_ok]).abs().max().item() <= 1e-5
+    assert (ba.state[env_ok] - bb.state[env_ok]).abs().max().item() <= 1e-5
+    assert (ba.reward[env_ok] - bb.reward[env_ok]).abs().max().item() <= 1e-4
+    assert (ba.logp[env_ok] - bb.logp[env_ok]).abs().max().item() <= 1e-4
+    assert (ra.env_state[env_ok] - rb.env_state[env_ok]).abs().max().item() <= 1e-5
+
+
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
 
