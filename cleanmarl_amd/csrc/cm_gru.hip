@@ -1015,6 +1015,256 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
 }
 
 // ============================================================================================ rollout step
+// ============================================================================================ 32-row backward sweep
+// Same arithmetic and workspace as k_gru_chunk_bwd on 32-row tiles (twice the workgroups, half the MFMA work per workgroup and
+// step).  Waves: wn = column half, role = wave >> 1.  Weight gradients: wave (role, wn) owns the (n-half = role, k-half = wn)
+// 32x32 tile of every 64x64 gradient block, contraction over the tile's 32 rows.  Data path: role 0 accumulates
+// dx1 = sum_g dG_i[g] W_ih[g], role 1 accumulates dh_prev = sum_g dG_h[g] W_hh[g] -- concurrently, W_ih[g] / W_hh[g] streamed as
+// a pair through two LDS buffers (three staging rounds per step instead of six).  Head: role 1 does the fc2 weight gradient on
+// the MFMA, role 0 (threads 0..127 = the 4-lanes-per-row mapping of 32 rows) the VALU part.
+__device__ __forceinline__ void colred32(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = Zs_n0 + h * LDT + r;
+    const float* bp = Xs_k0 + h * LDT + r;
+#pragma unroll
+    for (int kk = 0; kk < T32 / 2; kk += 4) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { av[i] = ap[2 * (kk + i) * LDT]; bv[i] = bp[2 * (kk + i) * LDT]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = mfma32(av[i], bv[i], acc);
+    }
+}
+
+constexpr int G32B_LDS_FLOATS = 7 * T32 * LDT + 2 * HP * LDT + 8 * HP + T32 * LSP + 2 * NTHREADS;
+inline size_t gru32b_lds_bytes() { return (size_t)G32B_LDS_FLOATS * sizeof(float); }
+
+template <bool WV>
+__global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = 8;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* DH = p; p += T32 * LDT;
+    float* A1 = p; p += T32 * LDT;
+    float* HPV = p; p += T32 * LDT;
+    float* G0 = p; p += T32 * LDT;
+    float* G1 = p; p += T32 * LDT;
+    float* G2 = p; p += T32 * LDT;
+    float* G3 = p; p += T32 * LDT;
+    float* W = p; p += HP * LDT;
+    float* W2 = p; p += HP * LDT;
+    float* wouts = p; p += KP * HP;
+    float* ls = p; p += T32 * LSP;
+    float* red = p;  // 2 * NTHREADS floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, role = wave >> 1, h = lane >> 5, lc = lane & 31;
+    const int hrow = tid >> 2, hq = tid & 3;
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const int col = 32 * wn + lc;
+    for (int i = tid; i < KP * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < T32 * LSP; i += NTHREADS) ls[i] = 0.0f;
+
+    f32x16 accW1, accWih[3], accWhh[3], accWo;
+    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbo = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        accW1[g] = 0.f; accWo[g] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
+    }
+    const long ntiles = (R + T32 - 1) / T32;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * T32;
+        __syncthreads();
+        for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
+        for (int s = CL - 1; s >= 0; --s) {
+            const int t = a.t0 + s;
+            const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
+            // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
+            __syncthreads();
+            {
+                const int r = tid >> 3, k = tid & 7;  // 32 rows x KP = 256 entries
+                ls[r * LSP + k] = (row0 + r < R && k < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + k] : 0.0f;
+            }
+#pragma unroll 4
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                G3[r * LDT + c] = (row0 + r < R) ? fmaxf(wsS[(long)r * WS_ACT + 5 * HP + c], 0.0f) : 0.0f;
+            }
+            __syncthreads();
+            if (role == 1) colred_head(accWo, ls, G3 + 32 * wn);  // fc2 weight gradient: [32 k] x [32 columns of this wave]
+            {
+                const int k = tid & 31, part = tid >> 5;
+                float sb = 0.f;
+                if (part < T32 / 8) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sb += ls[(part * 8 + r) * LSP + k];
+                }
+                dbo += sb;
+            }
+            if (hrow < T32) {  // DH += (dlogits * W2) .* (h' > 0): 4 lanes per row, 16 columns each
+                float dz[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dz[i] = 0.f;
+                for (int k0 = 0; k0 < K; k0 += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(ls + hrow * LSP + k0);
+                    const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + (k0 + q) * HP + 16 * hq);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 w4 = wp4[i];
+                            dz[4 * i] = fmaf(dk[q], w4.x, dz[4 * i]); dz[4 * i + 1] = fmaf(dk[q], w4.y, dz[4 * i + 1]);
+                            dz[4 * i + 2] = fmaf(dk[q], w4.z, dz[4 * i + 2]); dz[4 * i + 3] = fmaf(dk[q], w4.w, dz[4 * i + 3]);
+                        }
+                    }
+                }
+                float* dp = DH + hrow * LDT + 16 * hq;
+                const float* gp = G3 + hrow * LDT + 16 * hq;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (gp[i] > 0.0f) dp[i] += dz[i];
+            }
+            __syncthreads();
+            // ---- B2: gate derivatives (elementwise, flat mapping), h_prev -> HPV, x1 -> A1
+#pragma unroll 2
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                float rr = 0.f, zz = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, x1 = 0.f;
+                if (row0 + r < R && c < H) {
+                    const float* w = wsS + (long)r * WS_ACT;
+                    x1 = w[c]; rr = w[HP + c]; zz = w[2 * HP + c]; nn = w[3 * HP + c]; ghn = w[4 * HP + c];
+                    if (s > 0) hprev = a.ws_act[((s - 1) * R + row0 + r) * WS_ACT + 5 * HP + c];
+                    else if (a.h_in) hprev = a.h_in[(row0 + r) * H + c];
+                }
+                const float dh = DH[r * LDT + c];
+                const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
+                const float dn_pre = dn * (1.0f - nn * nn);
+                const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+                const float dz_pre = dzg * zz * (1.0f - zz);
+                G0[r * LDT + c] = dr_pre; G1[r * LDT + c] = dz_pre; G2[r * LDT + c] = dn_pre; G3[r * LDT + c] = dn_pre * rr;
+                HPV[r * LDT + c] = hprev; A1[r * LDT + c] = x1;
+                DH[r * LDT + c] = dh * zz;
+            }
+            __syncthreads();
+            // ---- B3: weight gradients of the gates (the first weight pair of B4/B5 is requested now, under these MFMAs)
+            Tile16 tw, tw2;
+            gate_load<WV>(tw, a.params + off.Wih, H);
+            gate_load<WV>(tw2, a.params + off.Whh, H);
+            colred32(accWih[0], G0 + 32 * role, A1 + 32 * wn);
+            colred32(accWih[1], G1 + 32 * role, A1 + 32 * wn);
+            colred32(accWih[2], G2 + 32 * role, A1 + 32 * wn);
+            colred32(accWhh[0], G0 + 32 * role, HPV + 32 * wn);
+            colred32(accWhh[1], G1 + 32 * role, HPV + 32 * wn);
+            colred32(accWhh[2], G3 + 32 * role, HPV + 32 * wn);
+            {
+                const int c = tid & 63, part = tid >> 6;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int r = 0; r < T32 / 4; ++r) {
+                    const int o = (part * (T32 / 4) + r) * LDT + c;
+                    s0 += G0[o]; s1 += G1[o]; s2 += G2[o]; s3 += G3[o];
+                }
+                dbg[0] += s0; dbg[1] += s1; dbg[2] += s2; dbg[3] += s3;
+            }
+            // ---- B4 (role 0): dx1 = sum_g dgi_g W_ih[g]   |   B5 (role 1): dh_prev = sum_g dgh_g W_hh[g]
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            X32 xo;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) {
+                __syncthreads();
+                tile_store<WV>(W, tw);
+                tile_store<WV>(W2, tw2);
+                if (gate < 2) {
+                    gate_load<WV>(tw, a.params + off.Wih + (gate + 1) * H * H, H);
+                    gate_load<WV>(tw2, a.params + off.Whh + (gate + 1) * H * H, H);
+                } else {
+                    x32_load(xo, a.obs + (long)t * din, row0, R, (long)T * din, din);  // obs tile for B6
+                }
+                __syncthreads();
+                if (role == 0) rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G2), W + 32 * wn);
+                else rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G3), W2 + 32 * wn);
+            }
+            __syncthreads();  // every wave is done with A1 (B3) and G* (B4/B5)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (role == 0) {
+                    float* q = A1 + row * LDT + col;
+                    *q = (*q > 0.0f) ? acc[g] : 0.0f;
+                } else {
+                    DH[row * LDT + col] += acc[g];
+                }
+            }
+            // ---- B6: fc1 weight gradient: obs tile -> G0
+            x32_store(G0, xo);
+            __syncthreads();
+            colred32(accW1, A1 + 32 * role, G0 + 32 * wn);
+            {
+                const int c = tid & 63, part = tid >> 6;
+                float s0 = 0.f;
+#pragma unroll
+                for (int r = 0; r < T32 / 4; ++r) s0 += A1[(part * (T32 / 4) + r) * LDT + c];
+                db1 += s0;
+            }
+        }
+    }
+    // ================================ partial gradient of this workgroup (statistics come from the forward kernel)
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int n = 32 * role + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (n < H && col < din) out[off.W1 + n * din + col] = accW1[g];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (n < H && col < H) {
+                out[off.Wih + (q * H + n) * H + col] = accWih[q][g];
+                out[off.Whh + (q * H + n) * H + col] = accWhh[q][g];
+            }
+        }
+    }
+    if (role == 1) {  // fc2 weight: rows k of the 32 x 32 tile, columns of this wave
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (k < K && col < H) out[off.W2 + k * H + col] = accWo[g];
+        }
+    }
+    __syncthreads();
+    red[tid] = dbo;
+    __syncthreads();
+    if (tid < K) {
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sb += red[q * 32 + tid];
+        out[off.b2 + tid] = sb;
+    }
+    {   // column-sum biases: 4 row parts per column
+        float vals[5] = {db1, dbg[0], dbg[1], dbg[2], dbg[3]};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            __syncthreads();
+            red[(tid >> 6) * HP + (tid & 63)] = vals[q];
+            __syncthreads();
+            if (tid < H) {
+                const float sv = red[tid] + red[HP + tid] + red[2 * HP + tid] + red[3 * HP + tid];
+                if (q == 0) out[off.b1 + tid] = sv;
+                else if (q == 1) { out[off.bih + tid] = sv; out[off.bhh + tid] = sv; }
+                else if (q == 2) { out[off.bih + H + tid] = sv; out[off.bhh + H + tid] = sv; }
+                else if (q == 3) out[off.bih + 2 * H + tid] = sv;
+                else out[off.bhh + 2 * H + tid] = sv;
+            }
+        }
+    }
+}
+
 template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1127,7 +1377,16 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
 #define CM_GRU_LAUNCH_B(KJ_, WV_) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    if (fwd32) { if (wv) CM_GRU_LAUNCH_B(2, true); else CM_GRU_LAUNCH_B(2, false); }
+    if (fwd32) {  // 32-row backward sweep: one partial row per 32-row tile, like the forward
+        const size_t ldsb = gru32b_lds_bytes();
+        if (wv) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipLaunchKernelGGL((k_gru32_chunk_bwd<true>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipLaunchKernelGGL((k_gru32_chunk_bwd<false>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a);
+        }
+    }
     else if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
     else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }
 #undef CM_GRU_LAUNCH_B
@@ -1137,11 +1396,7 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     MlpArgs m = {};
     m.partial = a.partial; m.PS = a.PS;
     if (!fwd32) return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
-    // gradients: `grid` partial rows (backward kernel); statistics: `grid32` partial rows (forward kernel)
-    hipLaunchKernelGGL(k_reduce_partials, dim3(((int)P + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, (hipStream_t)stream, a.partial, grid, a.PS, 0, (int)P, grad_and_stats);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(RED_COLS * RED_GROUPS), 0, (hipStream_t)stream, a.partial, grid32, a.PS, (int)P, (int)P + CM_NUM_STATS, grad_and_stats);
-    CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd/reduce");
-    return 0;
+    return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");  // both sweeps: grid32 partial rows
 }
 
 extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
