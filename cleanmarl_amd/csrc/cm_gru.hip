@@ -1364,9 +1364,13 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_fwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    // forward sweep: the 32-row weights-stationary kernel for K <= 8 heads (its statistics land in grid32 partial rows), else
-    // the 64-row streaming kernel; the backward sweep is the 64-row kernel in both cases (same workspace format)
-    const bool fwd32 = n_actions <= 8 && din <= KC;
+    // K <= 8 heads at small / medium batch: 32-row forward (weights-stationary) + 32-row backward sweeps, grid32 partial rows;
+    // otherwise the 64-row streaming kernels (same workspace format)
+    // 32-row sweeps pay off while the 64-row tiling leaves CUs idle or barely filled (measured: 5k and 20k sequences faster,
+    // 82k sequences slower than the 64-row kernels); above 512 64-row tiles the streaming 64-row kernels take over
+    const char* tile_env = getenv("CM_GRU_TILE");  // test hook: CM_GRU_TILE=64 forces the 64-row kernels at any batch size
+    const bool force64 = tile_env && atoi(tile_env) == 64;
+    const bool fwd32 = !force64 && n_actions <= 8 && din <= KC && (long)R <= 512L * TM;
     const long nt32 = ((long)R + T32 - 1) / T32;
     const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
     if (fwd32) {

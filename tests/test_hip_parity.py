@@ -329,8 +329,15 @@ def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H):
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
 
+@pytest.mark.parametrize("tile", ["auto", "64"])
 @pytest.mark.parametrize("name,algo", GRU_CASES)
-def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo):
+def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile, monkeypatch):
+    # "auto" takes the 32-row forward / backward sweeps at this batch size; CM_GRU_TILE=64 (read per call) forces the 64-row
+    # streaming kernels that large batches and K > 8 heads use, so both tilings are pinned to the reference goldens
+    if tile == "64":
+        monkeypatch.setenv("CM_GRU_TILE", "64")
+    else:
+        monkeypatch.delenv("CM_GRU_TILE", raising=False)
     """cm_gru_actor_chunk_fwd_bwd + TBPTT schedule vs the unmodified reference's mappo/ippo_lstm_multienvs.py."""
     from oracle import restatement as R
     from cleanmarl_amd.gru import GRUPPOLearner
