@@ -22,6 +22,7 @@ class GRUPPOLearner(PPOLearner):
         assert actor_spec.kind == "gru"
         super().__init__(algo, actor_spec, critic_spec, n_agents, hp, device, actor_params, critic_params, process_group, world_size)
         self.gru_ws = None
+        self.g_rows = None
         self.h = [None, None]
 
     def _ensure(self, b):
@@ -40,6 +41,8 @@ class GRUPPOLearner(PPOLearner):
         chunks = [(t0, min(t0 + tb, T)) for t0 in range(0, T, tb)]
         nE = int(hp.epochs)
         rec_a = torch.zeros(nE, len(chunks), N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
+        if self.g_rows is None or self.g_rows.shape[0] < len(chunks):
+            self.g_rows = torch.zeros(len(chunks), Pa + N.NUM_STATS, dtype=torch.float32, device=self.device)
         rec_c = torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
         kept = []
         for ep in range(nE):
@@ -50,18 +53,18 @@ class GRUPPOLearner(PPOLearner):
                 ev0.record()
             for ci, (t0, t1) in enumerate(chunks):
                 h_out = self.h[ci & 1]
+                g = self.g_rows[ci]  # one [grads | stats] row per chunk: the statistics survive without per-chunk copies
                 N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
                     N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
                     b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(self.actor), N.ptr(h_in), N.ptr(h_out),
-                    hp.ppo_clip, hp.entropy_coef, N.ptr(self.g_actor), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
+                    hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
                     "cm_gru_actor_chunk_fwd_bwd")
-                self._allreduce(self.g_actor)
-                self._adam(self.actor, self.g_actor, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0))
-                rec_a[ep, ci, :N.NUM_STATS] = self.g_actor[Pa:]
-                rec_a[ep, ci, N.NUM_STATS] = self.norms[0]
+                self._allreduce(g)
+                self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:])
                 if keep_grads:
-                    steps.append((self.g_actor[:Pa].clone(), self.actor.clone()))
+                    steps.append((g[:Pa].clone(), self.actor.clone()))
                 h_in = h_out
+            rec_a[ep, :, :N.NUM_STATS] = self.g_rows[:len(chunks), Pa:]  # one strided copy per epoch
             if self.events is not None:
                 ev1.record()
                 self.events.append(("actor", ev0, ev1))

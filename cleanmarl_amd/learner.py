@@ -210,12 +210,14 @@ class PPOLearner:
             N.check(lib.cm_normalize(N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, N.ptr(self.moments), 0.0, 0, s), "cm_normalize")
 
     # ------------------------------------------------------------------ a8 - a12
-    def _adam(self, params, g, opt, which, s, grad_scale=1.0):
+    def _adam(self, params, g, opt, which, s, grad_scale=1.0, out_norm=None):
+        """out_norm: 1-element device view that receives the pre-clip gradient norm (default: self.norms[which])."""
         opt.step += 1
         hp = self.hp
         N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
                                                 opt.lr, 0.9, 0.999, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
-                                                grad_scale, N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
+                                                grad_scale, N.ptr(self.norms[which:] if out_norm is None else out_norm), s),
+                "cm_grad_norm_clip_adam")
 
     def _timed(self, kind, fn, *a):
         if self.events is None:
