@@ -398,9 +398,14 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
         for (int i = 0; i < 4; ++i) {
             const int idx = threadIdx.x + NTHREADS * i;
             const int r = idx >> 4, c4 = (idx & 15) * 4;
-            float4 v = t.v[i];
-            if (BF) v = make_float4(enc<true>(v.x), enc<true>(v.y), enc<true>(v.z), enc<true>(v.w));
-            *reinterpret_cast<float4*>(dst + r * LDT + c4) = v;
+            if (BF) {
+                const float4 v = t.v[i];
+                *reinterpret_cast<float4*>(dst + r * LDT + c4) = make_float4(enc<true>(v.x), enc<true>(v.y), enc<true>(v.z), enc<true>(v.w));
+            } else {  // keep this a DIRECT member-to-LDS store: routing it through a local float4 changed the register allocation
+                      // of the fp32 kernels (a prefetch register got recycled as a zero constant -> s_waitcnt vmcnt(0) right
+                      // after the prefetch was issued) and cost 2 % of the actor kernel
+                *reinterpret_cast<float4*>(dst + r * LDT + c4) = t.v[i];
+            }
         }
     } else {
         const float* f = reinterpret_cast<const float*>(t.v);
@@ -896,9 +901,12 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         const int r = idx >> 4, c4 = (idx & 15) * 4;
                         if (row0 + r < a.rows)
                         {
-                            float4 v = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
-                            if (BF) v = make_float4(dec<true>(v.x), dec<true>(v.y), dec<true>(v.z), dec<true>(v.w));
-                            *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = v;
+                            if (BF) {
+                                const float4 v = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
+                                *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = make_float4(dec<true>(v.x), dec<true>(v.y), dec<true>(v.z), dec<true>(v.w));
+                            } else {
+                                *reinterpret_cast<float4*>(a.dz0 + (row0 + r) * HP + c4) = *reinterpret_cast<const float4*>(Z0 + r * LDT + c4);
+                            }
                         }
                     }
                 }

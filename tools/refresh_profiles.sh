@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01g
+O=$R/gpurun_out/r01j
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
@@ -20,4 +20,12 @@ for w in cfg2 cfg4 cfg5; do python $R/bench.py --workload $w --no-cpu-baseline >
 python $R/tools/bench_coma.py > $O/coma_bench.json 2> $O/coma.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kc -- python $R/tools/bench_coma.py --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/kc -name "*kernel_stats.csv" | head -1) $O/coma_kernel_stats.csv
+ls -la $O
+# opt-in compensated-bf16 arithmetic (NOT the default): same bench / kernel stats / phases under the flag
+CM_MFMA=bf16x3 python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_bf16x3.json 2>/dev/null
+CM_MFMA=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kb -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+cp $(find /tmp/kb -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bf16x3.csv
+CM_MFMA=bf16x3 python $R/tools/phase_prof.py actor > $O/phase_actor_bf16x3.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k5 -- python $R/bench.py --workload cfg5 --no-cpu-baseline > /dev/null 2>&1
+cp $(find /tmp/k5 -name "*kernel_stats.csv" | head -1) $O/cfg5_kernel_stats.csv
 ls -la $O
