@@ -532,19 +532,9 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             __syncthreads();  // previous readers of Xs / W0s are done
             tile_store<VEC, BF>(Xs, px);
             if (!w0_resident) tile_store<VEC, BF>(W0s, pw);
-            // issue the next chunk's loads now; they land while the MFMAs below (and, for the last chunk,
-            // the whole rest of the tile) execute
-            {
-                const bool last = (c + 1 == nch);
-                const int cn = last ? 0 : c + 1;
-                const bool again = TRAIN && NCH > 0 && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
-                const long r0n = last ? (again ? row0 : next_row0) : row0;
-                const int wn_ = min(KC, din - cn * KC);
-                tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
-                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
-            }
             if (c == 0) {
-                // per-row head inputs: issued here, consumed (raw) only in the head phases after the MFMA layers
+                // per-row head inputs: issued here, BEFORE the tile prefetch below (the compiler turns them into booleans right
+                // after the layer-0 loop; vmcnt waits are in issue order, so behind the prefetch they would drag it along)
                 const bool use_avail = (MODE == M_ACTOR || MODE == M_COMA_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr);
                 if (rvalid && use_avail) {
                     const uint8_t* ap = a.avail + (long)grow * a.avail_stride;
@@ -563,6 +553,17 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                     else if (MODE == M_QCRITIC) { ri.act = a.action[grow]; ri.ret = a.ret[grow]; }
                     else if (a.per_agent) ri.ret = a.ret[grow];
                 }
+            }
+            // issue the next chunk's loads now; they land while the MFMAs below (and, for the last chunk,
+            // the whole rest of the tile) execute
+            {
+                const bool last = (c + 1 == nch);
+                const int cn = last ? 0 : c + 1;
+                const bool again = TRAIN && NCH > 0 && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
+                const long r0n = last ? (again ? row0 : next_row0) : row0;
+                const int wn_ = min(KC, din - cn * KC);
+                tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
+                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
             }
             __syncthreads();
             PH(0);
