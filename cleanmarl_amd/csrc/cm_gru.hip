@@ -1078,23 +1078,41 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
         for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
     }
     const long ntiles = (R + T32 - 1) / T32;
+    // Everything a step reads from the HBM workspace (8 elements of the flat 32 x 64 mapping per thread + one dlogit) is
+    // requested one step AHEAD, under the MFMA phases of the step before, instead of right where it is consumed.
+    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], hrelu[8], dl; } P;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * T32;
+        auto load_pre = [&](int s) {
+            const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
+                const bool rok = row0 + r < R;
+                const float* w = wsS + (long)r * WS_ACT;
+                P.hrelu[e] = rok ? w[5 * HP + c] : 0.0f;
+                P.x1[e] = P.rr[e] = P.zz[e] = P.nn[e] = P.ghn[e] = P.hprev[e] = 0.0f;
+                if (rok && c < H) {
+                    P.x1[e] = w[c]; P.rr[e] = w[HP + c]; P.zz[e] = w[2 * HP + c]; P.nn[e] = w[3 * HP + c]; P.ghn[e] = w[4 * HP + c];
+                    if (s > 0) P.hprev[e] = a.ws_act[((s - 1) * R + row0 + r) * WS_ACT + 5 * HP + c];
+                    else if (a.h_in) P.hprev[e] = a.h_in[(row0 + r) * H + c];
+                }
+            }
+            const int r = tid >> 3, kk = tid & 7;
+            P.dl = (row0 + r < R && kk < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + kk] : 0.0f;
+        };
         __syncthreads();
         for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
+        load_pre(CL - 1);
         for (int s = CL - 1; s >= 0; --s) {
             const int t = a.t0 + s;
-            const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
             // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
             __syncthreads();
-            {
-                const int r = tid >> 3, k = tid & 7;  // 32 rows x KP = 256 entries
-                ls[r * LSP + k] = (row0 + r < R && k < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + k] : 0.0f;
-            }
-#pragma unroll 4
-            for (int i = tid; i < T32 * HP; i += NTHREADS) {
-                const int r = i >> 6, c = i & 63;
-                G3[r * LDT + c] = (row0 + r < R) ? fmaxf(wsS[(long)r * WS_ACT + 5 * HP + c], 0.0f) : 0.0f;
+            ls[(tid >> 3) * LSP + (tid & 7)] = P.dl;  // 32 rows x KP = 256 entries
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
+                G3[r * LDT + c] = fmaxf(P.hrelu[e], 0.0f);
             }
             __syncthreads();
             if (role == 1) colred_head(accWo, ls, G3 + 32 * wn);  // fc2 weight gradient: [32 k] x [32 columns of this wave]
@@ -1132,16 +1150,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
             }
             __syncthreads();
             // ---- B2: gate derivatives (elementwise, flat mapping), h_prev -> HPV, x1 -> A1
-#pragma unroll 2
-            for (int i = tid; i < T32 * HP; i += NTHREADS) {
-                const int r = i >> 6, c = i & 63;
-                float rr = 0.f, zz = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, x1 = 0.f;
-                if (row0 + r < R && c < H) {
-                    const float* w = wsS + (long)r * WS_ACT;
-                    x1 = w[c]; rr = w[HP + c]; zz = w[2 * HP + c]; nn = w[3 * HP + c]; ghn = w[4 * HP + c];
-                    if (s > 0) hprev = a.ws_act[((s - 1) * R + row0 + r) * WS_ACT + 5 * HP + c];
-                    else if (a.h_in) hprev = a.h_in[(row0 + r) * H + c];
-                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
+                const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e], x1 = P.x1[e];
                 const float dh = DH[r * LDT + c];
                 const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
                 const float dn_pre = dn * (1.0f - nn * nn);
@@ -1152,6 +1164,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
                 DH[r * LDT + c] = dh * zz;
             }
             __syncthreads();
+            if (s > 0) load_pre(s - 1);  // the next (earlier) step's workspace rows land under this step's MFMA phases
             // ---- B3: weight gradients of the gates (the first weight pair of B4/B5 is requested now, under these MFMAs)
             Tile16 tw, tw2;
             gate_load<WV>(tw, a.params + off.Wih, H);
