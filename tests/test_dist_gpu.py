@@ -155,3 +155,50 @@ def test_two_ranks_reproduce_the_single_process_coma_reference(golden_dir, tmp_p
         assert _err(g["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(g["actor"].numpy(), z["actor_after"][0]) <= TOL
         assert _err(g["target"].numpy(), z["target_after"]) <= 1e-6
     assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
+
+
+def _gru_worker(rank, world, port, gold, algo, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import restatement as R
+    from cleanmarl_amd import dist
+    from cleanmarl_amd.gru import GRUPPOLearner
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec
+    batch, ap, cp, hp, z = R.load_golden(gold)
+    dev = torch.device("cuda:0")
+    lo, n = dist.shard(batch["obs"].shape[0], rank, world)
+    sl = slice(lo, lo + n)
+    b = DeviceBatch.from_reference_layout(batch["obs"][sl], batch["actions"][sl], batch["log_probs"][sl], batch["reward"][sl],
+                                          batch["states"][sl], batch["avail"][sl], batch["mask"][sl], dev)
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=False, normalize_advantage=bool(hp["normalize_advantage"]),
+                normalize_return=bool(hp["normalize_return"]), epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"],
+                entropy_coef=hp["entropy_coef"], clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], tbptt=int(hp["tbptt"]),
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], 0, ap[-1].shape[0], "gru")
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = GRUPPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
+                      process_group=torch.distributed.group.WORLD, world_size=world)
+    recs = L.train_iteration(b)
+    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu()), f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_lstm_ragged", "mappo"), ("ippo_lstm_ragged", "ippo")])
+def test_two_ranks_reproduce_the_single_process_gru_reference(golden_dir, tmp_path, name, algo):
+    """GRU / TBPTT: one all-reduce per chunk (actor) + one per epoch (critic); the env shards must land on the post-update
+    parameters of the unmodified single-process *_lstm_multienvs.py after all epochs x chunks optimiser steps."""
+    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+    gold = os.path.join(golden_dir, name + ".npz")
+    mp.spawn(_gru_worker, args=(world, port, gold, algo, out), nprocs=world, join=True)
+    z = np.load(gold)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    for g in got:
+        for e, r in enumerate(g["recs"]):
+            assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+            assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL and _err(r["kl"], z["kl_divergences"][e]) <= TOL
+            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL
+        assert _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+    assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
