@@ -1,4 +1,7 @@
-import itertools, math, os, sys, tempfile, traceback
+"""Run every drop-in script with unusual flag combinations (normalisations, AdamW, clipping, 0 / 2 hidden layers, no agent ids,
+pipe / shm vector envs, single env, batch_size 1, COMA n-step / target-update cadence) and check that it finishes with finite
+scalars.  usage (on a GPU box): python tools/cli_sweep.py"""
+import math, os, sys, tempfile, traceback
 sys.path.insert(0, os.getcwd())
 from cleanmarl_amd.driver import run
 from cleanmarl_amd.coma_driver import run as run_coma
