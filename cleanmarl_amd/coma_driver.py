@@ -48,6 +48,8 @@ def run(script, argv=None):
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         pg = torch.distributed.group.WORLD
     E_glob = args.batch_size
+    if E_glob < world:
+        raise N.NativeError(f"--batch_size={E_glob} < {world} ranks: every rank needs at least one environment (env-sharded data parallelism)")
     E = E_glob // world + (1 if rank < E_glob % world else 0)
     env_offset = rank * (E_glob // world) + min(rank, E_glob % world)
     synth = dict(agents=args.synthetic_agents, steps=args.synthetic_steps, obs=args.synthetic_obs, state=args.synthetic_state,
