@@ -202,3 +202,32 @@ def test_two_ranks_reproduce_the_single_process_gru_reference(golden_dir, tmp_pa
         assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL
         assert _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
     assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
+
+
+def test_bench_contract_single_gpu():
+    """The one JSON line `python bench.py` prints at N = 1: every field of the driver's contract, the roofline object of the
+    dominant kernel and the bounded CPU baseline (a smaller sample here to keep the test short)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-envs", "4"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "weak"
+    assert "4096 envs x 8 agents x 128 steps" in out["config"]["workload"] and "model" not in out["config"]
+    assert abs(out["value"] - 4096 * 8 * 128 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
+    assert rf["traffic"] is None or rf["traffic"] > 0.9 * rf["algorithmic_bytes_per_launch"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "envs" in cb["sample"]
+    assert out["value"] > 50 * cb["value"]  # north-star: >= 50x the reference-structured CPU path
