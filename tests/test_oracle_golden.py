@@ -118,3 +118,17 @@ def test_coma_restatement_matches_reference_golden(golden_dir, name):
     assert np.abs(R.flat(cp).numpy() - z["critic_after"][0]).max() < 2e-6
     assert np.abs(R.flat(ap).numpy() - z["actor_after"][0]).max() < 2e-6
     assert np.abs(R.flat(tp).numpy() - z["target_after"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("name,algo", MLP_CASES)
+def test_plain_c_loss_loop_matches_reference_golden(golden_dir, name, algo):
+    """oracle/ppo_loss.c (literal per-time-step, per-env, per-agent scalar loops of mappo_multienvs.py:527-576) reproduces the
+    epoch-0 logged scalars of the unmodified reference: actor loss, critic loss, entropy, approx KL, clip fraction."""
+    from oracle.build_c import ppo_losses_c
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    got = ppo_losses_c(batch, ap, cp, torch.from_numpy(z["advantages"]), torch.from_numpy(z["return_lambda"]), hp["ppo_clip"],
+                       hp["entropy_coef"], algo)
+    assert got["n_valid"] == float(batch["mask"].sum())
+    for k, zk in (("actor_loss", "actor_losses"), ("critic_loss", "critic_losses"), ("entropy", "entropies_bonuses"),
+                  ("kl", "kl_divergences"), ("clipfrac", "clipped_ratios")):
+        assert abs(got[k] - float(z[zk][0])) <= 5e-6 * (1.0 + abs(float(z[zk][0]))), (k, got[k], float(z[zk][0]))
