@@ -347,10 +347,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
 //   F1  g0: x1 = relu(fc1(obs))            (g1 idle; the next step's obs tile is already in flight in registers)
 //   F2  g0: r = sigma(..)   g1: z = sigma(..)   in parallel, results stay in the registers of their wave
 //   F3  g0: W_in x1         g1: W_hn h + b_hn -> LDS;  g0: n = tanh(.. + r * ghn) -> LDS;  g1: h' = (1 - z) n + z h -> LDS
-// Same workspace format and statistics as k_gru_chunk_fwd, so k_gru_chunk_bwd consumes it unchanged.  K <= 8 heads only.
+// Same workspace format and statistics as k_gru_chunk_fwd, so either backward kernel consumes it.  KJ = 2 (K <= 8) or 8 (K <= 32).
 constexpr int T32 = 32;
-constexpr int G32_LDS_FLOATS = 7 * HP * LDT + 3 * T32 * LDT + 8 * HP + HP + 6 * HP + KMAX + 64;
-inline size_t gru32_lds_bytes() { return (size_t)G32_LDS_FLOATS * sizeof(float); }
+constexpr int g32_lds_floats(int KP) { return 7 * HP * LDT + 3 * T32 * LDT + KP * HP + HP + 6 * HP + KMAX + 64; }
+constexpr int G32_LDS_FLOATS = g32_lds_floats(8);  // K <= 8 (the fused rollout)
+inline size_t gru32_lds_bytes(int KP) { return (size_t)g32_lds_floats(KP) * sizeof(float); }
 
 template <bool SAVE>
 __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* hp, float* hn, const float* b1, const float* bih,
@@ -448,9 +449,10 @@ __device__ __forceinline__ void x32_store(float* XA, const X32& x) {
     *reinterpret_cast<float4*>(XA + r * LDT + c0 + 4) = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
+template <int KJ>
 __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_fwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KJ = 2, KP = 8;
+    constexpr int KP = KJ * 4;
     const GruOff off = gru_offsets(a.din, a.H, a.K);
     float* Wt[7];
     float* p = smem;
@@ -1036,13 +1038,12 @@ __device__ __forceinline__ void colred32(f32x16& acc, const float* Zs_n0, const 
     }
 }
 
-constexpr int G32B_LDS_FLOATS = 7 * T32 * LDT + 2 * HP * LDT + 8 * HP + T32 * LSP + 2 * NTHREADS;
-inline size_t gru32b_lds_bytes() { return (size_t)G32B_LDS_FLOATS * sizeof(float); }
+inline size_t gru32b_lds_bytes(int KP) { return (size_t)(7 * T32 * LDT + 2 * HP * LDT + KP * HP + T32 * LSP + 2 * NTHREADS) * sizeof(float); }
 
-template <bool WV>
+template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KP = 8;
+    constexpr int KP = KJ * 4, NDL = KP / 8;  // dlogits entries per thread: 32 rows x KP / 256 threads
     const GruOff off = gru_offsets(a.din, a.H, a.K);
     float* p = smem;
     float* DH = p; p += T32 * LDT;
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
     const long ntiles = (R + T32 - 1) / T32;
     // Everything a step reads from the HBM workspace (8 elements of the flat 32 x 64 mapping per thread + one dlogit) is
     // requested one step AHEAD, under the MFMA phases of the step before, instead of right where it is consumed.
-    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], hrelu[8], dl; } P;
+    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], hrelu[8], dl[NDL]; } P;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * T32;
         auto load_pre = [&](int s) {
@@ -1098,8 +1099,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
                     else if (a.h_in) P.hprev[e] = a.h_in[(row0 + r) * H + c];
                 }
             }
-            const int r = tid >> 3, kk = tid & 7;
-            P.dl = (row0 + r < R && kk < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + kk] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < NDL; ++q) {
+                const int i = tid + NTHREADS * q, r = i / KP, kk = i - r * KP;
+                P.dl[q] = (row0 + r < R && kk < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + kk] : 0.0f;
+            }
         };
         __syncthreads();
         for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
@@ -1108,7 +1112,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
             const int t = a.t0 + s;
             // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
             __syncthreads();
-            ls[(tid >> 3) * LSP + (tid & 7)] = P.dl;  // 32 rows x KP = 256 entries
+#pragma unroll
+            for (int q = 0; q < NDL; ++q) {
+                const int i = tid + NTHREADS * q, r = i / KP;
+                ls[r * LSP + (i - r * KP)] = P.dl[q];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
@@ -1377,32 +1385,37 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_fwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    // K <= 8 heads at small / medium batch: 32-row forward (weights-stationary) + 32-row backward sweeps, grid32 partial rows;
+    // small / medium batch: 32-row forward (weights-stationary) + 32-row backward sweeps, grid32 partial rows;
     // otherwise the 64-row streaming kernels (same workspace format)
     // 32-row sweeps pay off while the 64-row tiling leaves CUs idle or barely filled (measured: 5k and 20k sequences faster,
     // 82k sequences slower than the 64-row kernels); above 512 64-row tiles the streaming 64-row kernels take over
     const char* tile_env = getenv("CM_GRU_TILE");  // test hook: CM_GRU_TILE=64 forces the 64-row kernels at any batch size
     const bool force64 = tile_env && atoi(tile_env) == 64;
-    const bool fwd32 = !force64 && n_actions <= 8 && din <= KC && (long)R <= 512L * TM;
+    const bool fwd32 = !force64 && din <= KC && (long)R <= 512L * TM;
     const long nt32 = ((long)R + T32 - 1) / T32;
     const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
+    const int KP32 = n_actions <= 8 ? 8 : KMAX;
     if (fwd32) {
-        const size_t lds32 = gru32_lds_bytes();
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-        hipLaunchKernelGGL(k_gru32_chunk_fwd, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
+        const size_t lds32 = gru32_lds_bytes(KP32);
+        if (n_actions <= 8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+            hipLaunchKernelGGL(k_gru32_chunk_fwd<2>, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+            hipLaunchKernelGGL(k_gru32_chunk_fwd<8>, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
+        }
     }
 #define CM_GRU_LAUNCH_B(KJ_, WV_) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
     if (fwd32) {  // 32-row backward sweep: one partial row per 32-row tile, like the forward
-        const size_t ldsb = gru32b_lds_bytes();
-        if (wv) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            hipLaunchKernelGGL((k_gru32_chunk_bwd<true>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            hipLaunchKernelGGL((k_gru32_chunk_bwd<false>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a);
-        }
+        const size_t ldsb = gru32b_lds_bytes(KP32);
+#define CM_GRU32_B(KJ_, WV_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+        hipLaunchKernelGGL((k_gru32_chunk_bwd<KJ_, WV_>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a); } while (0)
+        if (n_actions <= 8) { if (wv) CM_GRU32_B(2, true); else CM_GRU32_B(2, false); }
+        else { if (wv) CM_GRU32_B(8, true); else CM_GRU32_B(8, false); }
+#undef CM_GRU32_B
     }
     else if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
     else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }

@@ -376,6 +376,43 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
     assert k == len(z["actor_grads"])
 
 
+@pytest.mark.parametrize("tile", ["auto", "64"])
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,tb", [("ippo", 11, 4, 13, 37, 50, 17, 64, 5), ("mappo", 9, 3, 10, 21, 54, 5, 48, 4),
+                                                      ("mappo", 40, 5, 12, 35, 150, 5, 64, 10)])
+def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile, monkeypatch):
+    """Seeded GRU / TBPTT update (ragged episodes, availability masks, K = 17 heads, H < 64, several tiles) vs the CPU oracle,
+    on both tilings (32-row sweeps; CM_GRU_TILE=64 -> 64-row streaming kernels)."""
+    from oracle import restatement as R
+    from cleanmarl_amd.gru import GRUPPOLearner
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, init_params_like_torch
+    if tile == "64":
+        monkeypatch.setenv("CM_GRU_TILE", "64")
+    else:
+        monkeypatch.delenv("CM_GRU_TILE", raising=False)
+    torch.manual_seed(2)
+    batch = _random_case(77, E, A, T, Do, Ds, K)
+    aspec = NetSpec(Do, H, 0, K, "gru")
+    cspec = NetSpec(Ds if algo == "mappo" else Do, 64, 1, 1)
+    ap, cp = init_params_like_torch(aspec), init_params_like_torch(cspec)
+    hp = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=True, normalize_return=False, epochs=2, ppo_clip=0.2, entropy_coef=0.01,
+              clip_gradients=0.5, optimizer="Adam", learning_rate_actor=8e-4, learning_rate_critic=8e-4, tbptt=tb)
+    dev = torch.device("cuda:0")
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"], batch["states"],
+                                          batch["avail"], batch["mask"], dev)
+    L = GRUPPOLearner(algo, aspec, cspec, A, HParams(**hp), dev, actor_params=[p.clone() for p in ap], critic_params=[p.clone() for p in cp])
+    recs = L.train_iteration(b, keep_grads=True)
+    ret, adv, orecs = R.gru_update(ap, cp, batch, hp, algo)
+    assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL and _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
+    for r, o in zip(recs, orecs):
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
+            assert _err(r[k], o[k]) <= TOL, k
+        assert len(r["actor_steps"]) == len(o["actor_steps"])
+        for (g, after), ost in zip(r["actor_steps"], o["actor_steps"]):
+            assert _err(g.cpu().numpy(), R.flat(ost["grads"]).numpy()) <= TOL
+            assert _err(after.cpu().numpy(), R.flat(ost["after"]).numpy()) <= TOL
+        assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
+
+
 def test_gru_policy_act_matches_oracle():
     from oracle import restatement as R
     from oracle import sampling
