@@ -69,6 +69,19 @@ def test_learning_signal_on_synthetic_env(tmp_path, monkeypatch):
     assert last > first + 0.05 * abs(first), (first, last)
 
 
+def test_learning_signal_gru(tmp_path, monkeypatch):
+    """The GRU / TBPTT scripts (fused GRU rollout + 32-row sweeps) must improve the episode return of the on-device env too."""
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    common = ["--env_type=synthetic", "--batch_size=256", "--synthetic_agents=3", "--synthetic_steps=25", "--total_timesteps=960000",
+              "--eval_steps=100000", "--log_every=1", "--actor_hidden_dim=64", "--tbptt=10"]
+    for script in ("mappo_lstm_multienvs", "ippo_lstm_multienvs"):
+        out = run(script, common)
+        r = [v for t, v, _ in out["history"] if t == "rollout/ep_reward"]
+        first, last = sum(r[:15]) / 15, sum(r[-15:]) / 15
+        assert last > first + 0.05 * abs(first), (script, first, last)
+
+
 def test_checkpoint_resume_is_bit_exact(tmp_path, monkeypatch):
     """train 4 iterations in one go == train 2, checkpoint, resume 2 (replicated state + counter-based env/action RNG)."""
     import torch
