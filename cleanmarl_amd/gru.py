@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _native as N
-from .learner import DeviceBatch, PPOLearner
+from .learner import LazyRecords, _to_host_async, DeviceBatch, PPOLearner
 
 _GOLD = 0x9E3779B97F4A7C15
 
@@ -75,19 +75,23 @@ class GRUPPOLearner(PPOLearner):
             rec_c[ep, N.NUM_STATS] = self.norms[1]
             if keep_grads:
                 kept.append((steps, self.g_critic[:Pc].clone(), self.critic.clone()))
-        ra, rc = rec_a.cpu().double(), rec_c.cpu().double()  # single sync
-        out = []
-        for ep in range(nE):
-            tot = ra[ep, :, :N.NUM_STATS].sum(0)
-            n = float(tot[N.STAT_COUNT])
-            d = dict(actor_loss=float(-tot[N.STAT_PG] - hp.entropy_coef * tot[N.STAT_ENT]) / n,
-                     critic_loss=float(rc[ep, N.STAT_VLOSS]) / float(rc[ep, N.STAT_COUNT]),
-                     entropy=float(tot[N.STAT_ENT]) / n, kl=float(tot[N.STAT_KL]) / n, clipfrac=float(tot[N.STAT_CLIP]) / n,
-                     actor_gnorm=float(ra[ep, :, N.NUM_STATS].mean()), critic_gnorm=float(rc[ep, N.NUM_STATS]), n_valid=n)
-            if keep_grads:
-                d.update(actor_steps=kept[ep][0], critic_grads=kept[ep][1], critic_after=kept[ep][2])
-            out.append(d)
-        return out
+        ent_coef = hp.entropy_coef
+
+        def build(ra, rc):
+            out = []
+            for ep in range(nE):
+                tot = ra[ep, :, :N.NUM_STATS].sum(0)
+                n = float(tot[N.STAT_COUNT])
+                d = dict(actor_loss=float(-tot[N.STAT_PG] - ent_coef * tot[N.STAT_ENT]) / n,
+                         critic_loss=float(rc[ep, N.STAT_VLOSS]) / float(rc[ep, N.STAT_COUNT]),
+                         entropy=float(tot[N.STAT_ENT]) / n, kl=float(tot[N.STAT_KL]) / n, clipfrac=float(tot[N.STAT_CLIP]) / n,
+                         actor_gnorm=float(ra[ep, :, N.NUM_STATS].mean()), critic_gnorm=float(rc[ep, N.NUM_STATS]), n_valid=n)
+                if keep_grads:
+                    d.update(actor_steps=kept[ep][0], critic_grads=kept[ep][1], critic_after=kept[ep][2])
+                out.append(d)
+            return out
+        host, ev = _to_host_async(rec_a, rec_c)  # no host wait here: see learner.LazyRecords
+        return LazyRecords(nE, host, ev, build)
 
 
 class GRUSyntheticRollout:

@@ -140,6 +140,44 @@ class _Adam:
         self.step = 0
 
 
+class LazyRecords:
+    """Per-epoch records of an update whose numbers are still on their way from the device: the statistics buffer is copied to
+    pinned host memory asynchronously and turned into python floats on first access (len() never waits).  A caller that logs every
+    iteration (driver.py) sees the same values at the same place as before; a caller that does not (bench.py, users logging every
+    N iterations) no longer stalls the launch queue once per iteration."""
+
+    def __init__(self, n, host_tensors, event, build):
+        self._n, self._host, self._event, self._build, self._recs = n, host_tensors, event, build, None
+
+    def _get(self):
+        if self._recs is None:
+            self._event.synchronize()
+            self._recs = self._build(*[h.double() for h in self._host])
+            self._host = self._build = None
+        return self._recs
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __reduce__(self):  # pickles (torch.save) as the plain list of per-epoch dicts
+        return (list, (self._get(),))
+
+
+def _to_host_async(*tensors):
+    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    for h, t in zip(host, tensors):
+        h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
+
+
 class PPOLearner:
     """algo = "mappo" (central critic on state) or "ippo" (per-agent critic on obs)."""
 
@@ -272,20 +310,24 @@ class PPOLearner:
             rec[ep, 2 * N.NUM_STATS:] = self.norms
             if keep_grads:
                 kept.append((self.g_actor[:Pa].clone(), self.g_critic[:Pc].clone(), self.actor.clone(), self.critic.clone()))
-        r = rec.cpu().double()  # single sync
-        out = []
-        for ep in range(int(hp.epochs)):
-            st_a, st_c = r[ep, :N.NUM_STATS], r[ep, N.NUM_STATS:2 * N.NUM_STATS]
-            n = float(st_a[N.STAT_COUNT])
-            d = dict(actor_loss=float(-st_a[N.STAT_PG] - hp.entropy_coef * st_a[N.STAT_ENT]) / n,
-                     critic_loss=float(st_c[N.STAT_VLOSS]) / float(st_c[N.STAT_COUNT]),
-                     entropy=float(st_a[N.STAT_ENT]) / n, kl=float(st_a[N.STAT_KL]) / n,
-                     clipfrac=float(st_a[N.STAT_CLIP]) / n,
-                     actor_gnorm=float(r[ep, 2 * N.NUM_STATS]), critic_gnorm=float(r[ep, 2 * N.NUM_STATS + 1]), n_valid=n)
-            if keep_grads:
-                d.update(actor_grads=kept[ep][0], critic_grads=kept[ep][1], actor_after=kept[ep][2], critic_after=kept[ep][3])
-            out.append(d)
-        return out
+        nE, ent_coef = int(hp.epochs), hp.entropy_coef
+
+        def build(r):
+            out = []
+            for ep in range(nE):
+                st_a, st_c = r[ep, :N.NUM_STATS], r[ep, N.NUM_STATS:2 * N.NUM_STATS]
+                n = float(st_a[N.STAT_COUNT])
+                d = dict(actor_loss=float(-st_a[N.STAT_PG] - ent_coef * st_a[N.STAT_ENT]) / n,
+                         critic_loss=float(st_c[N.STAT_VLOSS]) / float(st_c[N.STAT_COUNT]),
+                         entropy=float(st_a[N.STAT_ENT]) / n, kl=float(st_a[N.STAT_KL]) / n,
+                         clipfrac=float(st_a[N.STAT_CLIP]) / n,
+                         actor_gnorm=float(r[ep, 2 * N.NUM_STATS]), critic_gnorm=float(r[ep, 2 * N.NUM_STATS + 1]), n_valid=n)
+                if keep_grads:
+                    d.update(actor_grads=kept[ep][0], critic_grads=kept[ep][1], actor_after=kept[ep][2], critic_after=kept[ep][3])
+                out.append(d)
+            return out
+        host, ev = _to_host_async(rec)  # no host wait here: see LazyRecords
+        return LazyRecords(nE, host, ev, build)
 
     def train_iteration(self, b, keep_grads=False):
         self.compute_targets(b)
