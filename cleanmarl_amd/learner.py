@@ -199,7 +199,9 @@ class PPOLearner:
         self.opt_a = _Adam(Pa, hp.learning_rate_actor, hp.optimizer, device)
         self.opt_c = _Adam(Pc, hp.learning_rate_critic, hp.optimizer, device)
         # one flat buffer [actor grads | 8 stats | critic grads | 8 stats] = ONE all-reduce per optimiser step
-        self.gbuf = torch.zeros(Pa + Pc + 2 * N.NUM_STATS, dtype=torch.float32, device=device)
+        # one row per epoch (the statistics of an epoch survive the next one without copies); row 0 is `gbuf`
+        self.gbuf_rows = torch.zeros(max(1, int(hp.epochs)), Pa + Pc + 2 * N.NUM_STATS, dtype=torch.float32, device=device)
+        self.gbuf = self.gbuf_rows[0]
         self.g_actor = self.gbuf[:Pa + N.NUM_STATS]
         self.g_critic = self.gbuf[Pa + N.NUM_STATS:]
         self.norms = torch.zeros(2, dtype=torch.float32, device=device)
@@ -274,22 +276,24 @@ class PPOLearner:
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
 
-    def critic_pass(self, b, s):
+    def critic_pass(self, b, s, g=None):
+        """g: [Pc + 8] gradient + statistics buffer to fill (default self.g_critic)."""
         self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
         N.check(self.lib.cm_critic_fwd_bwd(N.ptr(x), N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
                                            0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
-                                           N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws), self.ws.numel(), s),
+                                           N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws), self.ws.numel(), s),
                 "cm_critic_fwd_bwd")
 
-    def actor_pass(self, b, s):
+    def actor_pass(self, b, s, g=None):
+        """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor)."""
         self._ensure_ws(b)
         a = self.actor_spec
         N.check(self.lib.cm_ppo_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
                                               N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
                                               N.ptr(self.actor), self.hp.ppo_clip, self.hp.entropy_coef,
-                                              N.ptr(self.g_actor), N.ptr(self.ws), self.ws.numel(), s),
+                                              N.ptr(self.g_actor if g is None else g), N.ptr(self.ws), self.ws.numel(), s),
                 "cm_ppo_actor_fwd_bwd")
 
     def update(self, b, keep_grads=False):
@@ -297,19 +301,26 @@ class PPOLearner:
         Returns a list of per-epoch dicts (one host sync at the end)."""
         hp, s = self.hp, N.stream_ptr()
         Pa, Pc = self.actor.numel(), self.critic.numel()
-        rec = torch.zeros(int(hp.epochs), 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
+        nE0 = int(hp.epochs)
+        rec = torch.zeros(nE0, 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
+        # one [actor grads | 8 | critic grads | 8] row per epoch: the statistics survive the next epoch without per-epoch copies,
+        # the norms are written by the Adam kernel straight into `rec`; row 0 is self.gbuf (what single passes and tests read)
+        if self.gbuf_rows.shape[0] < nE0:
+            raise N.NativeError(f"epochs={nE0} exceeds the {self.gbuf_rows.shape[0]} gradient rows allocated at construction")
         kept = []
-        for ep in range(int(hp.epochs)):
-            self._timed("actor", self.actor_pass, b, s)
-            self._timed("critic", self.critic_pass, b, s)
-            self._allreduce(self.gbuf)  # the only data-path collective: grads + N + stat sums
-            self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
-            self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
-            rec[ep, :N.NUM_STATS] = self.g_actor[Pa:]
-            rec[ep, N.NUM_STATS:2 * N.NUM_STATS] = self.g_critic[Pc:]
-            rec[ep, 2 * N.NUM_STATS:] = self.norms
+        for ep in range(nE0):
+            g = self.gbuf_rows[ep]
+            g_actor, g_critic = g[:Pa + N.NUM_STATS], g[Pa + N.NUM_STATS:]
+            self._timed("actor", self.actor_pass, b, s, g_actor)
+            self._timed("critic", self.critic_pass, b, s, g_critic)
+            self._allreduce(g)  # the only data-path collective: grads + N + stat sums
+            self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
+            self._adam(self.critic, g_critic, self.opt_c, 1, s, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
             if keep_grads:
-                kept.append((self.g_actor[:Pa].clone(), self.g_critic[:Pc].clone(), self.actor.clone(), self.critic.clone()))
+                kept.append((g_actor[:Pa].clone(), g_critic[:Pc].clone(), self.actor.clone(), self.critic.clone()))
+        # two strided copies per update instead of three small ones per epoch
+        rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
+        rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
         nE, ent_coef = int(hp.epochs), hp.entropy_coef
 
         def build(r):
