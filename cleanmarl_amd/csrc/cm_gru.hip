@@ -375,7 +375,6 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
             const float v = fmaxf(acc[i] + bias, 0.0f);
             XA[row * LDT + col] = v;
-            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 0 * HP + col] = v;
         }
     }
     __syncthreads();
@@ -428,10 +427,22 @@ __device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* h
             const float n = hn[row * LDT + col], hprev = hp[row * LDT + col];
             const float hv = (col < H) ? (1.0f - gate[i]) * n + gate[i] * hprev : 0.0f;
             hn[row * LDT + col] = hv;
-            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 5 * HP + col] = hv;
         }
     }
     __syncthreads();  // hn = h'
+    if (SAVE) {
+        // x1 (still in XA) and h' (now in hn) leave as 16-byte stores from their row-major LDS tiles: 4 store instructions per thread
+        // instead of 32 scattered 4-byte ones from the accumulator layout (the forward step is store-issue bound)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = threadIdx.x + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+            if (row0 + r < nrows) {
+                float* w = wsrow + (long)r * WS_ACT + c4;
+                *reinterpret_cast<float4*>(w) = *reinterpret_cast<const float4*>(XA + r * LDT + c4);
+                *reinterpret_cast<float4*>(w + 5 * HP) = *reinterpret_cast<const float4*>(hn + r * LDT + c4);
+            }
+        }
+    }
 }
 
 // obs tile of 32 rows x din (<= 64) columns: 8 lanes per row, 8 columns each, register-staged one step ahead
