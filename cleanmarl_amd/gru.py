@@ -90,8 +90,10 @@ class GRUPPOLearner(PPOLearner):
                     d.update(actor_steps=kept[ep][0], critic_grads=kept[ep][1], critic_after=kept[ep][2])
                 out.append(d)
             return out
-        host, ev = _to_host_async(rec_a, rec_c)  # no host wait here: see learner.LazyRecords
-        return LazyRecords(nE, host, ev, build)
+        host, ev, attach = _to_host_async(self._ring, rec_a, rec_c)  # no host wait here: see learner.LazyRecords
+        out = LazyRecords(nE, host, ev, build)
+        attach(out)
+        return out
 
 
 class GRUSyntheticRollout:

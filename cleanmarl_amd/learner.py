@@ -169,13 +169,38 @@ class LazyRecords:
         return (list, (self._get(),))
 
 
-def _to_host_async(*tensors):
-    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
-    for h, t in zip(host, tensors):
-        h.copy_(t, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    return host, ev
+class _HostRing:
+    """A few preallocated pinned staging buffers reused round-robin (a fresh pinned allocation costs ~1 ms: it must not land in
+    the iteration).  A slot is reused RING iterations later; if the records that still point at it were never read they are
+    materialised first (their event completed long ago)."""
+    RING = 8
+
+    def __init__(self):
+        self.slots = [None] * self.RING  # (shapes, [pinned tensors], weakref to the LazyRecords using them)
+        self.i = 0
+
+    def stage(self, tensors):
+        import weakref
+        k = self.i
+        self.i = (self.i + 1) % self.RING
+        shapes = [tuple(t.shape) for t in tensors]
+        slot = self.slots[k]
+        if slot is not None and slot[2] is not None:
+            prev = slot[2]()
+            if prev is not None:
+                prev._get()
+        if slot is None or slot[0] != shapes:
+            slot = [shapes, [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors], None]
+            self.slots[k] = slot
+        for h, t in zip(slot[1], tensors):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return slot[1], ev, lambda rec, slot=slot: slot.__setitem__(2, weakref.ref(rec))
+
+
+def _to_host_async(ring, *tensors):
+    return ring.stage(tensors)
 
 
 class PPOLearner:
@@ -210,6 +235,7 @@ class PPOLearner:
         self.values = None
         self.mom_ws = None
         self.events = None  # bench.py sets this to a list to collect per-launch (kind, start, end) HIP events
+        self._ring = _HostRing()
 
     # ------------------------------------------------------------------ helpers
     def _allreduce(self, t):
@@ -337,8 +363,10 @@ class PPOLearner:
                     d.update(actor_grads=kept[ep][0], critic_grads=kept[ep][1], actor_after=kept[ep][2], critic_after=kept[ep][3])
                 out.append(d)
             return out
-        host, ev = _to_host_async(rec)  # no host wait here: see LazyRecords
-        return LazyRecords(nE, host, ev, build)
+        host, ev, attach = _to_host_async(self._ring, rec)  # no host wait here: see LazyRecords
+        out = LazyRecords(nE, host, ev, build)
+        attach(out)
+        return out
 
     def train_iteration(self, b, keep_grads=False):
         self.compute_targets(b)
