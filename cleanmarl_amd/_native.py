@@ -30,7 +30,11 @@ SIGNATURES = {
     "cm_mlp_param_count": (_l, [_i, _i, _i, _i]),
     "cm_gru_param_count": (_l, [_i, _i, _i]),
     "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "cm_mlp_forward_workspace_bytes": (_sz, [_l, _i, _i, _i, _i]),
+    "cm_mlp_forward_ws": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "cm_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_policy_act_workspace_bytes": (_sz, [_l, _i, _i, _i, _i]),
+    "cm_policy_act_ws": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _d, _u64, _l, _i, _p, _p, _l, _p, _sz, _p]),
     "cm_policy_act_eps": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _d, _u64, _l, _i, _p, _p, _l, _p]),
     "cm_coma_build_inputs": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "cm_gather_taken": (_i, [_p, _p, _l, _i, _p, _p]),
@@ -52,6 +56,7 @@ SIGNATURES = {
     "cm_masked_moments": (_i, [_p, _p, _i, _i, _i, _p, _p, _sz, _p]),
     "cm_normalize": (_i, [_p, _p, _i, _i, _i, _p, _f, _i, _p]),
     "cm_mlp_train_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cm_ppo_actor_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cm_ppo_actor_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),
     "cm_critic_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cm_critic_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),

@@ -120,7 +120,7 @@ class ComaArgs:
     actor_num_layers: int = 1
     """ Number of hidden layers of actor network"""
     critic_hidden_dim: int = 128
-    """ Hidden dimension of critic network (this build's kernels support <= 64: pass --critic_hidden_dim=64)"""
+    """ Hidden dimension of critic network (<= 64: fused kernels + factored critic input; 65..256: layered schedule)"""
     critic_num_layers: int = 1
     """ Number of hidden layers of critic network"""
     optimizer: str = "Adam"

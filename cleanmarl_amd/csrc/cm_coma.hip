@@ -9,7 +9,7 @@
 //                         normalisation of :664-667 (raw double sums, so ranks can all-reduce them)
 //   k_coma_normalize_adv  (adv - mean_t) / (std_t + 1e-8) where the reference's (sic) condition holds
 //   k_polyak              soft_update (:266-270)
-#include "cm_mlp_split.h"
+#include "cm_mlp_wide.h"
 
 namespace {
 
@@ -394,19 +394,22 @@ extern "C" int cm_polyak_update(float* target, const float* src, int64_t n, doub
 }
 
 extern "C" size_t cm_mlp_split_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout) {
+    if (wide_shape(hidden, n_hidden_layers)) return wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, true);
     return split_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout);
 }
 
 extern "C" int cm_qcritic_fwd_bwd(const float* x, const int32_t* action, const float* target, const int32_t* ep_len, int E, int A, int T,
                                   int din, int hidden, int n_hidden_layers, int n_actions, const float* params, float* grad_and_stats,
                                   void* ws, size_t ws_bytes, cm_stream_t stream) {
-    if (int rc = check_shapes("cm_qcritic_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
+    const bool wide = wide_shape(hidden, n_hidden_layers);  // layered schedule (cm_mlp_wide.h)
+    if (!wide) if (int rc = check_shapes("cm_qcritic_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_qcritic_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
     const long rows = (long)E * A * T;
     if (int rc = check_rows("cm_qcritic_fwd_bwd", rows)) return rc;
     MlpArgs a = {};
     a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.action = action; a.ret = target; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
+    if (wide) return wide_train<M_QCRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_qcritic_fwd_bwd");
     return run_train<M_QCRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_qcritic_fwd_bwd");
 }
 
@@ -414,7 +417,8 @@ extern "C" int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, con
                                      const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                                      const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
                                      cm_stream_t stream) {
-    if (int rc = check_shapes("cm_coma_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
+    const bool wide = wide_shape(hidden, n_hidden_layers);  // layered schedule (cm_mlp_wide.h)
+    if (!wide) if (int rc = check_shapes("cm_coma_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_coma_actor_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
     const long rows = (long)E * A * T;
     if (int rc = check_rows("cm_coma_actor_fwd_bwd", rows)) return rc;
@@ -422,6 +426,7 @@ extern "C" int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, con
     a.x = obs; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.avail = avail; a.avail_stride = n_actions; a.action = action; a.adv = adv; a.ep_len = ep_len;
     a.A = A; a.T = T; a.per_agent = 1; a.ent_coef = (float)entropy_coef;
+    if (wide) return wide_train<M_COMA_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_coma_actor_fwd_bwd");
     return run_train<M_COMA_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_coma_actor_fwd_bwd");
 }
 

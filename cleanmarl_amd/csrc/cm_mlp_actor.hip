@@ -1,5 +1,5 @@
 // cm_mlp_actor.hip -- cm_ppo_actor_fwd_bwd (a8/a9, actor side)
-#include "cm_mlp_train.h"
+#include "cm_mlp_wide.h"
 
 #ifdef CM_PHASE_PROF
 unsigned long long* g_prof = nullptr;
@@ -10,13 +10,28 @@ extern "C" size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden
     return train_ws_bytes(din, hidden, n_hidden_layers, dout);
 }
 
+/* rows-aware query: the layered schedule of wide / deep actors keeps its activations in the workspace */
+extern "C" size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions) {
+    if (wide_shape(hidden, n_hidden_layers)) return wide_ws_bytes((long)E * A * T, din, hidden, n_hidden_layers, n_actions, true);
+    return train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
+}
+
 extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
                                     const float* logp_old, const float* adv, const int32_t* ep_len,
                                     int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                                     const float* params, double ppo_clip, double entropy_coef,
                                     float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
-    if (int rc = check_shapes("cm_ppo_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_ppo_actor_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
+    if (wide_shape(hidden, n_hidden_layers)) {  // layered schedule (cm_mlp_wide.h)
+        MlpArgs a = {};
+        a.x = obs; a.x_stride = din; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+        a.params = params; a.avail = avail; a.avail_stride = n_actions;
+        a.action = action; a.logp_old = logp_old; a.adv = adv; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
+        a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip;
+        a.ent_coef = (float)entropy_coef;
+        return wide_train<M_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");
+    }
+    if (int rc = check_shapes("cm_ppo_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     const size_t need = train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
     CM_REQUIRE(ws && ws_bytes >= need, "cm_ppo_actor_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     const int64_t P = cm_mlp_param_count(din, hidden, n_hidden_layers, n_actions);

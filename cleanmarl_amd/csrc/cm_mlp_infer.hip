@@ -1,5 +1,5 @@
 // cm_mlp_infer.hip -- C-ABI entry points of the forward-only MLP kernels (a3/a4/a5)
-#include "cm_mlp_kernel.h"
+#include "cm_mlp_wide.h"
 
 extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                               const float* params, const uint8_t* avail, float* y, cm_stream_t stream) {
@@ -12,6 +12,22 @@ extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden,
     launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_mlp_forward");
     return 0;
+}
+
+/* cm_mlp_forward with a caller workspace: also covers the shapes of the layered schedule (hidden 65..256, any depth), whose
+ * activations live in the workspace.  cm_mlp_forward_workspace_bytes is 0 for shapes the fused kernel covers. */
+extern "C" size_t cm_mlp_forward_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout) {
+    return wide_shape(hidden, n_hidden_layers) ? wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, false) : 0;
+}
+
+extern "C" int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                                 const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    if (!wide_shape(hidden, n_hidden_layers)) return cm_mlp_forward(x, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream);
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
+    a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
+    return wide_forward(a, ws, ws_bytes, (hipStream_t)stream, "cm_mlp_forward_ws");
 }
 
 extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
@@ -63,6 +79,35 @@ extern "C" int cm_policy_act_greedy(const float* x, int64_t x_row_stride, const 
     launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_greedy");
     return 0;
+}
+
+/* cm_policy_act / cm_policy_act_eps / cm_policy_act_greedy behind ONE entry point with a caller workspace, so that actors of the
+ * layered schedule (hidden 65..256, any depth) can act too: eps == 0 samples Categorical(logits), eps in (0, 1] samples COMA's
+ * mixture, eps < 0 takes the argmax.  Same Philox keying (seed, row_offset + row, t) for every shape.  The query is 0 for
+ * shapes the fused kernel covers. */
+extern "C" size_t cm_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions) {
+    return wide_shape(hidden, n_hidden_layers) ? wide_ws(rows, din, hidden, n_hidden_layers, n_actions, false, true).total * sizeof(float) : 0;
+}
+
+extern "C" int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                                int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions, const float* params,
+                                double eps, uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp,
+                                int64_t out_stride, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    CM_REQUIRE(eps <= 1.0, "cm_policy_act_ws: eps=%g > 1", eps);
+    if (!wide_shape(hidden, n_hidden_layers)) {
+        if (eps < 0.0) return cm_policy_act_greedy(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_hidden_layers, n_actions,
+                                                   params, action, logp, out_stride, stream);
+        if (eps > 0.0) return cm_policy_act_eps(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_hidden_layers, n_actions,
+                                                params, eps, seed, row_offset, t, action, logp, out_stride, stream);
+        return cm_policy_act(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_hidden_layers, n_actions, params, seed,
+                             row_offset, t, action, logp, out_stride, stream);
+    }
+    if (rows <= 0) return 0;
+    MlpArgs a = {};
+    a.x = x; a.x_stride = x_row_stride; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.params = params; a.avail = avail; a.avail_stride = avail_row_stride; a.act_eps = (float)eps;
+    a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
+    return wide_act(a, ws, ws_bytes, (hipStream_t)stream, "cm_policy_act_ws");
 }
 
 /* Act for EVERY step of an episode in one launch when the observations do not depend on the actions (e.g. the shape

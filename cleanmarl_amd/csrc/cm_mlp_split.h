@@ -17,10 +17,15 @@ namespace {
 constexpr int RB = 8;  // row pairs per software-pipeline batch (16 rows)
 
 // wave w of the workgroup owns k-tiles {w, w+4, ...} (32 columns each); both 32-row halves of the 64 hidden units.
-template <int KTW>
+// GEN = false: the tuned layer-0 form (dZ0 row stride HP, X row stride din).  GEN = true (cm_mlp_wide.h): explicit row strides,
+// one or two 32-row halves of dZ.
+template <int KTW, bool GEN = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restrict__ dz0, const float* __restrict__ x,
                                                             long rows, int din, int H, long rows_per_wg,
-                                                            float* __restrict__ partial, int PS2, int col0) {
+                                                            float* __restrict__ partial, int PS2, int col0,
+                                                            int ldz_ = HP, long ldx_ = 0) {
+    const long ldz = GEN ? ldz_ : HP, ldx = GEN ? ldx_ : din;
+    const bool two = GEN ? (H > 32) : true;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const long row_lo = (long)blockIdx.x * rows_per_wg;
     const long row_hi = min(rows, row_lo + rows_per_wg);
@@ -42,10 +47,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restr
         for (int p = 0; p < RB; ++p) {
             const long row = base + 2 * p + h;
             const bool ok = row < row_hi;
-            A0[p] = ok ? dz0[row * HP + r] : 0.0f;
-            A1[p] = ok ? dz0[row * HP + 32 + r] : 0.0f;
+            A0[p] = ok ? dz0[row * ldz + r] : 0.0f;
+            A1[p] = (ok && two) ? dz0[row * ldz + 32 + r] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < KTW; ++j) B[p][j] = (ok && cok[j]) ? x[row * din + col[j]] : 0.0f;
+            for (int j = 0; j < KTW; ++j) B[p][j] = (ok && cok[j]) ? x[row * ldx + col[j]] : 0.0f;
         }
     };
     if (row_lo < row_hi) load(row_lo, a0, a1, b);
@@ -82,7 +87,9 @@ constexpr int DW0_GRID = 512;
 inline bool use_split(int din) { return (din + KC - 1) / KC > CM_WG2_MAX_NCH; }
 
 // dW[H x din] = dz0[rows][HP]^T X[rows][din]: per-workgroup partials -> out[H * din]
-inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H, float* part2, float* out, hipStream_t s, const char* who) {
+template <bool GEN = false>
+inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H, float* part2, float* out, hipStream_t s, const char* who,
+                     int ldz = HP, long ldx = 0) {
     long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
     rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
     const int grid2 = (int)((rows + rpw - 1) / rpw);
@@ -90,10 +97,10 @@ inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H
     for (int col0 = 0; col0 < din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
         const int nkt = (min(512, din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
         switch (ktw) {
-            case 1: hipLaunchKernelGGL((k_dw0_stream<1>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
-            case 2: hipLaunchKernelGGL((k_dw0_stream<2>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
-            case 3: hipLaunchKernelGGL((k_dw0_stream<3>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
-            default: hipLaunchKernelGGL((k_dw0_stream<4>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0); break;
+            case 1: hipLaunchKernelGGL((k_dw0_stream<1, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
+            case 2: hipLaunchKernelGGL((k_dw0_stream<2, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
+            case 3: hipLaunchKernelGGL((k_dw0_stream<3, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
+            default: hipLaunchKernelGGL((k_dw0_stream<4, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
         }
     }
     CM_CHECK_LAUNCH(who);

@@ -1,0 +1,482 @@
+// cm_mlp_wide.h -- the LAYERED schedule: MLPs the fused kernel (cm_mlp_kernel.h) does not cover, i.e. hidden widths 65..256
+// (the reference's COMA critic defaults to 128, cleanmarl/coma_multienvs.py:35) or more than two hidden->hidden layers.
+//
+// The fused kernel keeps a 64-wide network resident in LDS; a 128..256-wide one does not fit next to its activations, so this
+// schedule runs layer by layer with activations in HBM (caller's workspace; 288 GB makes rows x 256 floats per layer cheap):
+//   forward   act_0 = relu(X W0^T + b0), act_l = relu(act_{l-1} Wl^T + bl), out = act_L Wout^T + bout      k_wide_gemm
+//   loss      per-row head math of the four training modes (same formulas as the fused epilogue)           k_wide_loss<MODE>
+//   backward  dW = dZ^T A (k_dw0_stream, the streaming MFMA GEMM of the split schedule, one 64-unit slab at a time),
+//             db = column sums (k_wide_colsum), dZ_{l} = (dZ_{l+1} W) .* relu'(act_l) (k_wide_gemm on a transposed weight copy)
+// Same MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) and the same deterministic
+// per-workgroup-partials + ordered-reduce pattern as the fused path.  HBM-bound by design (every activation makes a round trip);
+// it exists so that every width the reference's CLI accepts up to 256 runs, not to be the fast path.
+#pragma once
+#include "cm_mlp_split.h"
+
+namespace {
+
+constexpr int WT_M = 128;   // rows per workgroup tile (4 waves x 32 rows)
+constexpr int WT_K = 32;    // contraction chunk
+constexpr int WT_LD = 36;   // LDS row stride: 16-lane groups of ds_read_b128 down a column of rows hit 64 distinct banks
+constexpr int WIDE_HMAX = 256;
+enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2 };
+
+inline bool wide_shape(int H, int L) { return H > HP || L > LMAX; }
+inline int wide_hs(int H) { return (H + 63) / 64 * 64; }  // activation row stride (zero padded; whole 64-unit slabs)
+
+// Y[r][n] = epi( sum_k X[r][k] * W[n][k] ),  n < N <= 32 * NJ, k < K.  Columns N..ncols-1 of Y are written as zeros.
+// Any k permutation is a valid contraction order as long as both operands use it: lane (lc, h) takes k = 16h + kk at step kk, so
+// its 16 operands of a chunk are contiguous in LDS (4 x ds_read_b128).
+template <int NJ, int EPI>
+__global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const float* __restrict__ X, long ldx, long rows, int K,
+                                                           const float* __restrict__ W, int ldw, int N,
+                                                           const float* __restrict__ bias, const uint8_t* __restrict__ avail, long lda,
+                                                           const float* __restrict__ gate, long ldg,
+                                                           float* __restrict__ Y, long ldy, int ncols, int vecx, int vecw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Ws = smem + WT_M * WT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 31, h = lane >> 5;
+    const int lr = tid >> 3, lk = 4 * (tid & 7);  // loader: row lr + 32 i, floats lk..lk+3 of the chunk
+    const int nk = (K + WT_K - 1) / WT_K;
+    const long ntiles = (rows + WT_M - 1) / WT_M;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * WT_M;
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[j][g] = 0.0f;
+        float4 xr[4], wr[NJ];
+        auto load = [&](int c) {
+            const int k0 = c * WT_K + lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = row0 + lr + 32 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows) {
+                    const float* p = X + row * ldx + k0;
+                    if (vecx) { if (k0 < K) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (k0 < K) v.x = p[0];
+                        if (k0 + 1 < K) v.y = p[1];
+                        if (k0 + 2 < K) v.z = p[2];
+                        if (k0 + 3 < K) v.w = p[3];
+                    }
+                }
+                xr[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int n = lr + 32 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < N) {
+                    const float* p = W + (long)n * ldw + k0;
+                    if (vecw) { if (k0 < K) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (k0 < K) v.x = p[0];
+                        if (k0 + 1 < K) v.y = p[1];
+                        if (k0 + 2 < K) v.z = p[2];
+                        if (k0 + 3 < K) v.w = p[3];
+                    }
+                }
+                wr[i] = v;
+            }
+        };
+        load(0);
+        for (int c = 0; c < nk; ++c) {
+            __syncthreads();  // the previous chunk's (or tile's) readers are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Xs + (lr + 32 * i) * WT_LD + lk) = xr[i];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) *reinterpret_cast<float4*>(Ws + (lr + 32 * i) * WT_LD + lk) = wr[i];
+            __syncthreads();
+            if (c + 1 < nk) load(c + 1);  // in flight under this chunk's MFMAs
+            float a[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + (32 * wave + lc) * WT_LD + 16 * h + 4 * q);
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float b[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(Ws + (32 * j + lc) * WT_LD + 16 * h + 4 * q);
+                    b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc[j] = mfma32(a[kk], b[kk], acc[j]);
+            }
+        }
+        // epilogue: acc[j][g] = Y[row0 + 32 wave + (g&3) + 8 (g>>2) + 4h][32 j + lc]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = 32 * j + lc;
+            const bool cv = col < N;
+            const float bv = (EPI != EPI_GATE && cv) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long row = row0 + 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (row < rows && col < ncols) {
+                    float v = acc[j][g] + bv;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+                    if (EPI == EPI_BIAS && avail && cv && !avail[row * lda + col]) v = -1e9f;  // masked_fill(~avail, -1e9)
+                    if (EPI == EPI_GATE) v = (cv && gate[row * ldg + col] > 0.0f) ? v : 0.0f;
+                    Y[row * ldy + col] = cv ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int EPI>
+inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W, int ldw, int N, const float* bias,
+                      const uint8_t* avail, long lda, const float* gate, long ldg, float* Y, long ldy, int ncols, hipStream_t s) {
+    const int nj = (max(N, ncols) + 31) / 32;
+    const int vecx = (ldx % 4 == 0 && K % 4 == 0 && al16(X)) ? 1 : 0;
+    const int vecw = (ldw % 4 == 0 && K % 4 == 0 && al16(W)) ? 1 : 0;
+    const long ntiles = (rows + WT_M - 1) / WT_M;
+    const int grid = (int)min(ntiles, 512L);
+#define CM_WIDE_CASE(NJ)                                                                                                        \
+    case NJ: {                                                                                                                  \
+        const size_t lds = (size_t)(WT_M + 32 * NJ) * WT_LD * sizeof(float);                                                    \
+        hipLaunchKernelGGL((k_wide_gemm<NJ, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail, \
+                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw);                                                               \
+    } break;
+    switch (nj) {
+        CM_WIDE_CASE(1) CM_WIDE_CASE(2) CM_WIDE_CASE(3) CM_WIDE_CASE(4) CM_WIDE_CASE(5) CM_WIDE_CASE(6) CM_WIDE_CASE(7)
+        default: { constexpr int NJ8 = 8;
+            const size_t lds = (size_t)(WT_M + 32 * NJ8) * WT_LD * sizeof(float);
+            hipLaunchKernelGGL((k_wide_gemm<NJ8, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail,
+                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw);
+        } break;
+    }
+#undef CM_WIDE_CASE
+}
+
+// Wt[k][n] = W[n][k] (n < N, k < K), row stride ldt >= N, columns N..ldt-1 zeroed
+__global__ void k_wide_transpose(const float* __restrict__ W, int N, int K, float* __restrict__ Wt, int ldt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * ldt) return;
+    const int k = i / ldt, n = i - k * ldt;
+    Wt[i] = n < N ? W[n * K + k] : 0.0f;
+}
+
+// partial[wg][c] = sum over the workgroup's rows of Z[row][c], c < N (N <= 256); 256 threads = NC columns x 256/NC row groups
+constexpr int CS_GRID = 1024;
+__global__ __launch_bounds__(NTHREADS) void k_wide_colsum(const float* __restrict__ Z, long ldz, long rows, int N, int NC,
+                                                          long rows_per_wg, float* __restrict__ partial) {
+    __shared__ float sh[NTHREADS];
+    const int c = threadIdx.x % NC, rg = threadIdx.x / NC, RG = NTHREADS / NC;
+    const long lo = (long)blockIdx.x * rows_per_wg, hi = min(rows, lo + rows_per_wg);
+    float s = 0.0f;
+    if (c < N)
+        for (long r = lo + rg; r < hi; r += RG) s += Z[r * ldz + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < RG; ++g) s += sh[g * NC + c];
+        partial[(long)blockIdx.x * NC + c] = s;
+    }
+}
+
+inline int wide_colsum(const float* Z, long ldz, long rows, int N, float* partial, float* out, hipStream_t s) {
+    int NC = 32;
+    while (NC < N) NC *= 2;
+    long rpw = (rows + CS_GRID - 1) / CS_GRID;
+    if (rpw < 64) rpw = 64;
+    const int grid = (int)((rows + rpw - 1) / rpw);
+    hipLaunchKernelGGL(k_wide_colsum, dim3(grid), dim3(NTHREADS), 0, s, Z, ldz, rows, N, NC, rpw, partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((N + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, partial, grid, NC, 0, N, out);
+    return 0;
+}
+
+// ---- per-row loss heads: one thread per row, logits in out[row][32] -> d(loss)/d(logits) written in place; statistics as
+// per-workgroup partials [grid][8] = {pg, entropy, kl, clipfrac, value loss, count, 0, 0}.  Formulas: the fused epilogue's
+// (cm_mlp_kernel.h; cleanmarl/mappo_multienvs.py:527-576, cleanmarl/coma_multienvs.py:620-631, :649-676).
+constexpr int LOSS_GRID = 2048;
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* __restrict__ out, float* __restrict__ partial) {
+    __shared__ float red[6][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dout = a.dout;
+    const int Aseq = (MODE == M_CRITIC && !a.per_agent) ? 1 : a.A;
+    const float invA = 1.0f / (float)a.A;
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_vl = 0.f, st_cnt = 0.f;
+    for (long row = (long)blockIdx.x * NTHREADS + tid; row < a.rows; row += (long)gridDim.x * NTHREADS) {
+        const long seq = row / a.T;
+        const int t = (int)(row - seq * a.T);
+        const int e = (int)(seq / Aseq), ag = (int)(seq - (long)e * Aseq);
+        const bool valid = t < a.ep_len[e];
+        float* z = out + row * KMAX;
+        if (MODE == M_CRITIC) {
+            float d = 0.0f;
+            if (valid) {
+                const float v = z[0];
+                if (a.per_agent) {
+                    const float df = v - a.ret[row];
+                    st_vl += invA * df * df;
+                    d = 2.0f * invA * df;
+                    if (ag == 0) st_cnt += 1.0f;
+                } else {
+                    float sd = 0.0f, sq = 0.0f;
+                    for (int q = 0; q < a.A; ++q) {
+                        const float df = v - a.ret[((long)e * a.A + q) * a.T + t];
+                        sd += df; sq += df * df;
+                    }
+                    st_vl += invA * sq;
+                    d = 2.0f * invA * sd;
+                    st_cnt += 1.0f;
+                }
+            }
+            z[0] = d;
+            continue;
+        }
+        const int act = a.action[row];
+        if (MODE == M_QCRITIC) {
+            const float df = z[act] - a.ret[row];
+            if (valid) {
+                st_vl += invA * df * df;
+                if (ag == 0) st_cnt += 1.0f;
+            }
+            for (int k = 0; k < dout; ++k) z[k] = (valid && k == act) ? 2.0f * invA * df : 0.0f;
+            continue;
+        }
+        // actors: logits were masked (-1e9) by the head GEMM's epilogue
+        float zr[KMAX], p[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { zr[k] = k < dout ? z[k] : -INFINITY; m = fmaxf(m, zr[k]); }
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { p[k] = k < dout ? expf(zr[k] - m) : 0.0f; s += p[k]; }
+        const float rs = 1.0f / s;
+        const float advv = a.adv[row];
+        if (MODE == M_ACTOR) {
+            const float lse = m + logf(s);
+            float ent = 0.0f, lpa = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < dout) {
+                    const float lp = zr[k] - lse;
+                    p[k] *= rs;
+                    ent -= p[k] * lp;
+                    if (k == act) lpa = lp;
+                }
+            const float log_ratio = lpa - a.logp_old[row];
+            const float ratio = expf(log_ratio);
+            const float pg1 = advv * ratio;
+            const float pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+            const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+            float g;  // d min(pg1, pg2) / d ratio with torch's tie rule (half the gradient to each operand)
+            if (pg1 < pg2) g = advv;
+            else if (pg1 > pg2) g = inr ? advv : 0.0f;
+            else g = 0.5f * advv + (inr ? 0.5f * advv : 0.0f);
+            if (valid) {
+                st_pg += invA * fminf(pg1, pg2);
+                st_ent += invA * ent;
+                st_kl += invA * ((ratio - 1.0f) - log_ratio);
+                st_clip += (fabsf(ratio - 1.0f) > a.clip_eps) ? invA : 0.0f;
+                if (ag == 0) st_cnt += 1.0f;
+            }
+            const float gr = g * ratio;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < dout) {
+                    const float lp = zr[k] - lse;
+                    float d = invA * (-gr * ((k == act ? 1.0f : 0.0f) - p[k]) + a.ent_coef * p[k] * (lp + ent));
+                    if (!valid || zr[k] <= -5e8f) d = 0.0f;  // padded rows; masked_fill blocks the gradient
+                    z[k] = d;
+                }
+        } else {  // M_COMA_ACTOR
+            const float invK = 1.0f / (float)dout;
+            float lq[KMAX];
+            float ent = 0.0f, lpa = 0.0f, pa = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                lq[k] = 0.0f;
+                if (k < dout) {
+                    p[k] *= rs;
+                    lq[k] = logf(p[k] + 1e-8f);
+                    ent -= p[k] * lq[k];
+                    if (k == act) { lpa = lq[k]; pa = p[k]; }
+                }
+            }
+            ent *= invK;
+            if (valid) {
+                st_pg += lpa * advv;
+                st_ent += ent;
+                if (ag == 0) st_cnt += 1.0f;
+            }
+            float gbar = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < dout) {
+                    float gk = a.ent_coef * invK * (lq[k] + p[k] / (p[k] + 1e-8f));
+                    if (k == act) gk -= advv / (pa + 1e-8f);
+                    lq[k] = gk;
+                    gbar += gk * p[k];
+                }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < dout) {
+                    float d = p[k] * (lq[k] - gbar);
+                    if (!valid || zr[k] <= -5e8f) d = 0.0f;
+                    z[k] = d;
+                }
+        }
+    }
+    float sv[6] = {st_pg, st_ent, st_kl, st_clip, st_vl, st_cnt};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float v = cm_wave_sum(sv[i]);
+        if (lane == 0) red[i][wave] = v;
+    }
+    __syncthreads();
+    if (tid < CM_NUM_STATS) partial[(long)blockIdx.x * CM_NUM_STATS + tid] = tid < 6 ? red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3] : 0.0f;
+}
+
+// ---- workspace carve (floats)
+struct WideWs { size_t act, dz, out, wt, part, total; int Hs; };
+inline WideWs wide_ws(long rows, int din, int H, int L, int dout, bool train, bool with_out = false) {
+    WideWs w; size_t p = 0;
+    w.Hs = wide_hs(H);
+    const size_t plane = ((size_t)rows * w.Hs + 63) / 64 * 64;
+    w.act = p; p += (train ? (size_t)(L + 1) : 2) * plane;  // forward only: two ping-pong planes
+    w.dz = p; if (train) p += 2 * plane;
+    w.out = p; if (train || with_out) p += ((size_t)rows * KMAX + 63) / 64 * 64;
+    w.wt = p; if (train) p += (size_t)WIDE_HMAX * WIDE_HMAX;
+    const int kmax = max(din, w.Hs);
+    w.part = p;
+    if (train) p += max((size_t)DW0_GRID * 64 * kmax, max((size_t)CS_GRID * WIDE_HMAX, (size_t)LOSS_GRID * CM_NUM_STATS));
+    w.total = p;
+    return w;
+}
+inline size_t wide_ws_bytes(long rows, int din, int H, int L, int dout, bool train) { return wide_ws(rows, din, H, L, dout, train).total * sizeof(float); }
+
+inline int wide_check(const char* who, int din, int H, int L, int dout) {
+    CM_REQUIRE(din > 0 && H > 0 && L >= 0 && dout > 0, "%s: bad dims din=%d H=%d L=%d dout=%d", who, din, H, L, dout);
+    CM_REQUIRE(H <= WIDE_HMAX, "%s: hidden_dim=%d > %d is not supported by this build", who, H, WIDE_HMAX);
+    CM_REQUIRE(dout <= KMAX, "%s: output width %d > %d is not supported by this build", who, dout, KMAX);
+    return 0;
+}
+
+// forward into act planes; returns the last hidden activation plane index through *last.  y (ld ldy, ncols) receives the head.
+inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bool train, float* y, long ldy, int ncols, hipStream_t s,
+                               const char* who, int* last) {
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
+    const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
+    auto act = [&](int l) { return wsf + w.act + (size_t)(train ? l : (l & 1)) * plane; };
+    wide_gemm<EPI_BIAS_RELU>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, a.params + off.b0, nullptr, 0, nullptr, 0,
+                             act(0), w.Hs, w.Hs, s);
+    for (int l = 1; l <= a.L; ++l)
+        wide_gemm<EPI_BIAS_RELU>(act(l - 1), w.Hs, a.rows, a.H, a.params + off.Wl(l - 1), a.H, a.H, a.params + off.bl(l - 1), nullptr, 0,
+                                 nullptr, 0, act(l), w.Hs, w.Hs, s);
+    wide_gemm<EPI_BIAS>(act(a.L), w.Hs, a.rows, a.H, a.params + off.Wout, a.H, a.dout, a.params + off.bout, a.avail, a.avail_stride, nullptr, 0, y,
+                        ldy, ncols, s);
+    CM_CHECK_LAUNCH(who);
+    *last = a.L;
+    return 0;
+}
+
+// cm_mlp_forward for wide shapes: y[rows][dout]
+inline int wide_forward(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+    if (int rc = wide_check(who, a.din, a.H, a.L, a.dout)) return rc;
+    const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, false);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
+    int last;
+    return wide_forward_layers(a, (float*)ws, w, false, a.y, a.dout, a.dout, s, who, &last);
+}
+
+// Actor.act for wide shapes: layered forward to masked logits [rows][KMAX] in the workspace, then one thread per row draws with the
+// SAME Philox keying and samplers as the fused M_ACT kernel (eps > 0: COMA's mixed sampling, eps < 0: greedy)
+__global__ void k_wide_sample(const float* __restrict__ logits, long rows, int K, unsigned long long seed, long row_offset, int t,
+                              float eps, int* __restrict__ action, float* __restrict__ logp, long out_stride) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const unsigned long long gr = (unsigned long long)(row_offset + row);
+    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float* z = logits + row * KMAX;
+    int chosen; float lp;
+    if (eps < 0.0f) cm_categorical_greedy(z, K, &chosen, &lp);
+    else if (eps > 0.0f) cm_categorical_sample_eps(z, K, cm_u01(rnd.x), eps, &chosen, &lp);
+    else cm_categorical_sample(z, K, cm_u01(rnd.x), &chosen, &lp);
+    action[row * out_stride] = chosen;
+    logp[row * out_stride] = lp;
+}
+
+inline int wide_act(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+    if (int rc = wide_check(who, a.din, a.H, a.L, a.dout)) return rc;
+    const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, false, true);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
+    float* out = (float*)ws + w.out;
+    int last;
+    if (int rc = wide_forward_layers(a, (float*)ws, w, false, out, KMAX, KMAX, s, who, &last)) return rc;
+    hipLaunchKernelGGL(k_wide_sample, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, out, a.rows, a.dout, a.seed, a.row_offset, a.t,
+                       a.act_eps, a.action_out, a.logp_out, a.out_stride);
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+
+// training pass of MODE over a wide MLP: grad_and_stats[P + 8]
+template <int MODE>
+inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+    if (int rc = wide_check(who, a.din, a.H, a.L, a.dout)) return rc;
+    const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, true);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
+    float* wsf = (float*)ws;
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
+    const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
+    auto act = [&](int l) { return wsf + w.act + (size_t)l * plane; };
+    float* out = wsf + w.out;
+    float* part = wsf + w.part;
+    float* wt = wsf + w.wt;
+    const int H = a.H, Hs = w.Hs;
+    int last;
+    if (int rc = wide_forward_layers(a, wsf, w, true, out, KMAX, KMAX, s, who, &last)) return rc;
+    // ---- loss heads: logits -> dlogits in place, statistics
+    {
+        const int grid = (int)min((a.rows + NTHREADS - 1) / NTHREADS, (long)LOSS_GRID);
+        hipLaunchKernelGGL((k_wide_loss<MODE>), dim3(grid), dim3(NTHREADS), 0, s, a, out, part);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(RED_COLS * RED_GROUPS), 0, s, part, grid, CM_NUM_STATS, 0, CM_NUM_STATS,
+                           grad_and_stats + off.P);
+        CM_CHECK_LAUNCH(who);
+    }
+    // ---- head: dWout = dOut^T act_L, dbout, dZ_L = (dOut Wout) .* relu'(act_L)
+    if (int rc = stream_dw<true>(out, act(a.L), a.rows, H, a.dout, part, grad_and_stats + off.Wout, s, who, KMAX, Hs)) return rc;
+    wide_colsum(out, KMAX, a.rows, a.dout, part, grad_and_stats + off.bout, s);
+    float* dz = wsf + w.dz;
+    float* dz2 = dz + plane;
+    {
+        const int ldt = (a.dout + 3) / 4 * 4;
+        hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, a.params + off.Wout, a.dout, H, wt, ldt);
+        // Wt[h][k] = Wout[k][h]: N = H output columns, contraction over the ldt (zero padded) head outputs
+        wide_gemm<EPI_GATE>(out, KMAX, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(a.L), Hs, dz, Hs, Hs, s);
+        CM_CHECK_LAUNCH(who);
+    }
+    // ---- hidden layers, top down: dz = dZ_{l+1} (pre-activation gradient of act(l+1))
+    for (int l = a.L - 1; l >= 0; --l) {
+        for (int n0 = 0; n0 < H; n0 += 64)
+            if (int rc = stream_dw<true>(dz + n0, act(l), a.rows, H, min(64, H - n0), part, grad_and_stats + off.Wl(l) + (size_t)n0 * H, s, who,
+                                         Hs, Hs)) return rc;
+        wide_colsum(dz, Hs, a.rows, H, part, grad_and_stats + off.bl(l), s);
+        const int ldt = (H + 3) / 4 * 4;
+        hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, a.params + off.Wl(l), H, H, wt, ldt);
+        wide_gemm<EPI_GATE>(dz, Hs, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(l), Hs, dz2, Hs, Hs, s);
+        CM_CHECK_LAUNCH(who);
+        float* tmp = dz; dz = dz2; dz2 = tmp;
+    }
+    // ---- layer 0: dW0 = dZ_0^T X, db0
+    for (int n0 = 0; n0 < H; n0 += 64)
+        if (int rc = stream_dw<true>(dz + n0, a.x, a.rows, a.din, min(64, H - n0), part, grad_and_stats + off.W0 + (size_t)n0 * a.din, s, who,
+                                     Hs, a.x_stride)) return rc;
+    wide_colsum(dz, Hs, a.rows, H, part, grad_and_stats + off.b0, s);
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+
+}  // namespace

@@ -39,6 +39,7 @@ class HostActor:
         self.L, self.A, self.recurrent, self.dev = learner, n_agents, recurrent, device
         self.lib = N.load()
         self.calls = 0
+        self.ws = None
 
     def act(self, obs, avail, h=None, seed=0, greedy=False, eps=0.0):
         spec = self.L.actor_spec
@@ -48,25 +49,21 @@ class HostActor:
         action = torch.empty(rows, dtype=torch.int32, device=self.dev)
         logp = torch.empty(rows, dtype=torch.float32, device=self.dev)
         self.calls += 1
-        if greedy and not self.recurrent:  # argmax of the masked logits (build option; the reference always samples)
-            N.check(self.lib.cm_policy_act_greedy(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
-                                                  spec.dout, N.ptr(self.L.actor), N.ptr(action), N.ptr(logp), 1, N.stream_ptr()),
-                    "cm_policy_act_greedy")
-            return action.cpu().numpy(), logp.cpu().numpy(), h
         if self.recurrent:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
             N.check(self.lib.cm_gru_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
                                                N.ptr(self.L.actor), N.ptr(h), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
                                                N.stream_ptr()), "cm_gru_policy_act")
-        elif eps > 0.0:  # COMA exploration
-            N.check(self.lib.cm_policy_act_eps(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
-                                               spec.dout, N.ptr(self.L.actor), float(eps), seed, 0, self.calls, N.ptr(action),
-                                               N.ptr(logp), 1, N.stream_ptr()), "cm_policy_act_eps")
         else:
-            N.check(self.lib.cm_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
-                                           spec.dout, N.ptr(self.L.actor), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
-                                           N.stream_ptr()), "cm_policy_act")
+            # eps < 0: argmax of the masked logits (build option; the reference always samples); eps > 0: COMA exploration
+            mode = -1.0 if greedy else float(eps)
+            need = self.lib.cm_policy_act_workspace_bytes(rows, spec.din, spec.hidden, spec.n_layers, spec.dout)  # 0 unless layered
+            if need and (self.ws is None or self.ws.numel() < need):
+                self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            N.check(self.lib.cm_policy_act_ws(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
+                                              spec.dout, N.ptr(self.L.actor), mode, seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                              N.ptr(self.ws) if need else None, need, N.stream_ptr()), "cm_policy_act_ws")
         return action.cpu().numpy(), logp.cpu().numpy(), h
 
 

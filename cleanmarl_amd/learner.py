@@ -264,8 +264,9 @@ class PPOLearner:
             self.values = torch.empty(E, Av, T, dtype=torch.float32, device=self.device)
         x = b.state if self.algo == "mappo" else b.obs
         rows = E * T * Av
-        N.check(lib.cm_mlp_forward(N.ptr(x), rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
-                                   N.ptr(self.values), s), "cm_mlp_forward")
+        self._ensure_ws(b)
+        N.check(lib.cm_mlp_forward_ws(N.ptr(x), rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
+                                      N.ptr(self.values), N.ptr(self.ws), self.ws.numel(), s), "cm_mlp_forward_ws")
         N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
                                       hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
         if hp.normalize_advantage:
@@ -297,8 +298,10 @@ class PPOLearner:
     def _ensure_ws(self, b):
         a, c = self.actor_spec, self.critic_spec
         need = self.lib.cm_critic_workspace_bytes(b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, c.din, c.hidden, c.n_layers)
+        need = max(need, self.lib.cm_mlp_forward_workspace_bytes(b.E * b.T * (1 if self.algo == "mappo" else b.A), c.din, c.hidden,
+                                                                 c.n_layers, 1))
         if a.kind == "mlp":
-            need = max(need, self.lib.cm_mlp_train_workspace_bytes(a.din, a.hidden, a.n_layers, a.dout))
+            need = max(need, self.lib.cm_ppo_actor_workspace_bytes(b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout))
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
 

@@ -62,17 +62,15 @@ class SyntheticSpreadRollout:
         N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,
                                        self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+        need = lib.cm_policy_act_workspace_bytes(E * A, actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K)  # 0 unless layered
+        if need and (getattr(self, "act_ws", None) is None or self.act_ws.numel() < need):
+            self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = N.ptr(self.act_ws) if need else None
         for t in range(T):
-            if eps > 0.0:
-                N.check(lib.cm_policy_act_eps(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
-                                              actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps),
-                                              act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
-                        "cm_policy_act_eps")
-            else:
-                N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
-                                          actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat),
-                                          act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s),
-                        "cm_policy_act")
+            N.check(lib.cm_policy_act_ws(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A,
+                                         actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps),
+                                         act_seed, self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, ws, need, s),
+                    "cm_policy_act_ws")
             N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,
                                           N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
         self.episode += 1

@@ -68,6 +68,12 @@ int64_t cm_gru_param_count(int din, int hidden, int dout);
  * (replaces the 2*E*T single-row critic calls at :492-504). */
 int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                    const float* params, const uint8_t* avail, float* y, cm_stream_t stream);
+/* The same with a caller workspace, which also covers the LAYERED schedule: hidden widths 65..256 (the reference's COMA critic
+ * defaults to 128, cleanmarl/coma_multienvs.py:35) or more than two hidden->hidden layers run layer by layer with activations in
+ * the workspace (csrc/cm_mlp_wide.h).  The query returns 0 for shapes the fused kernel covers (ws may then be NULL). */
+size_t cm_mlp_forward_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout);
+int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                      const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream);
 
 /* ---- a4: Actor.act  (cleanmarl/mappo_multienvs.py:172-176, called at :409-414) ----
  * Fused actor MLP + masked_fill + Categorical sample + log_prob for `rows` (env,agent) pairs.
@@ -79,6 +85,14 @@ int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, in
                   int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions,
                   const float* params, uint64_t seed, int64_t row_offset, int t,
                   int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
+/* The three act entry points (cm_policy_act, cm_policy_act_eps, cm_policy_act_greedy) behind one with a caller workspace, which
+ * also covers actors of the layered schedule (hidden 65..256, any depth): eps == 0 samples Categorical(logits), eps in (0, 1]
+ * samples COMA's mixture, eps < 0 takes the argmax.  Same Philox keying for every shape; the query is 0 for fused shapes. */
+size_t cm_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions);
+int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                     int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions, const float* params,
+                     double eps, uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp,
+                     int64_t out_stride, void* ws, size_t ws_bytes, cm_stream_t stream);
 
 /* Greedy variant (argmax of the masked logits, first maximum; logp of that action): the build's --greedy_eval option --
  * the reference's eval loop (cleanmarl/mappo_multienvs.py:614-650) always samples. */
@@ -120,6 +134,8 @@ int cm_normalize(float* x, const int32_t* ep_len, int E, int A, int T,
  * but not by N = b_mask.sum()); the division by the (global) N happens in cm_grad_norm_clip_adam so
  * that env-sharded ranks can all-reduce the buffer first. */
 size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden_layers, int dout);
+/* rows-aware query (use this one): also sizes the layered schedule of wide / deep actors (hidden 65..256, any depth) */
+size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions);
 int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
                          const float* logp_old, const float* adv, const int32_t* ep_len,
                          int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,

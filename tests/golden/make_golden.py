@@ -264,6 +264,11 @@ CASES = {
                    dict(batch_size=5, actor_hidden_dim=64, actor_num_layers=2, critic_hidden_dim=32,
                         critic_num_layers=0, clip_gradients=10.0, optimizer="AdamW"),
                    dict(A=2, obs_raw=35, K=4, horizon=12, ragged=True, avail_p=1.0, state_dim=None, done_mode="truncate")),
+    # widths / depths beyond the fused 64-wide kernels -> the layered schedule (csrc/cm_mlp_wide.h)
+    "mappo_wide": ("mappo_multienvs.py",
+                   dict(batch_size=6, actor_hidden_dim=128, critic_hidden_dim=128, critic_num_layers=3, normalize_advantage=True,
+                        clip_gradients=0.5),
+                   dict(A=3, obs_raw=6, K=5, horizon=14, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
     "ippo_dense": ("ippo_multienvs.py",
                    dict(batch_size=8, critic_hidden_dim=64, actor_hidden_dim=64),
                    dict(A=4, obs_raw=10, K=6, horizon=14, ragged=False, avail_p=1.0, state_dim=17, done_mode="truncate")),
@@ -285,6 +290,10 @@ CASES = {
     "coma_tdlambda": ("coma_multienvs.py",
                       dict(batch_size=6, actor_hidden_dim=64, critic_hidden_dim=64, clip_gradients=0.5, normalize_return=True),
                       dict(A=3, obs_raw=6, K=5, horizon=15, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
+    # the reference's DEFAULT critic width (128): layered schedule on the materialised critic input
+    "coma_default_width": ("coma_multienvs.py",
+                           dict(batch_size=5, clip_gradients=0.5),
+                           dict(A=3, obs_raw=6, K=5, horizon=13, ragged=True, avail_p=0.8, state_dim=None, done_mode="done")),
     "coma_nstep": ("coma_multienvs.py",
                    dict(batch_size=5, actor_hidden_dim=32, critic_hidden_dim=64, use_tdlamda=False, nsteps=3,
                         normalize_advantage=False, normalize_reward=True),

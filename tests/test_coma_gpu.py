@@ -36,7 +36,7 @@ def _learner(batch, ap, cp, hp, dev, reward=None, target=None):
     return L, b
 
 
-@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep"])
+@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep", "coma_default_width"])
 def test_coma_update_matches_reference_golden(golden_dir, name):
     from oracle import coma as C
     batch, ap, cp, hp, z = C.load_golden(os.path.join(golden_dir, name + ".npz"))
@@ -184,12 +184,17 @@ def test_coma_scripts_run_and_log_reference_tags(script, env_type, tmp_path, mon
     assert eps[0] == 0.5 and eps == sorted(eps, reverse=True) and abs(eps[1] - (0.5 + (0.002 - 0.5) / 750)) < 1e-12
 
 
-def test_coma_default_critic_width_fails_loudly(tmp_path, monkeypatch):
+def test_coma_reference_default_critic_width_runs_and_wider_than_256_fails_loudly(tmp_path, monkeypatch):
+    """--critic_hidden_dim defaults to 128 in the reference (coma_multienvs.py:35): layered schedule (csrc/cm_mlp_wide.h)."""
+    import math
     from cleanmarl_amd import _native as N
     from cleanmarl_amd.coma_driver import run
     monkeypatch.chdir(tmp_path)
-    with pytest.raises(N.NativeError, match="hidden_dim=128"):
-        run("coma_multienvs", ["--env_type=synthetic", "--batch_size=2", "--synthetic_steps=5", "--total_timesteps=10"])
+    out = run("coma_multienvs", ["--env_type=synthetic", "--batch_size=2", "--synthetic_steps=5", "--total_timesteps=30"])
+    assert out["training_step"] >= 1 and all(math.isfinite(v) for _, v, _ in out["history"])
+    with pytest.raises(N.NativeError, match="hidden_dim=300"):
+        run("coma_multienvs", ["--env_type=synthetic", "--batch_size=2", "--synthetic_steps=5", "--total_timesteps=10",
+                               "--critic_hidden_dim=300"])
 
 
 @pytest.mark.parametrize("E,A,T,Do,Ds,K,H,L", [(9, 3, 11, 10, 14, 5, 64, 1), (6, 5, 9, 40, 200, 12, 48, 2), (40, 8, 16, 56, 384, 5, 64, 1),

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # BASELINE.json north_star: returns / advantages / losses within 1e-4 fp32
 
-MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"),
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"),
              ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
 
 
@@ -92,6 +92,12 @@ def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
     ("ippo", 12, 10, 40, 115, 243, 17, 64, 1),  # config-4 shapes (2 chunks, 17 actions, avail masks)
     ("mappo", 9, 2, 17, 70, 140, 6, 32, 2),     # H=32 padded to 64, 2 hidden layers, 2/3 chunks
     ("ippo", 5, 3, 8, 7, 11, 3, 48, 0),         # no hidden->hidden layer, odd H
+    # the layered schedule (csrc/cm_mlp_wide.h): wider than 64 units or deeper than 2 hidden->hidden layers
+    ("mappo", 21, 3, 19, 21, 54, 5, 128, 1),    # the reference's COMA-critic default width
+    ("ippo", 12, 4, 15, 37, 50, 17, 96, 3),     # 1.5 slabs of 64 units, 3 hidden layers, odd input width (scalar loads), 17 actions
+    ("mappo", 9, 2, 17, 70, 140, 6, 200, 0),    # no hidden->hidden layer, 200 units
+    ("mappo", 7, 3, 11, 21, 54, 5, 32, 4),      # narrow but deep
+    ("mappo", 5, 2, 300, 24, 48, 5, 256, 2),    # widest supported, several row tiles
 ])
 def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
     _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
@@ -195,6 +201,23 @@ def test_mlp_forward_matches_oracle():
         N.check(lib.cm_mlp_forward(N.ptr(d_x), rows, din, H, L, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.stream_ptr()), "fwd")
         ref = R.actor_logits(p, x, avail)
         assert _err(y.cpu().numpy(), ref.numpy()) <= TOL
+    # layered schedule through the workspace entry point (which forwards narrow shapes to the fused kernel with ws = NULL)
+    for (rows, din, H, L, dout) in [(1000, 384, 128, 1, 1), (130, 21, 256, 2, 5), (77, 115, 100, 3, 17), (300, 56, 64, 1, 5), (1, 9, 65, 0, 32)]:
+        spec = NetSpec(din, H, L, dout)
+        p = init_params_like_torch(spec)
+        x = torch.randn(rows, din)
+        avail = torch.rand(rows, dout) < 0.6
+        y = torch.empty(rows, dout, device=dev)
+        d_x, d_p, d_a = x.to(dev), flatten_params(p, dev), avail.to(torch.uint8).to(dev)
+        need = lib.cm_mlp_forward_workspace_bytes(rows, din, H, L, dout)
+        assert (need == 0) == (H <= 64 and L <= 2)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        N.check(lib.cm_mlp_forward_ws(N.ptr(d_x), rows, din, H, L, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.ptr(ws) if need else None,
+                                      need, N.stream_ptr()), "fwd_ws")
+        assert _err(y.cpu().numpy(), R.actor_logits(p, x, avail).numpy()) <= TOL
+        if need:
+            assert lib.cm_mlp_forward_ws(N.ptr(d_x), rows, din, H, L, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.ptr(ws), need - 1,
+                                         N.stream_ptr()) != 0 and b"workspace too small" in lib.cm_last_error()
 
 
 def test_unsupported_shapes_fail_loudly():
@@ -265,6 +288,67 @@ def test_policy_act_matches_cpu_sampler():
     assert avail[:, :, t].reshape(E * A, K).numpy()[np.arange(E * A), a_gpu].all()  # never an unavailable action
     untouched = torch.ones(T, dtype=torch.bool); untouched[t] = False
     assert (action[:, :, untouched] == -7).all() and (logp[:, :, untouched] == 9.0).all()
+
+
+@pytest.mark.parametrize("H,L", [(64, 1), (128, 1), (200, 3), (32, 4)])
+def test_policy_act_ws_matches_cpu_sampler_for_fused_and_layered_shapes(H, L):
+    """cm_policy_act_ws (the three act modes behind one entry point; layered schedule for wide / deep actors) vs oracle/sampling.py."""
+    import ctypes as C
+    from oracle import restatement as R
+    from oracle import sampling
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    E, A, T, Do, K, t = 29, 5, 7, 40, 9, 4
+    spec = NetSpec(Do, H, L, K)
+    p = init_params_like_torch(spec)
+    obs = torch.randn(E, A, T, Do)
+    avail = torch.rand(E, A, T, K) < 0.5
+    avail[..., 2] = True
+    d_obs, d_av, d_p = obs.to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
+    need = lib.cm_policy_act_workspace_bytes(E * A, Do, H, L, K)
+    assert (need == 0) == (H <= 64 and L <= 2)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    av_t = avail[:, :, t].reshape(E * A, K).numpy()
+    logits = R.actor_logits(p, obs[:, :, t].reshape(E * A, Do), avail[:, :, t].reshape(E * A, K)).numpy()
+    for eps in (0.0, 0.3, -1.0):
+        action = torch.full((E, A, T), -7, dtype=torch.int32, device=dev)
+        logp = torch.full((E, A, T), 9.0, device=dev)
+        N.check(lib.cm_policy_act_ws(C.c_void_p(d_obs.data_ptr() + 4 * t * Do), T * Do, C.c_void_p(d_av.data_ptr() + t * K), T * K,
+                                     E * A, Do, H, L, K, N.ptr(d_p), eps, 99, 1234, t, C.c_void_p(action.data_ptr() + 4 * t),
+                                     C.c_void_p(logp.data_ptr() + 4 * t), T, N.ptr(ws) if need else None, need, N.stream_ptr()), "act_ws")
+        a_gpu = action[:, :, t].reshape(-1).cpu().numpy()
+        lp_gpu = logp[:, :, t].reshape(-1).cpu().numpy()
+        if eps < 0:
+            a_ref = logits.argmax(-1)
+            lp_ref = (logits - np.log(np.exp(logits - logits.max(-1, keepdims=True)).sum(-1, keepdims=True)) - logits.max(-1, keepdims=True))[
+                np.arange(E * A), a_ref]
+        elif eps > 0:
+            a_ref, lp_ref, _ = sampling.act_eps(logits, av_t, eps, 99, 1234, t)
+        else:
+            a_ref, lp_ref, _ = sampling.act(logits, av_t, 99, 1234, t)
+        same = a_gpu == a_ref
+        assert same.mean() >= 0.99
+        assert np.abs(lp_gpu[same] - lp_ref[same]).max() <= TOL
+        assert av_t[np.arange(E * A), a_gpu].all()
+        untouched = torch.ones(T, dtype=torch.bool); untouched[t] = False
+        assert (action[:, :, untouched] == -7).all() and (logp[:, :, untouched] == 9.0).all()
+
+
+@pytest.mark.parametrize("env_type", ["synthetic", "synthetic_cpu"])
+def test_wide_actor_rollout_and_training_run_end_to_end(env_type, tmp_path, monkeypatch):
+    """--actor_hidden_dim=128 --critic_hidden_dim=128 --critic_num_layers=3 through the CLI driver: per-step rollout with the
+    layered act, layered value pass and updates; finite logs and a changed policy."""
+    import math
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    out = run("mappo_multienvs", [f"--env_type={env_type}", "--batch_size=8", "--synthetic_steps=10", "--total_timesteps=400",
+                                  "--actor_hidden_dim=128", "--critic_hidden_dim=128", "--critic_num_layers=3", "--log_every=1",
+                                  "--eval_steps=2", "--num_eval_ep=2"])
+    assert all(math.isfinite(v) for _, v, _ in out["history"])
+    assert out["training_step"] >= 3 and "eval/ep_reward" in {t for t, _, _ in out["history"]}
 
 
 @pytest.mark.parametrize("E,A,T,H,L", [(37, 8, 12, 64, 1), (50, 3, 9, 64, 1), (10, 5, 6, 32, 0)])

@@ -8,7 +8,7 @@ import torch
 
 from oracle import restatement as R
 
-MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"),
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"),
              ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
@@ -97,7 +97,7 @@ def test_c_td_lambda_matches_reference(golden_dir, name, algo):
     _close(ret, r2.numpy(), 1e-6)
 
 
-@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep"])
+@pytest.mark.parametrize("name", ["coma_tdlambda", "coma_nstep", "coma_default_width"])
 def test_coma_restatement_matches_reference_golden(golden_dir, name):
     """oracle/coma.py vs the unmodified cleanmarl/coma_multienvs.py (one iteration: targets, critic step, polyak, actor step)."""
     from oracle import coma as C
