@@ -80,16 +80,8 @@ class COMALearner:
         self.scratch = torch.empty(E, A, T, **f32)            # the scan's unused advantage output
         self.tstats = torch.zeros(T, 4, dtype=torch.float64, device=dev)
         rows = E * A * T
-        # critics wider than 64 units (the reference default is 128) or deeper than 2 hidden layers: the literal schedule
-        # (cm_coma_build_inputs -> layered MLP, csrc/cm_mlp_wide.h) instead of the factored 64-wide kernels
-        self.wide_critic = cs.hidden > 64 or cs.n_layers > 2
-        if self.wide_critic:
-            self.cin = torch.empty(E, A, T, cs.din, **f32)
-            need_c = max(lib.cm_mlp_split_workspace_bytes(rows, cs.din, cs.hidden, cs.n_layers, K),
-                         lib.cm_mlp_forward_workspace_bytes(rows, cs.din, cs.hidden, cs.n_layers, K))
-        else:
-            need_c = lib.cm_coma_critic_workspace_bytes(E, A, T, b.Ds, b.Do, K, cs.hidden, cs.n_layers, 1)
-        need = max(need_c, lib.cm_mlp_split_workspace_bytes(rows, a.din, a.hidden, a.n_layers, K),
+        need = max(lib.cm_coma_critic_workspace_bytes(E, A, T, b.Ds, b.Do, K, cs.hidden, cs.n_layers, 1),
+                   lib.cm_mlp_split_workspace_bytes(rows, a.din, a.hidden, a.n_layers, K),
                    lib.cm_mlp_forward_workspace_bytes(rows, a.din, a.hidden, a.n_layers, K),
                    lib.cm_coma_advantage_workspace_bytes(E, A, T), lib.cm_masked_moments_workspace_bytes(E, A, T))
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -109,13 +101,6 @@ class COMALearner:
     def _q(self, params, avail, out, b, s):
         """Q[E,A,T,K] of Critic(state, obs, actions) without materialising coma_inputs (factored layer 0, csrc/cm_coma.hip)."""
         cs = self.critic_spec
-        if self.wide_critic:
-            N.check(self.lib.cm_coma_build_inputs(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), b.E, b.A, b.T, b.Ds, b.Do, b.K,
-                                                  N.ptr(self.cin), s), "cm_coma_build_inputs")
-            N.check(self.lib.cm_mlp_forward_ws(N.ptr(self.cin), b.E * b.A * b.T, cs.din, cs.hidden, cs.n_layers, b.K, N.ptr(params),
-                                               N.ptr(avail) if avail is not None else None, N.ptr(out), N.ptr(self.ws),
-                                               self.ws.numel(), s), "cm_mlp_forward_ws")
-            return
         N.check(self.lib.cm_coma_q_forward(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(avail) if avail is not None else None,
                                            b.E, b.A, b.T, b.Ds, b.Do, b.K, cs.hidden, cs.n_layers, N.ptr(params), N.ptr(out),
                                            N.ptr(self.ws), self.ws.numel(), s), "cm_coma_q_forward")
@@ -148,16 +133,9 @@ class COMALearner:
         cs, a = self.critic_spec, self.actor_spec
         Pa, Pc = self.actor.numel(), self.critic.numel()
         # ---- critic step
-        if self.wide_critic:
-            N.check(lib.cm_coma_build_inputs(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), E, A, T, b.Ds, b.Do, K, N.ptr(self.cin), s),
-                    "cm_coma_build_inputs")
-            N.check(lib.cm_qcritic_fwd_bwd(N.ptr(self.cin), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, cs.din, cs.hidden,
-                                           cs.n_layers, K, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws), self.ws.numel(), s),
-                    "cm_qcritic_fwd_bwd")
-        else:
-            N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, b.Ds,
-                                               b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws),
-                                               self.ws.numel(), s), "cm_coma_critic_fwd_bwd")
+        N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, b.Ds,
+                                           b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws),
+                                           self.ws.numel(), s), "cm_coma_critic_fwd_bwd")
         dist.allreduce_sum_(self.g_critic, self.pg, self.world)
         self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
         self.training_step += 1

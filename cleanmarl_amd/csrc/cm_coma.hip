@@ -181,12 +181,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_linear_nt(const float* __restri
 // the transposed action block of W0 in LDS ([(A-1)K][64], conflict-free across lanes).
 __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S, const int* __restrict__ action,
                                                      const float* __restrict__ W0, int E, int A, int T, int H, int Dc, int Ds, int Do,
-                                                     int K, float* __restrict__ out) {
+                                                     int K, float* __restrict__ out, int h0, long ldS, long ldo) {
+    // h0 / ldS / ldo: this launch covers hidden units h0..h0+63 of S and out rows with strides ldS / ldo (fused path: 0, HP, HP;
+    // the layered schedule of wide critics runs one launch per 64-unit slab)
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int Da = (A - 1) * K;
     for (int i = threadIdx.x; i < Da * HP; i += 256) {
         const int c = i / HP, hh = i - c * HP;
-        tab[i] = hh < H ? W0[(long)hh * Dc + Ds + Do + c] : 0.0f;
+        tab[i] = h0 + hh < H ? W0[(long)(h0 + hh) * Dc + Ds + Do + c] : 0.0f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,14 +197,14 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
         const long e = et / T;
         const int t = (int)(et - e * T);
         const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
-        const float sv = S[et * HP + lane];
+        const float sv = S[et * ldS + h0 + lane];
         for (int a = 0; a < A; ++a) {
             float v = sv;
             for (int slot = 0; slot < A - 1; ++slot) {
                 const int j = slot < a ? slot : slot + 1;
                 v += tab[(slot * K + __shfl(u, j, 64)) * HP + lane];
             }
-            out[((e * A + a) * T + t) * HP + lane] = v;
+            out[((e * A + a) * T + t) * ldo + h0 + lane] = v;
         }
     }
 }
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
 constexpr int OH_MAXA = 32;
 constexpr int OH_NWAVES = 8192;  // upper bound of gather waves (= partial tables)
 __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict__ dz0, const int* __restrict__ action, int E, int A, int T,
-                                                         int K, int waves_per_block, float* __restrict__ dS, float* __restrict__ part) {
+                                                         int K, int waves_per_block, float* __restrict__ dS, float* __restrict__ part,
+                                                         int h0, long ldz, long ldS) {
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int Da = (A - 1) * K;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -237,9 +240,9 @@ __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict
 #pragma unroll
             for (int a = 0; a < OH_MAXA; ++a) {
                 z[a] = 0.0f;
-                if (a < A) { z[a] = dz0[((e * A + a) * T + t) * HP + lane]; tot += z[a]; }
+                if (a < A) { z[a] = dz0[((e * A + a) * T + t) * ldz + h0 + lane]; tot += z[a]; }
             }
-            dS[et * HP + lane] = tot;
+            dS[et * ldS + h0 + lane] = tot;
             float pre = 0.0f;  // sum_{a<j}
 #pragma unroll
             for (int j = 0; j < OH_MAXA; ++j) {
@@ -325,7 +328,115 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     CM_REQUIRE(A <= 64, "%s: n_agents=%d > 64 is not supported by the factored critic input", who, A);
     const long g = (et + 3) / 4;
     hipLaunchKernelGGL(k_coma_z0_add, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E, A, T, H,
-                       Dc, Ds, Do, K, wsf + w.z0);
+                       Dc, Ds, Do, K, wsf + w.z0, 0, (long)HP, (long)HP);
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+
+// ---- the same factoring on the layered schedule (cm_mlp_wide.h) for critics wider than 64 units / deeper than 2 hidden layers
+// (the reference default is 128): S, z0_add, dZ0 and dS have row stride Hs and the two lane-per-unit kernels run once per 64-unit slab.
+struct ComaWideWs { size_t pc, S, z0, dS, gc, gs, ga, part, train, total; int Hs; };
+inline ComaWideWs coma_wide_ws(int E, int A, int T, int Ds, int Do, int K, int H, int L, bool train) {
+    const long rows = (long)E * A * T, et = (long)E * T;
+    const int Da = (A - 1) * K, DaP = Da > 0 ? Da : 1;
+    const size_t Pc = (size_t)cm_mlp_param_count(Do, H, L, K);
+    ComaWideWs w; size_t p = 0;
+    w.Hs = wide_hs(H);
+    w.pc = p; p += al64(Pc);
+    w.S = p; p += al64((size_t)et * w.Hs);
+    w.z0 = p; p += al64((size_t)rows * w.Hs);
+    w.dS = w.gc = w.gs = w.ga = w.part = p;
+    if (train) {
+        w.dS = p; p += al64((size_t)et * w.Hs);
+        w.gc = p; p += al64(Pc + CM_NUM_STATS);
+        w.gs = p; p += al64((size_t)H * Ds);
+        w.ga = p; p += al64((size_t)H * DaP);
+        const size_t a1 = (size_t)DW0_GRID * 64 * Ds, a2 = (size_t)(OH_NWAVES + 1) * DaP * HP;
+        w.part = p; p += al64(a1 > a2 ? a1 : a2);
+    }
+    w.train = p; p += al64(wide_ws_bytes(rows, Do, H, L, K, train) / sizeof(float) + 1);
+    w.total = p;
+    return w;
+}
+
+inline int coma_wide_prepare(const float* state, const int32_t* action, int E, int A, int T, int Ds, int Do, int K, int H, int L,
+                             const float* params, float* wsf, const ComaWideWs& w, hipStream_t s, const char* who) {
+    const int Dc = Ds + Do + (A - 1) * K;
+    const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc);
+    hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
+    CM_CHECK_LAUNCH(who);
+    const long et = (long)E * T;
+    wide_gemm<EPI_NONE>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.S, w.Hs, w.Hs, s);  // S = state W0s^T
+    CM_CHECK_LAUNCH(who);
+    const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
+    CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
+    CM_REQUIRE(A <= OH_MAXA, "%s: n_agents=%d > %d is not supported by the factored critic input", who, A, OH_MAXA);
+    const long g = (et + 3) / 4;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        hipLaunchKernelGGL(k_coma_z0_add, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E,
+                           A, T, H, Dc, Ds, Do, K, wsf + w.z0, h0, (long)w.Hs, (long)w.Hs);
+        CM_CHECK_LAUNCH(who);
+    }
+    return 0;
+}
+
+inline int coma_wide_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
+                               int Ds, int Do, int K, int H, int L, const float* params, float* q, void* ws, size_t ws_bytes,
+                               hipStream_t s, const char* who) {
+    if (int rc = wide_check(who, Do, H, L, K)) return rc;
+    const ComaWideWs w = coma_wide_ws(E, A, T, Ds, Do, K, H, L, false);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
+    float* wsf = (float*)ws;
+    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who)) return rc;
+    MlpArgs a = {};
+    a.x = obs; a.x_stride = Do; a.rows = (long)E * A * T; a.din = Do; a.H = H; a.L = L; a.dout = K;
+    a.params = wsf + w.pc; a.avail = avail; a.avail_stride = K; a.y = q; a.z0_add = wsf + w.z0;
+    return wide_forward(a, wsf + w.train, (w.total - w.train) * sizeof(float), s, who);
+}
+
+inline int coma_wide_critic_fwd_bwd(const float* state, const float* obs, const int32_t* action, const float* target,
+                                    const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int K, int H, int L, const float* params,
+                                    float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+    if (int rc = wide_check(who, Do, H, L, K)) return rc;
+    const long rows = (long)E * A * T, et = (long)E * T;
+    if (int rc = check_rows(who, rows)) return rc;
+    const ComaWideWs w = coma_wide_ws(E, A, T, Ds, Do, K, H, L, true);
+    CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
+    float* wsf = (float*)ws;
+    const int Da = (A - 1) * K, Dc = Ds + Do + Da, DaP = Da > 0 ? Da : 1;
+    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who)) return rc;
+    MlpArgs a = {};
+    a.x = obs; a.x_stride = Do; a.rows = rows; a.din = Do; a.H = H; a.L = L; a.dout = K;
+    a.params = wsf + w.pc; a.action = action; a.ret = target; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
+    a.z0_add = wsf + w.z0;
+    float* dz0 = nullptr;
+    if (int rc = wide_train<M_QCRITIC>(a, wsf + w.gc, wsf + w.train, (w.total - w.train) * sizeof(float), s, who, &dz0)) return rc;
+    const size_t per_wave = (size_t)DaP * HP * sizeof(float);
+    CM_REQUIRE(per_wave <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the LDS table", who, Da);
+    int wpb = (int)((64 * 1024) / per_wave);
+    wpb = wpb > 4 ? 4 : wpb;
+    long blocks = (et + wpb - 1) / wpb;
+    const long cap = OH_NWAVES / wpb;
+    if (blocks > cap) blocks = cap;
+    float* gpart = wsf + w.part;
+    float* gred = gpart + (size_t)blocks * wpb * DaP * HP;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        const int hn = min(64, H - h0);
+        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, h0,
+                           (long)w.Hs, (long)w.Hs);
+        CM_CHECK_LAUNCH(who);
+        if (Da > 0) {
+            const int n = Da * HP;
+            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks * wpb), n, 0, n, gred);
+            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, hn, Da, wsf + w.ga + (size_t)h0 * Da);
+            CM_CHECK_LAUNCH(who);
+        }
+    }
+    for (int h0 = 0; h0 < H; h0 += 64)  // state block: dW0s = dS^T state
+        if (int rc = stream_dw<true>(wsf + w.dS + h0, state, et, Ds, min(64, H - h0), wsf + w.part, wsf + w.gs + (size_t)h0 * Ds, s, who, w.Hs, Ds))
+            return rc;
+    const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc) + CM_NUM_STATS;
+    hipLaunchKernelGGL(k_coma_scatter_grads, dim3(128), dim3(256), 0, s, wsf + w.gc, wsf + w.gs, wsf + w.ga, H, Dc, Ds, Do, rest, grad_and_stats);
     CM_CHECK_LAUNCH(who);
     return 0;
 }
@@ -432,14 +543,18 @@ extern "C" int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, con
 
 extern "C" size_t cm_coma_critic_workspace_bytes(int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
                                                  int train) {
+    if (wide_shape(hidden, n_hidden_layers)) return coma_wide_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, train != 0).total * sizeof(float);
     return coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, train != 0).total * sizeof(float);
 }
 
 extern "C" int cm_coma_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
                                  int Ds, int Do, int n_actions, int hidden, int n_hidden_layers, const float* params, float* q, void* ws,
                                  size_t ws_bytes, cm_stream_t stream) {
-    if (int rc = check_shapes("cm_coma_q_forward", Do, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_q_forward: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    if (wide_shape(hidden, n_hidden_layers))
+        return coma_wide_q_forward(state, obs, action, avail, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, q, ws, ws_bytes,
+                                   (hipStream_t)stream, "cm_coma_q_forward");
+    if (int rc = check_shapes("cm_coma_q_forward", Do, hidden, n_hidden_layers, n_actions)) return rc;
     const ComaWs w = coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, false);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "cm_coma_q_forward: workspace too small (%zu < %zu)", ws_bytes, w.total * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
@@ -459,8 +574,11 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
                                       int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
                                       cm_stream_t stream) {
     const char* who = "cm_coma_critic_fwd_bwd";
-    if (int rc = check_shapes(who, Do, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_critic_fwd_bwd: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    if (wide_shape(hidden, n_hidden_layers))
+        return coma_wide_critic_fwd_bwd(state, obs, action, target, ep_len, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params,
+                                        grad_and_stats, ws, ws_bytes, (hipStream_t)stream, who);
+    if (int rc = check_shapes(who, Do, hidden, n_hidden_layers, n_actions)) return rc;
     const long rows = (long)E * A * T;
     if (int rc = check_rows(who, rows)) return rc;
     const ComaWs w = coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, true);
@@ -488,7 +606,7 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
         if (blocks > cap) blocks = cap;
         float* gpart = wsf + w.part;                       // [blocks * wpb][Da][HP]
         float* gred = gpart + (size_t)blocks * wpb * DaP * HP;  // [Da][HP]
-        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart);
+        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, 0, (long)HP, (long)HP);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * HP;

@@ -6,7 +6,8 @@
 //   forward   act_0 = relu(X W0^T + b0), act_l = relu(act_{l-1} Wl^T + bl), out = act_L Wout^T + bout      k_wide_gemm
 //   loss      per-row head math of the four training modes (same formulas as the fused epilogue)           k_wide_loss<MODE>
 //   backward  dW = dZ^T A (k_dw0_stream, the streaming MFMA GEMM of the split schedule, one 64-unit slab at a time),
-//             db = column sums (k_wide_colsum), dZ_{l} = (dZ_{l+1} W) .* relu'(act_l) (k_wide_gemm on a transposed weight copy)
+//             dZ_{l} = (dZ_{l+1} W) .* relu'(act_l) (k_wide_gemm on a transposed weight copy; its epilogue also accumulates the
+//             column sums of dZ_l = the bias gradient of the layer below), db_out = k_wide_colsum
 // Same MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) and the same deterministic
 // per-workgroup-partials + ordered-reduce pattern as the fused path.  HBM-bound by design (every activation makes a round trip);
 // it exists so that every width the reference's CLI accepts up to 256 runs, not to be the fast path.
@@ -16,30 +17,42 @@
 namespace {
 
 constexpr int WT_M = 128;   // rows per workgroup tile (4 waves x 32 rows)
-constexpr int WT_K = 32;    // contraction chunk
-constexpr int WT_LD = 36;   // LDS row stride: 16-lane groups of ds_read_b128 down a column of rows hit 64 distinct banks
+#ifndef CM_WT_K
+#define CM_WT_K 32
+#endif
+constexpr int WT_K = CM_WT_K;      // contraction chunk (32 or 64)
+constexpr int WT_LD = WT_K + 4;    // LDS row stride (36 / 68): 16-lane groups of ds_read_b128 down a column of rows hit 64 distinct banks
+constexpr int WT_KQ = WT_K / 2;    // operands per lane and chunk (lane (lc, h) takes k = WT_KQ h + kk)
+constexpr int WT_TPR = WT_K / 4;   // loader threads per row (one float4 each)
+constexpr int WT_RPP = NTHREADS / WT_TPR;  // rows per loader pass
+constexpr int WT_XP = WT_M / WT_RPP;       // loader passes over the X tile
 constexpr int WIDE_HMAX = 256;
-enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2 };
+enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend
 
 inline bool wide_shape(int H, int L) { return H > HP || L > LMAX; }
 inline int wide_hs(int H) { return (H + 63) / 64 * 64; }  // activation row stride (zero padded; whole 64-unit slabs)
 
 // Y[r][n] = epi( sum_k X[r][k] * W[n][k] ),  n < N <= 32 * NJ, k < K.  Columns N..ncols-1 of Y are written as zeros.
-// Any k permutation is a valid contraction order as long as both operands use it: lane (lc, h) takes k = 16h + kk at step kk, so
-// its 16 operands of a chunk are contiguous in LDS (4 x ds_read_b128).
+// Any k permutation is a valid contraction order as long as both operands use it: lane (lc, h) takes k = WT_KQ h + kk at step
+// kk, so its WT_KQ operands of a chunk are contiguous in LDS (ds_read_b128).
 template <int NJ, int EPI>
 __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const float* __restrict__ X, long ldx, long rows, int K,
                                                            const float* __restrict__ W, int ldw, int N,
                                                            const float* __restrict__ bias, const uint8_t* __restrict__ avail, long lda,
                                                            const float* __restrict__ gate, long ldg,
-                                                           float* __restrict__ Y, long ldy, int ncols, int vecx, int vecw) {
+                                                           float* __restrict__ Y, long ldy, int ncols, int vecx, int vecw,
+                                                           float* __restrict__ colsum_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* Ws = smem + WT_M * WT_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 31, h = lane >> 5;
-    const int lr = tid >> 3, lk = 4 * (tid & 7);  // loader: row lr + 32 i, floats lk..lk+3 of the chunk
+    const int lr = tid / WT_TPR, lk = 4 * (tid % WT_TPR);  // loader: row lr + WT_RPP i, floats lk..lk+3 of the chunk
+    constexpr int WP = 32 * NJ / WT_RPP;                   // loader passes over the W tile
     const int nk = (K + WT_K - 1) / WT_K;
     const long ntiles = (rows + WT_M - 1) / WT_M;
+    float cs[NJ];  // EPI_GATE: column sums of the output (= the bias gradient of the layer below), over this workgroup's tiles
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cs[j] = 0.0f;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * WT_M;
         f32x16 acc[NJ];
@@ -47,12 +60,12 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[j][g] = 0.0f;
-        float4 xr[4], wr[NJ];
+        float4 xr[WT_XP], wr[WP];
         auto load = [&](int c) {
             const int k0 = c * WT_K + lk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long row = row0 + lr + 32 * i;
+            for (int i = 0; i < WT_XP; ++i) {
+                const long row = row0 + lr + WT_RPP * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < rows) {
                     const float* p = X + row * ldx + k0;
@@ -67,8 +80,8 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                 xr[i] = v;
             }
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) {
-                const int n = lr + 32 * i;
+            for (int i = 0; i < WP; ++i) {
+                const int n = lr + WT_RPP * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < N) {
                     const float* p = W + (long)n * ldw + k0;
@@ -87,27 +100,27 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
         for (int c = 0; c < nk; ++c) {
             __syncthreads();  // the previous chunk's (or tile's) readers are done
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Xs + (lr + 32 * i) * WT_LD + lk) = xr[i];
+            for (int i = 0; i < WT_XP; ++i) *reinterpret_cast<float4*>(Xs + (lr + WT_RPP * i) * WT_LD + lk) = xr[i];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) *reinterpret_cast<float4*>(Ws + (lr + 32 * i) * WT_LD + lk) = wr[i];
+            for (int i = 0; i < WP; ++i) *reinterpret_cast<float4*>(Ws + (lr + WT_RPP * i) * WT_LD + lk) = wr[i];
             __syncthreads();
             if (c + 1 < nk) load(c + 1);  // in flight under this chunk's MFMAs
-            float a[16];
+            float a[WT_KQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(Xs + (32 * wave + lc) * WT_LD + 16 * h + 4 * q);
+            for (int q = 0; q < WT_KQ / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + (32 * wave + lc) * WT_LD + WT_KQ * h + 4 * q);
                 a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float b[16];
+                float b[WT_KQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(Ws + (32 * j + lc) * WT_LD + 16 * h + 4 * q);
+                for (int q = 0; q < WT_KQ / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(Ws + (32 * j + lc) * WT_LD + WT_KQ * h + 4 * q);
                     b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
                 }
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) acc[j] = mfma32(a[kk], b[kk], acc[j]);
+                for (int kk = 0; kk < WT_KQ; ++kk) acc[j] = mfma32(a[kk], b[kk], acc[j]);
             }
         }
         // epilogue: acc[j][g] = Y[row0 + 32 wave + (g&3) + 8 (g>>2) + 4h][32 j + lc]
@@ -115,19 +128,33 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
         for (int j = 0; j < NJ; ++j) {
             const int col = 32 * j + lc;
             const bool cv = col < N;
-            const float bv = (EPI != EPI_GATE && cv) ? bias[col] : 0.0f;
+            const float bv = ((EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) && cv) ? bias[col] : 0.0f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const long row = row0 + 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
                 if (row < rows && col < ncols) {
                     float v = acc[j][g] + bv;
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.0f);
+                    if (EPI == EPI_BIAS_RELU) {
+                        if (gate && cv) v += gate[row * ldg + col];  // COMA's factored layer-0 addend
+                        v = fmaxf(v, 0.0f);
+                    }
                     if (EPI == EPI_BIAS && avail && cv && !avail[row * lda + col]) v = -1e9f;  // masked_fill(~avail, -1e9)
-                    if (EPI == EPI_GATE) v = (cv && gate[row * ldg + col] > 0.0f) ? v : 0.0f;
+                    if (EPI == EPI_GATE) { v = (cv && gate[row * ldg + col] > 0.0f) ? v : 0.0f; cs[j] += v; }
                     Y[row * ldy + col] = cv ? v : 0.0f;
                 }
             }
         }
+    }
+    if (EPI == EPI_GATE && colsum_part) {  // per-workgroup partial [32 NJ]: lanes h = 0/1 -> 4 waves, fixed order
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float o = __shfl_xor(cs[j], 32, 64);
+            if (h == 0) smem[wave * 32 * NJ + 32 * j + lc] = cs[j] + o;
+        }
+        __syncthreads();
+        for (int i = tid; i < 32 * NJ; i += NTHREADS)
+            colsum_part[(long)blockIdx.x * 32 * NJ + i] = (smem[i] + smem[32 * NJ + i]) + (smem[2 * 32 * NJ + i] + smem[3 * 32 * NJ + i]);
     }
 }
 
@@ -135,7 +162,8 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int EPI>
 inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W, int ldw, int N, const float* bias,
-                      const uint8_t* avail, long lda, const float* gate, long ldg, float* Y, long ldy, int ncols, hipStream_t s) {
+                      const uint8_t* avail, long lda, const float* gate, long ldg, float* Y, long ldy, int ncols, hipStream_t s,
+                      float* colsum_part = nullptr, float* colsum_out = nullptr) {
     const int nj = (max(N, ncols) + 31) / 32;
     const int vecx = (ldx % 4 == 0 && K % 4 == 0 && al16(X)) ? 1 : 0;
     const int vecw = (ldw % 4 == 0 && K % 4 == 0 && al16(W)) ? 1 : 0;
@@ -145,17 +173,20 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     case NJ: {                                                                                                                  \
         const size_t lds = (size_t)(WT_M + 32 * NJ) * WT_LD * sizeof(float);                                                    \
         hipLaunchKernelGGL((k_wide_gemm<NJ, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail, \
-                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw);                                                               \
+                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw, colsum_part);                                                  \
     } break;
     switch (nj) {
         CM_WIDE_CASE(1) CM_WIDE_CASE(2) CM_WIDE_CASE(3) CM_WIDE_CASE(4) CM_WIDE_CASE(5) CM_WIDE_CASE(6) CM_WIDE_CASE(7)
         default: { constexpr int NJ8 = 8;
             const size_t lds = (size_t)(WT_M + 32 * NJ8) * WT_LD * sizeof(float);
             hipLaunchKernelGGL((k_wide_gemm<NJ8, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail,
-                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw);
+                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw, colsum_part);
         } break;
     }
 #undef CM_WIDE_CASE
+    if (colsum_part)  // EPI_GATE only: fold the per-workgroup column sums (fixed order)
+        hipLaunchKernelGGL(k_reduce_partials, dim3((N + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, colsum_part, grid, 32 * nj, 0, N,
+                           colsum_out);
 }
 
 // Wt[k][n] = W[n][k] (n < N, k < K), row stride ldt >= N, columns N..ldt-1 zeroed
@@ -371,7 +402,7 @@ inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bo
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
     const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
     auto act = [&](int l) { return wsf + w.act + (size_t)(train ? l : (l & 1)) * plane; };
-    wide_gemm<EPI_BIAS_RELU>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, a.params + off.b0, nullptr, 0, nullptr, 0,
+    wide_gemm<EPI_BIAS_RELU>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, a.params + off.b0, nullptr, 0, a.z0_add, w.Hs,
                              act(0), w.Hs, w.Hs, s);
     for (int l = 1; l <= a.L; ++l)
         wide_gemm<EPI_BIAS_RELU>(act(l - 1), w.Hs, a.rows, a.H, a.params + off.Wl(l - 1), a.H, a.H, a.params + off.bl(l - 1), nullptr, 0,
@@ -423,8 +454,11 @@ inline int wide_act(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t s, 
 }
 
 // training pass of MODE over a wide MLP: grad_and_stats[P + 8]
+// a.z0_add (optional): [rows][Hs] addend of the layer-0 pre-activation; dz0_out (optional) receives the pointer to dZ_0 [rows][Hs]
+// inside the workspace (COMA's factored critic input needs both).
 template <int MODE>
-inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who,
+                      float** dz0_out = nullptr) {
     if (int rc = wide_check(who, a.din, a.H, a.L, a.dout)) return rc;
     const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, true);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
@@ -455,7 +489,9 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
         const int ldt = (a.dout + 3) / 4 * 4;
         hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, a.params + off.Wout, a.dout, H, wt, ldt);
         // Wt[h][k] = Wout[k][h]: N = H output columns, contraction over the ldt (zero padded) head outputs
-        wide_gemm<EPI_GATE>(out, KMAX, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(a.L), Hs, dz, Hs, Hs, s);
+        // the bias gradient of the layer that produced act(L) = column sums of dZ_L, accumulated in the GEMM's epilogue
+        wide_gemm<EPI_GATE>(out, KMAX, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(a.L), Hs, dz, Hs, Hs, s, part,
+                            grad_and_stats + (a.L >= 1 ? off.bl(a.L - 1) : off.b0));
         CM_CHECK_LAUNCH(who);
     }
     // ---- hidden layers, top down: dz = dZ_{l+1} (pre-activation gradient of act(l+1))
@@ -463,10 +499,10 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
         for (int n0 = 0; n0 < H; n0 += 64)
             if (int rc = stream_dw<true>(dz + n0, act(l), a.rows, H, min(64, H - n0), part, grad_and_stats + off.Wl(l) + (size_t)n0 * H, s, who,
                                          Hs, Hs)) return rc;
-        wide_colsum(dz, Hs, a.rows, H, part, grad_and_stats + off.bl(l), s);
         const int ldt = (H + 3) / 4 * 4;
         hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, a.params + off.Wl(l), H, H, wt, ldt);
-        wide_gemm<EPI_GATE>(dz, Hs, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(l), Hs, dz2, Hs, Hs, s);
+        wide_gemm<EPI_GATE>(dz, Hs, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(l), Hs, dz2, Hs, Hs, s, part,
+                            grad_and_stats + (l >= 1 ? off.bl(l - 1) : off.b0));
         CM_CHECK_LAUNCH(who);
         float* tmp = dz; dz = dz2; dz2 = tmp;
     }
@@ -474,8 +510,8 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
     for (int n0 = 0; n0 < H; n0 += 64)
         if (int rc = stream_dw<true>(dz + n0, a.x, a.rows, a.din, min(64, H - n0), part, grad_and_stats + off.W0 + (size_t)n0 * a.din, s, who,
                                      Hs, a.x_stride)) return rc;
-    wide_colsum(dz, Hs, a.rows, H, part, grad_and_stats + off.b0, s);
     CM_CHECK_LAUNCH(who);
+    if (dz0_out) *dz0_out = dz;
     return 0;
 }
 

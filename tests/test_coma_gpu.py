@@ -198,7 +198,10 @@ def test_coma_reference_default_critic_width_runs_and_wider_than_256_fails_loudl
 
 
 @pytest.mark.parametrize("E,A,T,Do,Ds,K,H,L", [(9, 3, 11, 10, 14, 5, 64, 1), (6, 5, 9, 40, 200, 12, 48, 2), (40, 8, 16, 56, 384, 5, 64, 1),
-                                                  (5, 1, 7, 12, 12, 4, 32, 0), (4, 10, 6, 115, 243, 17, 64, 1)])
+                                                  (5, 1, 7, 12, 12, 4, 32, 0), (4, 10, 6, 115, 243, 17, 64, 1),
+                                                  # layered schedule (csrc/cm_mlp_wide.h): the factoring runs once per 64-unit slab
+                                                  (9, 3, 11, 10, 14, 5, 128, 1), (6, 5, 9, 40, 200, 12, 96, 3), (7, 4, 8, 21, 54, 5, 256, 0),
+                                                  (5, 3, 6, 12, 30, 4, 48, 3)])
 def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
     """cm_coma_q_forward / cm_coma_critic_fwd_bwd (W0 x = W0o obs + state GEMM + gathered action columns) vs the literal
     path cm_coma_build_inputs -> cm_mlp_forward / cm_qcritic_fwd_bwd, and vs oracle/coma.py."""
@@ -215,10 +218,11 @@ def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
     cin = torch.empty(E, A, T, Dc, device=dev)
     N.check(lib.cm_coma_build_inputs(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), E, A, T, Ds, Do, K, N.ptr(cin), s), "build")
     q_lit, q_fac = torch.empty(E, A, T, K, device=dev), torch.empty(E, A, T, K, device=dev)
-    ws = torch.empty(max(lib.cm_coma_critic_workspace_bytes(E, A, T, Ds, Do, K, H, L, 1),
+    ws = torch.empty(max(lib.cm_coma_critic_workspace_bytes(E, A, T, Ds, Do, K, H, L, 1), lib.cm_mlp_forward_workspace_bytes(rows, Dc, H, L, K),
                          lib.cm_mlp_split_workspace_bytes(rows, Dc, H, L, K)), dtype=torch.uint8, device=dev)
     for avail in (None, b.avail):
-        N.check(lib.cm_mlp_forward(N.ptr(cin), rows, Dc, H, L, K, N.ptr(p), N.ptr(avail) if avail is not None else None, N.ptr(q_lit), s), "fwd")
+        N.check(lib.cm_mlp_forward_ws(N.ptr(cin), rows, Dc, H, L, K, N.ptr(p), N.ptr(avail) if avail is not None else None, N.ptr(q_lit),
+                                      N.ptr(ws), ws.numel(), s), "fwd")
         N.check(lib.cm_coma_q_forward(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(avail) if avail is not None else None, E, A, T,
                                       Ds, Do, K, H, L, N.ptr(p), N.ptr(q_fac), N.ptr(ws), ws.numel(), s), "qfwd")
         ref = C.q_values(cp, batch, K, batch["avail"] if avail is not None else None).permute(0, 2, 1, 3)

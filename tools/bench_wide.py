@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from cleanmarl_amd import _native as _N  # noqa: E402
+if os.environ.get("CM_LIB"):  # A/B builds of the same sources (e.g. -DCM_WT_K=64)
+    _N.LIB_PATH = os.path.abspath(os.environ["CM_LIB"])
 from cleanmarl_amd.coma_learner import COMAHParams, COMALearner, coma_critic_input_dim  # noqa: E402
 from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch  # noqa: E402
 from cleanmarl_amd.rollout import SyntheticSpreadRollout  # noqa: E402
@@ -54,7 +57,7 @@ for ch in (64, 128):
     L = COMALearner(aspec, cspec, A, COMAHParams(), dev, init_params_like_torch(aspec), init_params_like_torch(cspec))
     b = roll.collect(L.actor, aspec, eps=0.3)
     ms = timeit(lambda: L.train_iteration(b))
-    print(f"COMA  {E}x{A}x{T} critic {ch}x2 ({'factored, fused' if ch <= 64 else 'materialised input, layered'}): targets + critic + actor step "
+    print(f"COMA  {E}x{A}x{T} critic {ch}x2 ({'factored, fused' if ch <= 64 else 'factored, layered'}): targets + critic + actor step "
           f"{ms:7.2f} ms", flush=True)
     del L, b
     torch.cuda.empty_cache()
