@@ -29,3 +29,7 @@ CM_MFMA=bf16x3 python $R/tools/phase_prof.py actor > $O/phase_actor_bf16x3.txt 2
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k5 -- python $R/bench.py --workload cfg5 --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/k5 -name "*kernel_stats.csv" | head -1) $O/cfg5_kernel_stats.csv
 ls -la $O
+# layered schedule (hidden 65..256 / deeper than 2 hidden layers)
+python $R/tools/bench_wide.py 2>&1 | grep -v amdgpu.ids > $O/wide_schedule.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kw -- python $R/tools/probes/wide_prof.py > /dev/null 2>&1
+cp $(find /tmp/kw -name "*kernel_stats.csv" | head -1) $O/wide_kernel_stats.csv
