@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch
 from cleanmarl_amd.rollout import SyntheticSpreadRollout
 E, A, T = 4096, 8, 128
