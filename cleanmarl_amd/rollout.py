@@ -96,7 +96,12 @@ class SyntheticShapeRollout:
     def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
-        if eps > 0.0:
+        need = 0
+        if actor_spec.kind != "gru":  # layered schedule (hidden > 64 / deeper than 2 hidden layers): per-step act with a workspace
+            need = lib.cm_policy_act_workspace_bytes(E * A, actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K)
+            if need and (getattr(self, "act_ws", None) is None or self.act_ws.numel() < need):
+                self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if eps > 0.0 or need:
             fused = False
         N.check(lib.cm_shape_env_fill(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
                                       self.episode, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.avail), s), "cm_shape_env_fill")
@@ -119,14 +124,11 @@ class SyntheticShapeRollout:
                 N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                               actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
                                               _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
-            elif eps > 0.0:
-                N.check(lib.cm_policy_act_eps(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                              actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps), act_seed,
-                                              self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_policy_act_eps")
             else:
-                N.check(lib.cm_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                          actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A, t,
-                                          _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_policy_act")
+                N.check(lib.cm_policy_act_ws(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                             actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps), act_seed,
+                                             self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T,
+                                             N.ptr(self.act_ws) if need else None, need, s), "cm_policy_act_ws")
         N.check(lib.cm_shape_env_reward(E, A, T, K, self.seed, self.env_offset, self.episode, N.ptr(b.action), N.ptr(b.reward), s),
                 "cm_shape_env_reward")
         self.episode += 1

@@ -15,12 +15,19 @@ cases = [
  ("mappo", ["--env_type=synthetic_shape_cpu", "--synthetic_obs=9", "--synthetic_state=7", "--synthetic_actions=3", "--normalize_reward"]),
  ("ippo_lstm", ["--env_type=synthetic_cpu", "--greedy_eval", "--tbptt=3"]),
  ("mappo_multienvs", ["--env_type=synthetic", "--batch_size=1", "--synthetic_agents=1", "--synthetic_steps=2", "--total_timesteps=4"]),
+ # the layered schedule (hidden 65..256 / deeper than 2 hidden layers)
+ ("mappo_multienvs", ["--env_type=synthetic", "--critic_hidden_dim=128", "--normalize_advantage"]),
+ ("ippo_multienvs", ["--env_type=synthetic_shape", "--actor_hidden_dim=128", "--critic_hidden_dim=96", "--critic_num_layers=3", "--synthetic_obs=20", "--synthetic_state=12", "--synthetic_actions=6"]),
+ ("mappo", ["--env_type=synthetic_cpu", "--actor_num_layers=4", "--greedy_eval", "--clip_gradients=0.5"]),
+ ("mappo_lstm_multienvs", ["--env_type=synthetic", "--critic_hidden_dim=256", "--tbptt=5"]),
  ("ippo_multienvs", ["--env_type=synthetic", "--batch_size=1", "--synthetic_agents=2", "--synthetic_steps=3", "--total_timesteps=6", "--normalize_advantage"]),
 ]
 coma_cases = [
  ("coma_multienvs", ["--env_type=synthetic", "--critic_hidden_dim=64", "--use_tdlamda=False", "--nsteps=5", "--normalize_return", "--clip_gradients=0.5", "--no-agent_ids", "--target_network_update_freq=2", "--exploration_fraction=2"]),
  ("coma", ["--env_type=synthetic_shape_cpu", "--critic_hidden_dim=32", "--critic_num_layers=2", "--actor_num_layers=0", "--synthetic_obs=9", "--synthetic_state=7", "--synthetic_actions=3", "--normalize_advantage=False", "--optimizer=AdamW"]),
  ("coma_multienvs", ["--env_type=synthetic_cpu", "--critic_hidden_dim=64", "--vector_env=pipe", "--batch_size=1", "--synthetic_agents=1"]),
+ ("coma_multienvs", ["--env_type=synthetic", "--clip_gradients=0.5"]),  # reference default critic width 128
+ ("coma", ["--env_type=synthetic_shape", "--actor_hidden_dim=128", "--critic_hidden_dim=200", "--critic_num_layers=3", "--synthetic_obs=9", "--synthetic_state=7", "--synthetic_actions=3"]),
 ]
 bad = 0
 for script, extra in cases + coma_cases:
