@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libcleanmarl_hip.so")
 
 NUM_STATS = 8
 STAT_PG, STAT_ENT, STAT_KL, STAT_CLIP, STAT_VLOSS, STAT_COUNT = range(6)
-OPT_ADAM, OPT_ADAMW = 0, 1
+OPT_ADAM, OPT_ADAMW, OPT_SGD, OPT_RMSPROP = 0, 1, 2, 3
 
 _p = C.c_void_p
 _i = C.c_int

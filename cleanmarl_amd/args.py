@@ -34,7 +34,7 @@ class Args:
     critic_num_layers: int = 1
     """ Number of hidden layers of critic network"""
     optimizer: str = "Adam"
-    """ The optimizer"""
+    """ The optimizer (torch.optim class name with its defaults: Adam, AdamW, SGD, RMSprop have a HIP implementation)"""
     learning_rate_actor: float = 0.0008
     """ Learning rate for the actor"""
     learning_rate_critic: float = 0.0008
@@ -124,7 +124,7 @@ class ComaArgs:
     critic_num_layers: int = 1
     """ Number of hidden layers of critic network"""
     optimizer: str = "Adam"
-    """ The optimizer"""
+    """ The optimizer (torch.optim class name with its defaults: Adam, AdamW, SGD, RMSprop have a HIP implementation)"""
     learning_rate_actor: float = 0.0005
     """ Learning rate for the actor"""
     learning_rate_critic: float = 0.0005

@@ -95,7 +95,7 @@ class COMALearner:
     def _adam(self, params, g, opt, which, s):
         opt.step += 1
         N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
-                                                opt.lr, 0.9, 0.999, 1e-8, opt.wd, opt.kind, float(self.hp.clip_gradients), 1.0,
+                                                opt.lr, 0.9, opt.beta2, 1e-8, opt.wd, opt.kind, float(self.hp.clip_gradients), 1.0,
                                                 N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
 
     def _q(self, params, avail, out, b, s):

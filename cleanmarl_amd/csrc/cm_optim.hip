@@ -4,13 +4,30 @@
 //   loss /= b_mask.sum()            -> gradient sums are scaled by grad_scale / N (N read from the stats tail)
 //   norm_d([p.grad ...], 2)         -> pre-clip global L2 norm, written to out_norm[0]
 //   clip_grad_norm_(max_norm)       -> g *= min(1, max_norm / (norm + 1e-6)) when max_norm > 0
-//   optimizer.step()                -> torch.optim.Adam / AdamW update rule
+//   optimizer.step()                -> torch.optim.Adam / AdamW update rule; the script looks the class up
+//                                      with getattr(optim, args.optimizer), so SGD and RMSprop (torch defaults: no momentum,
+//                                      alpha = 0.99 passed as beta2, eps = 1e-8, not centred) are here as well
 // The parameter vectors are tiny (8k - 30k floats), so ONE workgroup of 1024 threads does all of it in a
 // single launch: pass 1 scales + accumulates the squared norm, a block reduction broadcasts the clip
 // coefficient, pass 2 applies the moment updates.  No host sync, no atomics, deterministic.
 #include "cm_common.h"
 
 #define OPT_THREADS 1024
+
+// one parameter's update; mi / vi are the two state slots (Adam: exp_avg, exp_avg_sq; RMSprop: vi = square_avg; SGD: unused)
+__device__ __forceinline__ float cm_opt_step(int kind, float p, float gi, float& mi, float& vi, float lr, float step_size, float beta1,
+                                             float beta2, float eps, float weight_decay, float bc2_sqrt) {
+    if (kind == CM_OPT_SGD) return p - lr * gi;
+    if (kind == CM_OPT_RMSPROP) {
+        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+        return p - lr * (gi / (sqrtf(vi) + eps));
+    }
+    if (kind == CM_OPT_ADAMW) p *= (1.0f - lr * weight_decay);
+    mi = beta1 * mi + (1.0f - beta1) * gi;
+    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    return p - step_size * (mi / denom);
+}
 
 __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam(
     float* __restrict__ params, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
@@ -44,13 +61,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam(
     for (long i = threadIdx.x; i < n; i += OPT_THREADS) {
         const float gi = g[i] * coef;
         g[i] = gi;  // post-clip gradient stays readable (what optimizer.step() consumed)
-        float p = params[i];
-        if (opt_kind == CM_OPT_ADAMW) p *= (1.0f - lr * weight_decay);
-        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        float mi = m[i], vi = v[i];
+        params[i] = cm_opt_step(opt_kind, params[i], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
         m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        params[i] = p - step_size * (mi / denom);
     }
 }
 
@@ -107,13 +120,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam_small(
             if (i < n) {
                 const float gi = gv[b + k] * coef;
                 g[i] = gi;
-                float p = pv[k];
-                if (opt_kind == CM_OPT_ADAMW) p *= (1.0f - lr * weight_decay);
-                const float mi = beta1 * mv[k] + (1.0f - beta1) * gi;
-                const float vi = beta2 * vv[k] + (1.0f - beta2) * gi * gi;
+                float mi = mv[k], vi = vv[k];
+                params[i] = cm_opt_step(opt_kind, pv[k], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
                 m[i] = mi; v[i] = vi;
-                const float denom = sqrtf(vi) / bc2_sqrt + eps;
-                params[i] = p - step_size * (mi / denom);
             }
         }
     }
@@ -124,7 +133,7 @@ extern "C" int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, floa
                                       double weight_decay, int opt_kind, double max_norm, double grad_scale,
                                       float* out_norm, cm_stream_t stream) {
     CM_REQUIRE(n_params > 0 && step >= 1, "cm_grad_norm_clip_adam: bad n_params=%ld step=%d", (long)n_params, step);
-    CM_REQUIRE(opt_kind == CM_OPT_ADAM || opt_kind == CM_OPT_ADAMW, "cm_grad_norm_clip_adam: unknown optimiser kind %d", opt_kind);
+    CM_REQUIRE(opt_kind >= CM_OPT_ADAM && opt_kind <= CM_OPT_RMSPROP, "cm_grad_norm_clip_adam: unknown optimiser kind %d", opt_kind);
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     if (n_params <= (int64_t)OPT_THREADS * OPT_PT)

@@ -127,13 +127,17 @@ class HParams:
 
 
 class _Adam:
-    """Optimiser state for one flat parameter buffer (torch.optim.Adam / AdamW defaults)."""
+    """Optimiser state for one flat parameter buffer.  The reference looks the class up with getattr(optim, args.optimizer) and
+    passes only lr (cleanmarl/mappo_multienvs.py:341-343), so each kind runs with torch's defaults: Adam / AdamW (wd 0.01) /
+    SGD (no momentum) / RMSprop (alpha 0.99, eps 1e-8)."""
+    KINDS = {"Adam": N.OPT_ADAM, "AdamW": N.OPT_ADAMW, "SGD": N.OPT_SGD, "RMSprop": N.OPT_RMSPROP}
 
     def __init__(self, nparams, lr, kind, device):
-        if kind not in ("Adam", "AdamW"):
-            raise N.NativeError(f"optimizer={kind!r}: only Adam and AdamW have a HIP implementation")
-        self.kind = N.OPT_ADAMW if kind == "AdamW" else N.OPT_ADAM
+        if kind not in self.KINDS:
+            raise N.NativeError(f"optimizer={kind!r}: only {sorted(self.KINDS)} have a HIP implementation")
+        self.kind = self.KINDS[kind]
         self.wd = 0.01 if kind == "AdamW" else 0.0
+        self.beta2 = 0.99 if kind == "RMSprop" else 0.999
         self.lr = lr
         self.m = torch.zeros(nparams, dtype=torch.float32, device=device)
         self.v = torch.zeros(nparams, dtype=torch.float32, device=device)
@@ -282,7 +286,7 @@ class PPOLearner:
         opt.step += 1
         hp = self.hp
         N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
-                                                opt.lr, 0.9, 0.999, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
+                                                opt.lr, 0.9, opt.beta2, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
                                                 grad_scale, N.ptr(self.norms[which:] if out_norm is None else out_norm), s),
                 "cm_grad_norm_clip_adam")
 

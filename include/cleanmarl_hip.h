@@ -51,7 +51,7 @@ enum {
     CM_NUM_STATS = 8
 };
 
-enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1 };
+enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1, CM_OPT_SGD = 2, CM_OPT_RMSPROP = 3 };  /* RMSprop: beta2 := alpha (torch default 0.99) */
 
 const char* cm_last_error(void);
 int cm_version(void);

@@ -161,7 +161,8 @@ def clip_grads_(grads, max_norm):
 
 class AdamState:
     """Hand-written torch.optim.Adam / AdamW (defaults betas=(0.9,0.999), eps=1e-8;
-    Adam wd=0, AdamW decoupled wd=0.01) -- SURVEY.md §8(a) row a12."""
+    Adam wd=0, AdamW decoupled wd=0.01) -- SURVEY.md §8(a) row a12; plus SGD (no momentum) and RMSprop (alpha 0.99,
+    eps 1e-8, not centred), the other classes getattr(optim, args.optimizer) is commonly pointed at."""
 
     def __init__(self, params, lr, kind="Adam", betas=(0.9, 0.999), eps=1e-8, weight_decay=None):
         self.lr, self.kind, self.b1, self.b2, self.eps = lr, kind, betas[0], betas[1], eps
@@ -175,6 +176,13 @@ class AdamState:
         bc1 = 1 - self.b1 ** self.t
         bc2 = 1 - self.b2 ** self.t
         for p, g, m, v in zip(params, grads, self.m, self.v):
+            if self.kind == "SGD":
+                p.add_(g, alpha=-self.lr)
+                continue
+            if self.kind == "RMSprop":
+                v.mul_(0.99).addcmul_(g, g, value=1 - 0.99)
+                p.addcdiv_(g, v.sqrt().add_(self.eps), value=-self.lr)
+                continue
             if self.kind == "AdamW" and self.wd:
                 p.mul_(1 - self.lr * self.wd)
             m.mul_(self.b1).add_(g, alpha=1 - self.b1)

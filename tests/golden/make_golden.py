@@ -180,7 +180,7 @@ def run_reference(script, overrides, env_spec):
         Snap.__name__ = base.__name__
         return Snap
 
-    saved = {n: getattr(optim, n) for n in ("Adam", "AdamW")}
+    saved = {n: getattr(optim, n) for n in ("Adam", "AdamW", "SGD", "RMSprop")}
     try:
         for n, b in saved.items():
             setattr(optim, n, make(b))
@@ -269,6 +269,13 @@ CASES = {
                    dict(batch_size=6, actor_hidden_dim=128, critic_hidden_dim=128, critic_num_layers=3, normalize_advantage=True,
                         clip_gradients=0.5),
                    dict(A=3, obs_raw=6, K=5, horizon=14, ragged=True, avail_p=0.7, state_dim=None, done_mode="done")),
+    # --optimizer is looked up with getattr(optim, ...): RMSprop (the COMA paper's choice) and plain SGD with torch's defaults
+    "mappo_rmsprop": ("mappo_multienvs.py",
+                      dict(batch_size=5, optimizer="RMSprop", clip_gradients=0.5, learning_rate_actor=5e-4, learning_rate_critic=5e-4),
+                      dict(A=3, obs_raw=6, K=5, horizon=12, ragged=True, avail_p=0.8, state_dim=None, done_mode="done")),
+    "ippo_sgd": ("ippo_multienvs.py",
+                 dict(batch_size=5, optimizer="SGD", learning_rate_actor=1e-2, learning_rate_critic=1e-2),
+                 dict(A=2, obs_raw=7, K=4, horizon=10, ragged=False, avail_p=1.0, state_dim=9, done_mode="truncate")),
     "ippo_dense": ("ippo_multienvs.py",
                    dict(batch_size=8, critic_hidden_dim=64, actor_hidden_dim=64),
                    dict(A=4, obs_raw=10, K=6, horizon=14, ragged=False, avail_p=1.0, state_dim=17, done_mode="truncate")),

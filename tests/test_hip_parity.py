@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # BASELINE.json north_star: returns / advantages / losses within 1e-4 fp32
 
-MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"),
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"), ("mappo_rmsprop", "mappo"), ("ippo_sgd", "ippo"),
              ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
 
 
@@ -218,6 +218,13 @@ def test_mlp_forward_matches_oracle():
         if need:
             assert lib.cm_mlp_forward_ws(N.ptr(d_x), rows, din, H, L, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.ptr(ws), need - 1,
                                          N.stream_ptr()) != 0 and b"workspace too small" in lib.cm_last_error()
+
+
+def test_unknown_optimizer_fails_loudly():
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner
+    with pytest.raises(N.NativeError, match="Adagrad"):
+        PPOLearner("mappo", NetSpec(8, 32, 1, 3), NetSpec(16, 32, 1, 1), 2, HParams(optimizer="Adagrad"), torch.device("cuda:0"))
 
 
 def test_unsupported_shapes_fail_loudly():

@@ -8,7 +8,7 @@ import torch
 
 from oracle import restatement as R
 
-MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"),
+MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"), ("mappo_rmsprop", "mappo"), ("ippo_sgd", "ippo"),
              ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
