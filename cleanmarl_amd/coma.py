@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MI355X-native drop-in for the reference script cleanmarl/coma.py (same flags, defaults and TensorBoard tags).  The
 reference's default --critic_hidden_dim=128 runs on the layered schedule (csrc/cm_mlp_wide.h); --critic_hidden_dim=64 takes
-the fused kernels with the factored critic input (about 4x faster per iteration).
+the fused kernels with the factored critic input (about 3x faster per iteration).
 
     python cleanmarl_amd/coma.py --env_type=pz --env_family=mpe --env_name=simple_spread_v3 --batch_size=4
     python cleanmarl_amd/coma.py --env_type=synthetic --synthetic_agents=8 --synthetic_steps=128 --batch_size=1024 --critic_hidden_dim=64

@@ -29,6 +29,8 @@ constexpr int WT_XP = WT_M / WT_RPP;       // loader passes over the X tile
 constexpr int WIDE_HMAX = 256;
 enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend
 
+#define WIDE_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 inline bool wide_shape(int H, int L) { return H > HP || L > LMAX; }
 inline int wide_hs(int H) { return (H + 63) / 64 * 64; }  // activation row stride (zero padded; whole 64-unit slabs)
 
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                                                            const float* __restrict__ bias, const uint8_t* __restrict__ avail, long lda,
                                                            const float* __restrict__ gate, long ldg,
                                                            float* __restrict__ Y, long ldy, int ncols, int vecx, int vecw,
-                                                           float* __restrict__ colsum_part) {
+                                                           int vecy, int vecg, float* __restrict__ colsum_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* Ws = smem + WT_M * WT_LD;
@@ -50,9 +52,15 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
     constexpr int WP = 32 * NJ / WT_RPP;                   // loader passes over the W tile
     const int nk = (K + WT_K - 1) / WT_K;
     const long ntiles = (rows + WT_M - 1) / WT_M;
-    float cs[NJ];  // EPI_GATE: column sums of the output (= the bias gradient of the layer below), over this workgroup's tiles
+    // epilogue geometry: a lane owns the float4 column group c4 of the rows rsub, rsub + RPI, ... of a 16-row half tile
+    constexpr int CG = 8 * NJ, CGP = CG <= 8 ? 8 : (CG <= 16 ? 16 : (CG <= 32 ? 32 : 64)), RPI = 64 / CGP, SLD = 32 * NJ + 8;
+    const int c4 = lane % CGP, rsub = lane / CGP;
+    float bv4[4], cs4[4];  // bias of the lane's columns; EPI_GATE: their column sums (= the bias gradient of the layer below)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) cs[j] = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        cs4[q] = 0.0f;
+        bv4[q] = ((EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) && c4 < CG && 4 * c4 + q < N) ? bias[4 * c4 + q] : 0.0f;
+    }
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * WT_M;
         f32x16 acc[NJ];
@@ -123,39 +131,80 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                 for (int kk = 0; kk < WT_KQ; ++kk) acc[j] = mfma32(a[kk], b[kk], acc[j]);
             }
         }
-        // epilogue: acc[j][g] = Y[row0 + 32 wave + (g&3) + 8 (g>>2) + 4h][32 j + lc]
+        // epilogue through LDS so that HBM sees whole rows: acc[j][g] = Y[row0 + 32 wave + (g&3) + 8 (g>>2) + 4h][32 j + lc] would
+        // store 128-byte row segments; instead each wave parks 16 rows at a time in its own slice of the (now dead) operand
+        // buffers and reads them back row-contiguous, one float4 per lane (addend / gate / output: 16-byte accesses, full rows).
+        __syncthreads();  // every wave is done with Xs / Ws
+        {
+            float* stg = smem + wave * (16 * SLD);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = 32 * j + lc;
-            const bool cv = col < N;
-            const float bv = ((EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) && cv) ? bias[col] : 0.0f;
+            for (int p = 0; p < 2; ++p) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const long row = row0 + 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (row < rows && col < ncols) {
-                    float v = acc[j][g] + bv;
-                    if (EPI == EPI_BIAS_RELU) {
-                        if (gate && cv) v += gate[row * ldg + col];  // COMA's factored layer-0 addend
-                        v = fmaxf(v, 0.0f);
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int gg = 0; gg < 8; ++gg) stg[((gg & 3) + 8 * (gg >> 2) + 4 * h) * SLD + 32 * j + lc] = acc[j][8 * p + gg];
+                WIDE_WAVE_SYNC();
+                if (c4 < CG) {
+#pragma unroll
+                    for (int it = 0; it < 16 / RPI; ++it) {
+                        const int rl = it * RPI + rsub;
+                        const long row = row0 + 32 * wave + 16 * p + rl;
+                        if (row < rows) {
+                            const float4 t = *reinterpret_cast<const float4*>(stg + rl * SLD + 4 * c4);
+                            float v[4] = {t.x, t.y, t.z, t.w};
+                            float gt[4] = {0.f, 0.f, 0.f, 0.f};
+                            const bool has_g = (EPI == EPI_GATE) || (EPI == EPI_BIAS_RELU && gate != nullptr);
+                            if (has_g) {
+                                const float* gp = gate + row * ldg + 4 * c4;
+                                if (vecg && 4 * c4 + 3 < N) { const float4 q4 = *reinterpret_cast<const float4*>(gp); gt[0] = q4.x; gt[1] = q4.y; gt[2] = q4.z; gt[3] = q4.w; }
+                                else {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) if (4 * c4 + q < N) gt[q] = gp[q];
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int col = 4 * c4 + q;
+                                const bool cv = col < N;
+                                float x = v[q] + bv4[q];
+                                if (EPI == EPI_BIAS_RELU) x = fmaxf(x + gt[q], 0.0f);  // gt = COMA's factored layer-0 addend (or 0)
+                                if (EPI == EPI_BIAS && avail && cv && !avail[row * lda + col]) x = -1e9f;  // masked_fill(~avail, -1e9)
+                                if (EPI == EPI_GATE) { x = gt[q] > 0.0f ? x : 0.0f; cs4[q] += cv ? x : 0.0f; }
+                                v[q] = cv ? x : 0.0f;
+                            }
+                            float* yp = Y + row * ldy + 4 * c4;
+                            if (vecy && 4 * c4 + 3 < ncols) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                            else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) if (4 * c4 + q < ncols) yp[q] = v[q];
+                            }
+                        }
                     }
-                    if (EPI == EPI_BIAS && avail && cv && !avail[row * lda + col]) v = -1e9f;  // masked_fill(~avail, -1e9)
-                    if (EPI == EPI_GATE) { v = (cv && gate[row * ldg + col] > 0.0f) ? v : 0.0f; cs[j] += v; }
-                    Y[row * ldy + col] = cv ? v : 0.0f;
                 }
+                WIDE_WAVE_SYNC();
             }
         }
+        // the next tile's first barrier (top of its chunk loop) orders these LDS reads before its operand stores
     }
-    if (EPI == EPI_GATE && colsum_part) {  // per-workgroup partial [32 NJ]: lanes h = 0/1 -> 4 waves, fixed order
+    if (EPI == EPI_GATE && colsum_part) {  // per-workgroup partial [32 NJ]: (4 waves x RPI row groups) summed in a fixed order
         __syncthreads();
+        if (c4 < CG) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float o = __shfl_xor(cs[j], 32, 64);
-            if (h == 0) smem[wave * 32 * NJ + 32 * j + lc] = cs[j] + o;
+            for (int q = 0; q < 4; ++q) smem[(wave * RPI + rsub) * 32 * NJ + 4 * c4 + q] = cs4[q];
         }
         __syncthreads();
-        for (int i = tid; i < 32 * NJ; i += NTHREADS)
-            colsum_part[(long)blockIdx.x * 32 * NJ + i] = (smem[i] + smem[32 * NJ + i]) + (smem[2 * 32 * NJ + i] + smem[3 * 32 * NJ + i]);
+        for (int i = tid; i < 32 * NJ; i += NTHREADS) {
+            float t = 0.0f;
+            for (int k = 0; k < 4 * RPI; ++k) t += smem[k * 32 * NJ + i];
+            colsum_part[(long)blockIdx.x * 32 * NJ + i] = t;
+        }
     }
+}
+
+// operand tiles (X: WT_M rows, W: 32 NJ rows, stride WT_LD) or the epilogue's four 16-row staging slices (stride 32 NJ + 8)
+inline size_t wide_gemm_lds(int nj) {
+    const size_t ops = (size_t)(WT_M + 32 * nj) * WT_LD, stage = (size_t)64 * (32 * nj + 8);
+    return (ops > stage ? ops : stage) * sizeof(float);
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -167,20 +216,26 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     const int nj = (max(N, ncols) + 31) / 32;
     const int vecx = (ldx % 4 == 0 && K % 4 == 0 && al16(X)) ? 1 : 0;
     const int vecw = (ldw % 4 == 0 && K % 4 == 0 && al16(W)) ? 1 : 0;
+    const int vecy = (ldy % 4 == 0 && al16(Y)) ? 1 : 0;
+    const int vecg = (gate && ldg % 4 == 0 && al16(gate)) ? 1 : 0;
     const long ntiles = (rows + WT_M - 1) / WT_M;
     const int grid = (int)min(ntiles, 512L);
 #define CM_WIDE_CASE(NJ)                                                                                                        \
     case NJ: {                                                                                                                  \
-        const size_t lds = (size_t)(WT_M + 32 * NJ) * WT_LD * sizeof(float);                                                    \
+        const size_t lds = wide_gemm_lds(NJ);                                                                                   \
+        if (lds > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_gemm<NJ, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_wide_gemm<NJ, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail, \
-                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw, colsum_part);                                                  \
+                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part);                                      \
     } break;
     switch (nj) {
         CM_WIDE_CASE(1) CM_WIDE_CASE(2) CM_WIDE_CASE(3) CM_WIDE_CASE(4) CM_WIDE_CASE(5) CM_WIDE_CASE(6) CM_WIDE_CASE(7)
         default: { constexpr int NJ8 = 8;
-            const size_t lds = (size_t)(WT_M + 32 * NJ8) * WT_LD * sizeof(float);
+            const size_t lds = wide_gemm_lds(NJ8);
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_gemm<NJ8, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_wide_gemm<NJ8, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail,
-                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw, colsum_part);
+                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part);
         } break;
     }
 #undef CM_WIDE_CASE
