@@ -1061,6 +1061,13 @@ inline bool can_vec(const MlpArgs& a) {
 
 template <int NCH, int MODE, bool VEC, int LCAP, int KJ, bool BF = false>
 inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
+#ifdef CM_PHASE_PROF
+    // profiling build only (tools/phase_prof.py): CM_PROF_ONE_WG=1 pads LDS so that ONE workgroup fits a CU and halves the grid --
+    // timing experiment for the occupancy argument of DESIGN.md section 10 (results of such a launch are not meaningful)
+    if (const char* e = getenv("CM_PROF_ONE_WG")) {
+        if (e[0] == '1') { if (lds_bytes < 100 * 1024) lds_bytes = 100 * 1024; if (grid > 256) grid = 256; }
+    }
+#endif
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
