@@ -30,7 +30,8 @@ __device__ __forceinline__ void ld16(float (&d)[16], const float* p) {
 }
 
 __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, long rows, const float* __restrict__ params,
-                                                 const int* __restrict__ action, const float* __restrict__ adv, float* __restrict__ out) {
+                                                 const int* __restrict__ action, const float* __restrict__ adv, float* __restrict__ out,
+                                                 unsigned long long* __restrict__ ticks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W0s = smem;
     float* W1s = W0s + H * LD;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, lo
         for (int j = 0; j < 4; ++j) { aW0[i][j] = f32x4{0, 0, 0, 0}; aW1[i][j] = f32x4{0, 0, 0, 0}; }
     }
     const long ntiles = rows / 16;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     const long stride = (long)gridDim.x * NW;
     long tile = (long)blockIdx.x * NW + wave;
     float xa[16];
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, lo
 #endif
         WAVE_SYNC();
     }
+    if (tid == 0) ticks[blockIdx.x] = __builtin_amdgcn_s_memtime() - t_start;
     // per-wave partials (the product kernel would sum the 8 waves through LDS first)
     float* o = out + ((size_t)blockIdx.x * NW + wave) * (64 * 148);
 #pragma unroll
@@ -241,6 +244,7 @@ int main() {
     CK(hipMalloc(&adv, rows * sizeof(float)));
     CK(hipMalloc(&action, rows * sizeof(int)));
     const int grid = 256;
+    unsigned long long* ticks; CK(hipMalloc(&ticks, grid * sizeof(unsigned long long)));
     CK(hipMalloc(&out, (size_t)grid * NW * 64 * 148 * sizeof(float)));
     std::vector<float> h((size_t)4 * H * H);
     for (size_t i = 0; i < h.size(); ++i) h[i] = ((float)rand() / RAND_MAX - 0.5f) * 0.25f;
@@ -255,11 +259,11 @@ int main() {
     CK(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out, ticks);
     CK(hipDeviceSynchronize());
     const int N = 10;
     CK(hipEventRecord(e0));
-    for (int it = 0; it < N; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out);
+    for (int it = 0; it < N; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out, ticks);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= N;
@@ -268,6 +272,11 @@ int main() {
 #else
     const double mfma_flop = (double)rows / 16 * 368 * 2048;  // issued (padded) MFMA FLOPs
 #endif  // issued (padded) MFMA FLOPs
+    static unsigned long long th[256];
+    CK(hipMemcpy(th, ticks, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long tk = 0, tmin = ~0ull;
+    for (int i = 0; i < grid; ++i) { tk = th[i] > tk ? th[i] : tk; tmin = th[i] < tmin ? th[i] : tmin; }
+    printf("shader clock %.0f MHz (longest workgroup window in s_memtime ticks / wall; shortest window %.2f of it)\n", tk / (ms * 1e3), (double)tmin / tk);
     printf("wave-private skeleton: %.3f ms per pass over %ld rows, LDS %zu B; issued-MFMA rate %.1f TFLOP/s = %.1f%% of the 157.3 fp32 peak "
            "(k_mlp<1,M_ACTOR>: 1.87 ms, 103 TFLOP/s issued = 65%%)\n", ms, rows, lds, mfma_flop / ms / 1e9, mfma_flop / ms / 1e9 / 157.3 * 100);
     return 0;
