@@ -70,6 +70,26 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* ticks, 
     if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+// the 16x16x4 form (same FLOP rate): 16 independent accumulator chains from registers
+__global__ __launch_bounds__(256) void k16(float* out, unsigned long long* ticks, int iters) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[16];
+    for (int q = 0; q < 16; ++q) acc[q] = f32x4{0, 0, 0, 0};
+    float a = 1e-3f * threadIdx.x, b = 2e-3f * threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int q = 0; q < 16; ++q) s += acc[q][0] + acc[q][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 template <int LDS>
 static void run(const char* name, int wg_per_cu, float* out, unsigned long long* ticks, const float4* gsrc) {
     // LDS padding so that exactly wg_per_cu workgroups (4 waves each = wg_per_cu waves per SIMD) fit a CU
@@ -105,5 +125,21 @@ int main() {
     for (int w : {1, 2}) run<5>("V N + VALU           ", w, out, ticks, gsrc);
     for (int w : {1, 2}) run<6>("G N + global loads   ", w, out, ticks, gsrc);
     for (int w : {1, 2}) run<7>("A N + all three      ", w, out, ticks, gsrc);
+    {
+        const int grid = 256, iters = 4000;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k16, dim3(grid), dim3(256), 0, 0, out, ticks, iters);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k16, dim3(grid), dim3(256), 0, 0, out, ticks, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        static unsigned long long th[256];
+        hipMemcpy(th, ticks, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t = 0; for (int i = 0; i < grid; ++i) t = th[i] > t ? th[i] : t;
+        const double flop = (double)grid * 4 * iters * 256 * 2048.0;
+        printf("R16 registers, 16x16x4 1 waves/SIMD: %8.3f ms  %7.1f TFLOP/s = %5.1f %% of 157.3   shader clock %6.0f MHz\n", ms, flop / ms / 1e9,
+               flop / ms / 1e9 / 157.3 * 100, t / (ms * 1e3));
+    }
     return 0;
 }
