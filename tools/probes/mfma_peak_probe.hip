@@ -12,7 +12,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int LDS>
-__global__ __launch_bounds__(256) void k(float* out, unsigned long long* ticks, int iters, int pad_floats, const float4* __restrict__ gsrc) {
+__global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* ticks, int iters, int pad_floats, const float4* __restrict__ gsrc) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     for (int i = threadIdx.x; i < 64 * 68; i += 256) sm[i] = 1e-3f * (i % 97);

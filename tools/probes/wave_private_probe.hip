@@ -19,7 +19,14 @@ constexpr int WBUF = 16 * LD;                       // one private row buffer (f
 constexpr int PRIV = 3 * WBUF + 16 * DL;            // X | H0 | H1 | dlogits
 constexpr int LDS_FLOATS = 2 * H * LD + 16 * LD + NW * PRIV;
 
+#ifdef NO_FENCE
+#define WAVE_SYNC() do { __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define WAVE_SYNC_REAL
+#endif
+#ifdef WAVE_SYNC_REAL
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 __device__ __forceinline__ void ld16(float (&d)[16], const float* p) {
 #pragma unroll
@@ -64,14 +71,22 @@ __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, lo
     const long stride = (long)gridDim.x * NW;
     long tile = (long)blockIdx.x * NW + wave;
     float xa[16];
+#ifdef NO_XLOAD
+    for (int i = 0; i < 16; ++i) xa[i] = 1e-3f * (lane + i);
+#else
     if (tile < ntiles) ld16(xa, x + (tile * 16 + r) * H + 16 * g);
+#endif
     for (; tile < ntiles; tile += stride) {
         const long row0 = tile * 16;
         // ---- X: A operand in registers (k = 16 g + s), B-layout copy in the private LDS slice for dW0
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Xb + r * LD + 16 * g + 4 * q) = make_float4(xa[4 * q], xa[4 * q + 1], xa[4 * q + 2], xa[4 * q + 3]);
+#ifdef NO_XLOAD
+        const int act = 0; const float av = 0.5f;
+#else
         const int act = action[row0 + r];
         const float av = adv[row0 + r];
+#endif
         // ---- forward layer 0
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -84,8 +99,10 @@ __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, lo
             for (int i = 0; i < 4; ++i) H0[(4 * g + i) * LD + 16 * j + r] = fmaxf(acc[i] + b0[j], 0.0f);
         }
         {   // next tile's X in flight under the rest of this tile
+#ifndef NO_XLOAD
             const long nt = tile + stride;
             if (nt < ntiles) ld16(xa, x + (nt * 16 + r) * H + 16 * g);
+#endif
         }
         WAVE_SYNC();
         // ---- forward layer 1
