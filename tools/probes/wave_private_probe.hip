@@ -188,12 +188,16 @@ __global__ __launch_bounds__(NT, 1) void k_probe(const float* __restrict__ x, lo
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { a[t][s] = H1[(4 * s + g) * LD + 16 * t + r]; b[t][s] = H0[(4 * s + g) * LD + 16 * t + r]; }
+#ifndef NO_DW1
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) aW1[i][j] = mfma16(a[i][s], b[j][s], aW1[i][j]);
+#else
+            aW1[0][0][0] += a[0][0] + b[0][0] + a[3][3] + b[3][3];
+#endif
             float az[16];
             ld16(az, H1 + r * LD + 16 * g);
             f32x4 dz[4];
@@ -284,7 +288,9 @@ int main() {
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= N;
-    #ifdef NO_DW0
+    #if defined(NO_DW0) && defined(NO_DW1)
+    const double mfma_flop = (double)rows / 16 * 240 * 2048;
+#elif defined(NO_DW0)
     const double mfma_flop = (double)rows / 16 * 304 * 2048;
 #else
     const double mfma_flop = (double)rows / 16 * 368 * 2048;  // issued (padded) MFMA FLOPs
