@@ -9,8 +9,9 @@
 //             dZ_{l} = (dZ_{l+1} W) .* relu'(act_l) (k_wide_gemm on a transposed weight copy; its epilogue also accumulates the
 //             column sums of dZ_l = the bias gradient of the layer below), db_out = k_wide_colsum
 // Same MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) and the same deterministic
-// per-workgroup-partials + ordered-reduce pattern as the fused path.  HBM-bound by design (every activation makes a round trip);
-// it exists so that every width the reference's CLI accepts up to 256 runs, not to be the fast path.
+// per-workgroup-partials + ordered-reduce pattern as the fused path.  HBM-bound by design (every activation makes a round trip; the
+// GEMM epilogue is staged through LDS so that those round trips are whole rows): it exists so that every width the reference's CLI
+// accepts up to 256 runs, not to be the fast path.
 #pragma once
 #include "cm_mlp_split.h"
 
@@ -451,9 +452,9 @@ inline int wide_check(const char* who, int din, int H, int L, int dout) {
     return 0;
 }
 
-// forward into act planes; returns the last hidden activation plane index through *last.  y (ld ldy, ncols) receives the head.
+// forward into the activation planes (act(l), l = 0..L; forward-only: two ping-pong planes); y (row stride ldy, ncols columns) receives the head
 inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bool train, float* y, long ldy, int ncols, hipStream_t s,
-                               const char* who, int* last) {
+                               const char* who) {
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
     const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
     auto act = [&](int l) { return wsf + w.act + (size_t)(train ? l : (l & 1)) * plane; };
@@ -465,7 +466,6 @@ inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bo
     wide_gemm<EPI_BIAS>(act(a.L), w.Hs, a.rows, a.H, a.params + off.Wout, a.H, a.dout, a.params + off.bout, a.avail, a.avail_stride, nullptr, 0, y,
                         ldy, ncols, s);
     CM_CHECK_LAUNCH(who);
-    *last = a.L;
     return 0;
 }
 
@@ -474,8 +474,7 @@ inline int wide_forward(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t
     if (int rc = wide_check(who, a.din, a.H, a.L, a.dout)) return rc;
     const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, false);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
-    int last;
-    return wide_forward_layers(a, (float*)ws, w, false, a.y, a.dout, a.dout, s, who, &last);
+    return wide_forward_layers(a, (float*)ws, w, false, a.y, a.dout, a.dout, s, who);
 }
 
 // Actor.act for wide shapes: layered forward to masked logits [rows][KMAX] in the workspace, then one thread per row draws with the
@@ -500,8 +499,7 @@ inline int wide_act(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t s, 
     const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, false, true);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
     float* out = (float*)ws + w.out;
-    int last;
-    if (int rc = wide_forward_layers(a, (float*)ws, w, false, out, KMAX, KMAX, s, who, &last)) return rc;
+    if (int rc = wide_forward_layers(a, (float*)ws, w, false, out, KMAX, KMAX, s, who)) return rc;
     hipLaunchKernelGGL(k_wide_sample, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, out, a.rows, a.dout, a.seed, a.row_offset, a.t,
                        a.act_eps, a.action_out, a.logp_out, a.out_stride);
     CM_CHECK_LAUNCH(who);
@@ -525,8 +523,7 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
     float* part = wsf + w.part;
     float* wt = wsf + w.wt;
     const int H = a.H, Hs = w.Hs;
-    int last;
-    if (int rc = wide_forward_layers(a, wsf, w, true, out, KMAX, KMAX, s, who, &last)) return rc;
+    if (int rc = wide_forward_layers(a, wsf, w, true, out, KMAX, KMAX, s, who)) return rc;
     // ---- loss heads: logits -> dlogits in place, statistics
     {
         const int grid = (int)min((a.rows + NTHREADS - 1) / NTHREADS, (long)LOSS_GRID);
