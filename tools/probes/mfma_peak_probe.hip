@@ -4,6 +4,8 @@
 //   N  both operands re-read from LDS for every 4 MFMAs: 2 x ds_read_b128 per 4 MFMAs, exactly cm_mlp_kernel.h's rowpar_nt
 //   W / V / G / A  = N plus, per 4 MFMAs: 2 ds_write_b32 (activation stores) / 12 VALU ops (epilogue math) / one 16-byte global
 //       load per 16 MFMAs (tile prefetch) / all three -- the side activity of the fused training kernel
+//   P  phases: 128 MFMAs from registers, then an LDS-only phase (32 ds_write_b32 + 32 ds_read_b32, wave-private slice): alone a wave keeps the
+//      pipe ~2/3 busy, two waves per SIMD fill each other's LDS phases -- the structure of the fused kernels
 //   C  both operands as scalar reads: 8 x ds_read_b32 per 4 MFMAs, exactly cm_mlp_kernel.h's colred / the B side of rowpar_tn
 // for 1, 2 and 4 waves per SIMD.  s_memtime counts shader clocks, so ticks / wall time is the clock the run sustained.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/peak tools/probes/mfma_peak_probe.hip && /tmp/peak
@@ -15,7 +17,10 @@ template <int LDS>
 __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* ticks, int iters, int pad_floats, const float4* __restrict__ gsrc) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    for (int i = threadIdx.x; i < 64 * 68; i += 256) sm[i] = 1e-3f * (i % 97);
+    for (int i = threadIdx.x; i < 64 * 68; i += 256) {
+        unsigned u = (unsigned)i * 2654435761u + blockIdx.x * 40503u; u ^= u >> 13; u *= 2246822519u; u ^= u >> 16;
+        sm[i] = pad_floats ? ((float)(u & 0xFFFFFF) / 16777216.0f - 0.5f) : 1e-3f * (i % 97);  // pad_floats != 0: high-entropy operands
+    }
     __syncthreads();
     f32x16 acc[4];
     for (int q = 0; q < 4; ++q) for (int g = 0; g < 16; ++g) acc[q][g] = 0.f;
@@ -23,6 +28,15 @@ __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* tick
     float side = 1.0f + lane;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
+        if (LDS == 8) {
+            float* mine = sm + 64 * 68 + (threadIdx.x >> 6) * 2048;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) mine[64 * v + lane] = side + v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int v = 0; v < 32; ++v) side += mine[64 * v + (lane ^ 1)];
+            a.x += side * 1e-9f;
+        }
         asm volatile("" ::: "memory");  // LDS contents are "unknown" again: the operand reads below stay inside the loop
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -91,16 +105,16 @@ __global__ __launch_bounds__(256) void k16(float* out, unsigned long long* ticks
 }
 
 template <int LDS>
-static void run(const char* name, int wg_per_cu, float* out, unsigned long long* ticks, const float4* gsrc) {
+static void run(const char* name, int wg_per_cu, float* out, unsigned long long* ticks, const float4* gsrc, int entropy = 0) {
     // LDS padding so that exactly wg_per_cu workgroups (4 waves each = wg_per_cu waves per SIMD) fit a CU
     const size_t lds = wg_per_cu == 1 ? 100 * 1024 : 70 * 1024;  // >= 64*68*4 + 32 KB of store scratch
     hipFuncSetAttribute((const void*)k<LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int grid = 256 * wg_per_cu, iters = 4000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<LDS>, dim3(grid), dim3(256), lds, 0, out, ticks, iters, 0, gsrc);
+    hipLaunchKernelGGL(k<LDS>, dim3(grid), dim3(256), lds, 0, out, ticks, iters, entropy, gsrc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<LDS>, dim3(grid), dim3(256), lds, 0, out, ticks, iters, 0, gsrc);
+    hipLaunchKernelGGL(k<LDS>, dim3(grid), dim3(256), lds, 0, out, ticks, iters, entropy, gsrc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     static unsigned long long th[1024];
@@ -125,6 +139,10 @@ int main() {
     for (int w : {1, 2}) run<5>("V N + VALU           ", w, out, ticks, gsrc);
     for (int w : {1, 2}) run<6>("G N + global loads   ", w, out, ticks, gsrc);
     for (int w : {1, 2}) run<7>("A N + all three      ", w, out, ticks, gsrc);
+    for (int w : {1, 2}) run<8>("P MFMA / LDS phases  ", w, out, ticks, gsrc);
+    for (int w : {1, 2}) run<2>("N, random operands   ", w, out, ticks, gsrc, 1);
+    for (int w : {1, 2}) run<3>("C, random operands   ", w, out, ticks, gsrc, 1);
+    for (int w : {1, 2}) run<8>("P, random operands   ", w, out, ticks, gsrc, 1);
     {
         const int grid = 256, iters = 4000;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

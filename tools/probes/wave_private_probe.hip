@@ -268,10 +268,11 @@ int main() {
     unsigned long long* ticks; CK(hipMalloc(&ticks, grid * sizeof(unsigned long long)));
     CK(hipMalloc(&out, (size_t)grid * NW * 64 * 148 * sizeof(float)));
     std::vector<float> h((size_t)4 * H * H);
-    for (size_t i = 0; i < h.size(); ++i) h[i] = ((float)rand() / RAND_MAX - 0.5f) * 0.25f;
+    const bool zero = getenv("WPP_ZERO") != nullptr;  // all-zero operands: no bit toggling in the MFMA / LDS / register data paths
+    for (size_t i = 0; i < h.size(); ++i) h[i] = zero ? 0.0f : ((float)rand() / RAND_MAX - 0.5f) * 0.25f;
     CK(hipMemcpy(params, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     std::vector<float> hx((size_t)1 << 24);
-    for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)rand() / RAND_MAX - 0.5f;
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = zero ? 0.0f : (float)rand() / RAND_MAX - 0.5f;
     for (size_t off = 0; off < (size_t)rows * H; off += hx.size())
         CK(hipMemcpy(x + off, hx.data(), std::min(hx.size(), (size_t)rows * H - off) * sizeof(float), hipMemcpyHostToDevice));
     CK(hipMemcpy(adv, hx.data(), rows * sizeof(float), hipMemcpyHostToDevice));
@@ -280,7 +281,8 @@ int main() {
     CK(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out, ticks);
+    const int warm = getenv("WPP_WARM") ? atoi(getenv("WPP_WARM")) : 3;
+    for (int it = 0; it < warm; ++it) hipLaunchKernelGGL(k_probe, dim3(grid), dim3(NT), lds, 0, x, rows, params, action, adv, out, ticks);
     CK(hipDeviceSynchronize());
     const int N = 10;
     CK(hipEventRecord(e0));
