@@ -619,6 +619,10 @@ def test_full_size_update_is_deterministic_and_finite():
     ("mappo", 1, 1, 1, 3, 5, 2, 8, 1),      # smallest possible batch: one env, one agent, one step
     ("ippo", 1, 2, 3, 4, 9, 1, 64, 1),      # single action (degenerate softmax), E = 1 (the reference's IPPO crashes here)
     ("mappo", 3, 4, 70, 130, 1100, 32, 64, 2),  # widest supported head / 3 actor chunks / split critic schedule, 3 column windows
+    # the same corners on the layered schedule
+    ("mappo", 1, 1, 1, 3, 5, 2, 65, 1),      # one row, one unit past the fused width (second 64-unit slab holds 1 unit)
+    ("ippo", 1, 2, 3, 4, 9, 1, 128, 3),      # single action, E = 1, deep
+    ("mappo", 3, 4, 70, 130, 1100, 32, 160, 1),  # 32 actions, 1100-wide critic input (3 column windows of the streaming dW), 2.5 slabs
 ])
 def test_update_edge_shapes_match_oracle(algo, E, A, T, Do, Ds, K, H, L):
     _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=False)  # a single sample has no unbiased std
@@ -633,13 +637,14 @@ def test_all_steps_masked_is_finite_and_a_no_op_for_the_gradient():
     b = DeviceBatch(E, A, T, Do, Ds, K, dev)
     b.obs.normal_(); b.state.normal_(); b.avail.fill_(1); b.reward.normal_()  # ep_len stays 0
     torch.manual_seed(0)
-    L = PPOLearner("mappo", NetSpec(Do, 64, 1, K), NetSpec(Ds, 64, 1, 1), A, HParams(epochs=1), dev)
-    L.compute_targets(b)
-    assert (b.ret == 0).all() and (b.adv == 0).all()
-    s = N.stream_ptr()
-    L.actor_pass(b, s); L.critic_pass(b, s)
-    torch.cuda.synchronize()
-    assert torch.isfinite(L.gbuf).all() and (L.gbuf == 0).all()
+    for H, nl in ((64, 1), (128, 3)):  # fused kernels, layered schedule
+        L = PPOLearner("mappo", NetSpec(Do, H, nl, K), NetSpec(Ds, H, nl, 1), A, HParams(epochs=1), dev)
+        L.compute_targets(b)
+        assert (b.ret == 0).all() and (b.adv == 0).all()
+        s = N.stream_ptr()
+        L.actor_pass(b, s); L.critic_pass(b, s)
+        torch.cuda.synchronize()
+        assert torch.isfinite(L.gbuf).all() and (L.gbuf == 0).all()
 
 
 def test_rollout_edge_shapes():
