@@ -52,7 +52,7 @@ else:
     ws = torch.empty(lib.cm_critic_workspace_bytes(E, A, T, 0, Ds, 64, 1), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_critic_fwd_bwd(N.ptr(st), N.ptr(ret), N.ptr(ep_len), E, A, T, 0, Ds, 64, 1, N.ptr(p),
                                                 N.ptr(g), N.ptr(ws), ws.numel(), s), "critic")
-for _ in range(2):
+for _ in range(int(os.environ.get("CM_PROF_WARMUP", "2"))):  # CM_PROF_WARMUP=300: steady-state clock (the GPU ramps for ~0.1 s after idle)
     run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
