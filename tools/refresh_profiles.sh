@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01j
+O=$R/gpurun_out/r01l
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
