@@ -24,6 +24,7 @@ class GRUPPOLearner(PPOLearner):
         self.gru_ws = None
         self.g_rows = None
         self.h = [None, None]
+        self._critic_stream = None
 
     def _ensure(self, b):
         a = self.actor_spec
@@ -44,8 +45,27 @@ class GRUPPOLearner(PPOLearner):
         if self.g_rows is None or self.g_rows.shape[0] < len(chunks):
             self.g_rows = torch.zeros(len(chunks), Pa + N.NUM_STATS, dtype=torch.float32, device=self.device)
         rec_c = torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
-        kept = []
+        kept, kept_c = [], []
+        # The critic's epoch (one pass + one step, independent of the actor: it reads returns and states only, own workspace, own
+        # gradient buffer) is enqueued on a second stream at the start of every actor epoch.  The TBPTT chunk kernels are 32-row
+        # sweeps -- E*A/32 workgroups, fewer than the 256 CUs at config 5 -- and strictly sequential, so the critic kernels fill the
+        # idle CUs instead of extending the serial chain.  Issue order (critic epoch, then that epoch's chunks) is identical on all
+        # ranks, so the collectives still pair up.
+        main = torch.cuda.current_stream()
+        if self._critic_stream is None:
+            self._critic_stream = torch.cuda.Stream(device=self.device)
+        side = self._critic_stream
+        side.wait_stream(main)
         for ep in range(nE):
+            with torch.cuda.stream(side):
+                sc = N.stream_ptr()
+                self._timed("critic", self.critic_pass, b, sc)
+                self._allreduce(self.g_critic)
+                self._adam(self.critic, self.g_critic, self.opt_c, 1, sc)
+                rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
+                rec_c[ep, N.NUM_STATS] = self.norms[1]
+                if keep_grads:
+                    kept_c.append((self.g_critic[:Pc].clone(), self.critic.clone()))
             steps = []
             h_in = None
             if self.events is not None:  # bench.py: one event pair around all TBPTT chunks of the epoch
@@ -68,13 +88,9 @@ class GRUPPOLearner(PPOLearner):
             if self.events is not None:
                 ev1.record()
                 self.events.append(("actor", ev0, ev1))
-            self._timed("critic", self.critic_pass, b, s)
-            self._allreduce(self.g_critic)
-            self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
-            rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
-            rec_c[ep, N.NUM_STATS] = self.norms[1]
             if keep_grads:
-                kept.append((steps, self.g_critic[:Pc].clone(), self.critic.clone()))
+                kept.append((steps,) + kept_c[ep])
+        main.wait_stream(side)
         ent_coef = hp.entropy_coef
 
         def build(ra, rc):
