@@ -782,3 +782,43 @@ def test_optin_wave_private_actor_kernel_matches_the_default(tmp_path):
     errs = [float(m) for m in re.findall(r"max rel err vs \S+ ([0-9.eE+-]+)", r.stdout)]
     assert len(errs) == 4, r.stdout + r.stderr
     assert max(errs) < 1e-5, r.stdout  # fp32 re-association only
+
+
+@pytest.mark.parametrize("kind", ["Adam", "AdamW", "SGD", "RMSprop"])
+def test_optimiser_step_matches_torch_at_size_boundaries(kind):
+    """cm_grad_norm_clip_adam against torch.optim + clip_grad_norm_ (cleanmarl/mappo_multienvs.py:584-594) on sizes around the switch
+    between the two-launch form (<= 32768 parameters: norm pass + multi-workgroup update) and the one-workgroup kernel, with the
+    gradient scaled by grad_scale / N as the learners pass it, with and without clipping, three consecutive steps."""
+    from cleanmarl_amd import _native as N
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    kinds = {"Adam": N.OPT_ADAM, "AdamW": N.OPT_ADAMW, "SGD": N.OPT_SGD, "RMSprop": N.OPT_RMSPROP}
+    for n in (1, 1000, 1024, 4097, 32767, 32768, 32769, 100003):
+        for max_norm in (-1.0, 0.5):
+            gen = torch.Generator().manual_seed(n)
+            p0 = torch.randn(n, generator=gen)
+            ref = torch.nn.Parameter(p0.clone())
+            kw = dict(lr=8e-4)
+            opt = getattr(torch.optim, kind)([ref], **kw)
+            p = p0.clone().to(dev)
+            m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            norm = torch.zeros(1, device=dev)
+            count, grad_scale = 37.0, 0.25
+            for step in (1, 2, 3):
+                gsum = torch.randn(n, generator=gen) * 50.0
+                ref.grad = gsum * (grad_scale / count)
+                want_norm = float(ref.grad.norm())
+                if max_norm > 0:
+                    torch.nn.utils.clip_grad_norm_([ref], max_norm)
+                want_grad = ref.grad.clone()
+                opt.step()
+                g = torch.zeros(n + N.NUM_STATS, device=dev)
+                g[:n] = gsum.to(dev)
+                g[n + N.STAT_COUNT] = count
+                N.check(lib.cm_grad_norm_clip_adam(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), n, step, 8e-4, 0.9,
+                                                   0.99 if kind == "RMSprop" else 0.999, 1e-8, 0.01 if kind == "AdamW" else 0.0,
+                                                   kinds[kind], max_norm, grad_scale, N.ptr(norm), N.stream_ptr()), "cm_grad_norm_clip_adam")
+                torch.cuda.synchronize()
+                assert abs(float(norm) - want_norm) <= 1e-5 * (1 + want_norm), (kind, n, step)
+                assert _err(g[:n].cpu().numpy(), want_grad.numpy()) <= 1e-6, (kind, n, max_norm, step)  # what optimizer.step() consumed
+                assert _err(p.cpu().numpy(), ref.detach().numpy()) <= 1e-6, (kind, n, max_norm, step)
