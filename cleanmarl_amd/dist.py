@@ -14,11 +14,17 @@ def shard(n_envs, rank, world):
 
 
 def allreduce_sum_(buf, pg=None, world=1):
-    """THE data-path collective: one all-reduce(sum) of [actor grads | stats | critic grads | stats] per
-    optimiser step (latency-bound ~150 KB message; RCCL picks a one-shot/tree algorithm over xGMI)."""
+    """THE data-path collective: all-reduce(sum) of a [grads | stats] buffer per optimiser step (latency-bound 30 - 150 KB
+    messages; RCCL picks a one-shot/tree algorithm over xGMI).  Blocking form: GRU chunk steps, COMA, single passes."""
     if world > 1:
         torch.distributed.all_reduce(buf, group=pg)
     return buf
+
+
+def allreduce_sum_async(buf, pg=None):
+    """Same collective, not waited for: returns the work handle (`.wait()` makes the CURRENT stream wait, not the host, on RCCL).
+    PPOLearner uses it to put the actor's message under the critic pass and the critic's under the next actor pass."""
+    return torch.distributed.all_reduce(buf, group=pg, async_op=True)
 
 
 def merge_moments_(mom, pg=None, world=1):

@@ -341,12 +341,42 @@ class PPOLearner:
         if self.gbuf_rows.shape[0] < nE0:
             raise N.NativeError(f"epochs={nE0} exceeds the {self.gbuf_rows.shape[0]} gradient rows allocated at construction")
         kept = []
-        for ep in range(nE0):
+        if self.world > 1:
+            # N > 1: the two networks are independent, so each one's all-reduce is issued right after its pass and waited for only where
+            # its optimiser step is due -- the actor's message travels under the critic pass, the critic's under the NEXT epoch's actor
+            # pass (its Adam step is deferred to just before the next critic pass).  Same sums, same order of updates per network; only
+            # the last critic message of an update is exposed.  Issue order is identical on every rank.
+            kept_a, kept_c = [], []
+            pending = None
+
+            def finish_critic(p):
+                work, epi, gc = p
+                work.wait()
+                self._adam(self.critic, gc, self.opt_c, 1, s, out_norm=rec[epi, 2 * N.NUM_STATS + 1:])
+                if keep_grads:
+                    kept_c.append((gc[:Pc].clone(), self.critic.clone()))
+
+            for ep in range(nE0):
+                g = self.gbuf_rows[ep]
+                g_actor, g_critic = g[:Pa + N.NUM_STATS], g[Pa + N.NUM_STATS:]
+                self._timed("actor", self.actor_pass, b, s, g_actor)
+                wa = dist.allreduce_sum_async(g_actor, self.pg)
+                if pending is not None:
+                    finish_critic(pending)
+                self._timed("critic", self.critic_pass, b, s, g_critic)
+                pending = (dist.allreduce_sum_async(g_critic, self.pg), ep, g_critic)
+                wa.wait()
+                self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
+                if keep_grads:
+                    kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
+            if pending is not None:
+                finish_critic(pending)
+            kept = [(ka[0], kc[0], ka[1], kc[1]) for ka, kc in zip(kept_a, kept_c)]
+        for ep in range(nE0 if self.world == 1 else 0):
             g = self.gbuf_rows[ep]
             g_actor, g_critic = g[:Pa + N.NUM_STATS], g[Pa + N.NUM_STATS:]
             self._timed("actor", self.actor_pass, b, s, g_actor)
             self._timed("critic", self.critic_pass, b, s, g_critic)
-            self._allreduce(g)  # the only data-path collective: grads + N + stat sums
             self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
             self._adam(self.critic, g_critic, self.opt_c, 1, s, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
             if keep_grads:
