@@ -10,8 +10,15 @@ grad all-reduce when N > 1, fused norm/clip/Adam).  Inputs never leave HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement): `value` = agents*envs*steps per second
-summed over all ranks (weak scaling: every rank owns `--envs` environments, global env index = rank*E + e).
+Prints ONE JSON line on rank 0 (contract in the task statement): `value` = agents*envs*steps per second summed over all
+ranks.  Scaling is STRONG by default, as BASELINE.json's north_star defines it ("num_envs shards across the 8 GPUs"): the
+workload's env count is global, rank r owns envs dist.shard(E, r, N), global env index = first + e.  `--scaling weak` keeps E
+envs on every rank instead; with N > 1 the default run also times a short weak-scaling leg after the timed region and reports
+it under "weak_scaling" (extra key; `value` is always the mode named in "scaling").
+
+Extra keys (N = 1): "phase_roofline" (rollout / value pass / critic against their own bounds), "other_workloads" (the other
+BASELINE.json configs, a few steps each after the timed region) and "strong_scaling_shares" (the per-GPU share of each sharded
+config timed on this one GPU: t(E) / t(E/8) bounds the 8-GPU speed-up before the all-reduces).
 """
 import argparse
 import json
@@ -27,14 +34,141 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (envs per GPU, A, T, algo, env, actor, description) -- BASELINE.json configs[2] is the headline (the metric is
-    # quoted on it) and the default; the others are parity-test cases that can be timed on request (--workload)
+    # name: (GLOBAL envs, A, T, algo, env, actor, description) -- BASELINE.json configs[2] is the headline (the metric is
+    # quoted on it) and the default; the others are parity-test cases, timed after the headline (other_workloads) or on request
     "cfg3": (4096, 8, 128, "mappo", "spread", "mlp", "MAPPO synthetic-MPE 4096 envs x 8 agents x 128 steps, 2x64 MLP (BASELINE.json configs[2])"),
     "cfg2": (1024, 3, 128, "mappo", "spread", "mlp", "MAPPO synthetic-MPE 1024 envs x 3 agents x 128 steps, 2x64 MLP (BASELINE.json configs[1])"),
-    "cfg4": (256, 10, 256, "ippo", "shape", "mlp", "IPPO smaclite-shape synthetic, 256 envs per GPU (2048 / 8 GPUs) x 10 agents x 256 steps, 2x64 MLP (BASELINE.json configs[3])"),
+    "cfg4": (2048, 10, 256, "ippo", "shape", "mlp", "IPPO smaclite-shape synthetic 2048 envs x 10 agents x 256 steps, 2x64 MLP (BASELINE.json configs[3])"),
     "cfg5": (1024, 5, 128, "mappo", "spread", "gru", "MAPPO-GRU synthetic-MPE 1024 envs x 5 agents x 128 steps, GRU hidden 64, tbptt 10 (BASELINE.json configs[4])"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec rate
+
+
+class Workload:
+    """One BASELINE config on this rank's env shard: device rollout + learner, reference default hyper-parameters."""
+
+    def __init__(self, name, E, env_offset, dev, pg=None, world=1):
+        from cleanmarl_amd.gru import GRUPPOLearner, GRUSyntheticRollout
+        from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch
+        from cleanmarl_amd.rollout import SyntheticShapeRollout, SyntheticSpreadRollout
+        _, A, T, algo, env_kind, actor_kind, desc = WORKLOADS[name]
+        self.name, self.E, self.A, self.T, self.algo, self.actor_kind, self.desc = name, E, A, T, algo, actor_kind, desc
+        self.world, self.pg = world, pg
+        self.hp = hp = HParams()  # reference defaults: gamma .99, lambda .95, eps .2, c_ent 1e-3, lr 8e-4, epochs 3 (tbptt 10)
+        if env_kind == "shape":
+            self.roll = SyntheticShapeRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=env_offset)
+        elif actor_kind == "gru":
+            self.roll = GRUSyntheticRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=env_offset)
+        else:
+            self.roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=env_offset)
+        roll = self.roll
+        self.aspec = NetSpec(roll.Do, 64, 0 if actor_kind == "gru" else 1, roll.K, actor_kind)
+        self.cspec = NetSpec(roll.Ds if algo == "mappo" else roll.Do, 64, 1, 1)
+        torch.manual_seed(1)  # reference construction order actor -> critic (:329-339); identical on every rank
+        a_init = init_params_like_torch(self.aspec)
+        c_init = init_params_like_torch(self.cspec)
+        self.learner = (GRUPPOLearner if actor_kind == "gru" else PPOLearner)(algo, self.aspec, self.cspec, A, hp, dev, a_init, c_init,
+                                                                          pg, world)
+
+    def one_step(self, evts=None):
+        L = self.learner
+        if evts is not None:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        b = self.roll.collect(L.actor, self.aspec)
+        if evts is not None:
+            e[1].record()
+        L.compute_targets(b)
+        if evts is not None:
+            e[2].record()
+        L.update(b)
+        if evts is not None:
+            e[3].record()
+            evts.append(e)
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier(group=self.pg)
+
+    def run(self, steps, warmup):
+        """1 untimed setup pass + `warmup` untimed steps, then EXACTLY `steps` timed steps between barrier + synchronize pairs;
+        returns wall seconds (max over ranks), per-phase event times and the per-launch times of the dominant kernels."""
+        L = self.learner
+        # setup pass (not one of the W warmup steps, never timed): the first use of every entry point allocates its workspace /
+        # pinned staging buffers and loads its code object; with it the timed region measures steady-state steps even for W = 0
+        self.one_step()
+        torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.one_step()
+        torch.cuda.synchronize()
+        self.barrier()
+        L.events = []  # per-launch HIP events around the dominant kernels (same stream as the launches)
+        evts = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.one_step(evts)
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=L.device)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            dt = float(tt.item())
+        phases = [0.0, 0.0, 0.0]
+        for e in evts:
+            for i in range(3):
+                phases[i] += e[i].elapsed_time(e[i + 1])
+        phases = [p / max(1, len(evts)) for p in phases]
+        act_ms = [s.elapsed_time(e) for (k, s, e) in L.events if k == "actor"]
+        cri_ms = [s.elapsed_time(e) for (k, s, e) in L.events if k == "critic"]
+        L.events = None
+        mean = lambda v: sum(v) / max(1, len(v))
+        return dict(dt=dt, steps=steps, ms_per_step=1e3 * dt / steps, phase_ms=dict(rollout=phases[0], value_pass_scan=phases[1],
+                    update=phases[2]), actor_ms=mean(act_ms), critic_ms=mean(cri_ms))
+
+    # ---- algorithmic work per launch (SURVEY.md §8(d); weights, MFMA-tile padding and recomputation are NOT counted)
+    def work(self):
+        E, A, T, K = self.E, self.A, self.T, self.roll.K
+        Do, Dc, H = self.aspec.din, self.cspec.din, 64
+        rows_a = E * A * T
+        rows_c = E * T * (1 if self.algo == "mappo" else A)
+        if self.actor_kind == "gru":  # fc1 + 6 gate blocks + head (SURVEY.md §8a row a13)
+            Pa = Do * H + 6 * H * H + H * K
+        else:
+            Pa = Do * H + H * H + H * K
+        Pc = Dc * H + H * H + H
+        return dict(
+            rows_a=rows_a, rows_c=rows_c,
+            actor=dict(flop=rows_a * (2 * Pa + 2 * Pa + 2 * (Pa - Do * H)), bytes=rows_a * (4 * Do + K + 12)),
+            critic=dict(flop=rows_c * (4 * Pc + 2 * (Pc - Dc * H)), bytes=rows_c * (4 * Dc + 4)),
+            value_pass=dict(flop=rows_c * 2 * Pc, bytes=rows_c * (4 * Dc + 4) + E * T * (8 + 8 * A)),  # + the scan's reads / writes
+            rollout=dict(flop=rows_a * 2 * Pa, bytes=E * T * (4 * A * Do + 4 * self.roll.Ds + 4 + 8 * A)))
+
+    def close(self):
+        self.roll = self.learner = None
+        torch.cuda.empty_cache()
+
+
+def _bound(work, ms):
+    """Achieved rates of one launch / phase against BOTH peaks; the bound is the one that takes longer at peak."""
+    if ms <= 0:
+        return None
+    tf, gb = work["flop"] / (ms * 1e-3) / 1e12, work["bytes"] / (ms * 1e-3) / 1e9
+    t_mfma, t_hbm = work["flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12), work["bytes"] / (PEAK_HBM_GBS * 1e9)
+    b = "mfma" if t_mfma >= t_hbm else "hbm"
+    return dict(ms=ms, bound=b, tflops=tf, gbs=gb, frac=(tf / PEAK_F32_MFMA_TFLOPS if b == "mfma" else gb / PEAK_HBM_GBS))
+
+
+def summarize(w, r):
+    """Compact record of one timed workload (used for other_workloads / strong_scaling_shares)."""
+    wk = w.work()
+    units = w.world * w.E * w.A * w.T * r["steps"]
+    return dict(envs=w.E, ms_per_step=r["ms_per_step"], value=units / r["dt"], phase_ms=r["phase_ms"],
+                actor_fwd_bwd_ms=r["actor_ms"], critic_fwd_bwd_ms=r["critic_ms"],
+                roofline_frac=(_bound(wk["actor"], r["actor_ms"]) or {}).get("frac"))
 
 
 def main():
@@ -43,9 +177,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, north_star): the workload's envs are sharded over the ranks; weak: every rank owns all of them")
+    ap.add_argument("--envs", type=int, default=0, help="override the env count (global in strong mode, per GPU in weak mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=64, help="envs in the bounded CPU-baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / strong_scaling_shares / weak_scaling legs")
+    ap.add_argument("--cpu-envs", type=int, default=256, help="envs in the bounded CPU-baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,123 +209,134 @@ def main():
         pg = torch.distributed.group.WORLD
 
     from cleanmarl_amd import _native as N
-    from cleanmarl_amd.gru import GRUPPOLearner, GRUSyntheticRollout
-    from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner, init_params_like_torch
-    from cleanmarl_amd.rollout import SyntheticShapeRollout, SyntheticSpreadRollout
+    from cleanmarl_amd import dist
 
-    E, A, T, algo, env_kind, actor_kind, desc = WORKLOADS[args.workload]
-    if args.envs:
-        E = args.envs
-    hp = HParams()  # reference defaults: gamma .99, lambda .95, eps .2, c_ent 1e-3, lr 8e-4, epochs 3 (tbptt 10)
-    if env_kind == "shape":
-        roll = SyntheticShapeRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
-    elif actor_kind == "gru":
-        roll = GRUSyntheticRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
+    E_glob = args.envs or WORKLOADS[args.workload][0]
+    if args.scaling == "strong":
+        if E_glob < world:
+            raise SystemExit(f"{E_glob} envs cannot be sharded over {world} ranks")
+        first, E = dist.shard(E_glob, rank, world)
     else:
-        roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, env_offset=rank * E)
-    aspec = NetSpec(roll.Do, 64, 0 if actor_kind == "gru" else 1, roll.K, actor_kind)
-    cspec = NetSpec(roll.Ds if algo == "mappo" else roll.Do, 64, 1, 1)
-    torch.manual_seed(1)  # reference construction order actor -> critic (:329-339); identical on every rank
-    a_init = init_params_like_torch(aspec)
-    c_init = init_params_like_torch(cspec)
-    learner = (GRUPPOLearner if actor_kind == "gru" else PPOLearner)(algo, aspec, cspec, A, hp, dev, a_init, c_init, pg, world)
+        first, E = rank * E_glob, E_glob
+    w = Workload(args.workload, E, first, dev, pg, world)
+    r = w.run(args.steps, args.warmup)
+    A, T, hp = w.A, w.T, w.hp
+    total_envs = E_glob if args.scaling == "strong" else world * E_glob
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier(group=pg)
-
-    def one_step(evts=None):
-        if evts is not None:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-        b = roll.collect(learner.actor, aspec)
-        if evts is not None:
-            e[1].record()
-        learner.compute_targets(b)
-        if evts is not None:
-            e[2].record()
-        learner.update(b)
-        if evts is not None:
-            e[3].record()
-            evts.append(e)
-
-    # setup pass (not one of the W warmup steps, never timed): the first use of every entry point allocates its workspace / pinned
-    # staging buffers and loads its code object; with it the timed region measures steady-state steps even for --warmup 0
-    one_step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    barrier()
-    learner.events = []  # per-launch HIP events around the dominant kernels (same stream as the launches)
-    evts = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(evts)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
-        dt = float(tt.item())
-
-    phases = [0.0, 0.0, 0.0]
-    for e in evts:
-        for i in range(3):
-            phases[i] += e[i].elapsed_time(e[i + 1])
-    phases = [p / max(1, len(evts)) for p in phases]
-    act_ms = [s.elapsed_time(e) for (k, s, e) in learner.events if k == "actor"]
-    cri_ms = [s.elapsed_time(e) for (k, s, e) in learner.events if k == "critic"]
-    learner.events = None
-
+    out = None
     if rank == 0:
-        units = world * E * A * T * args.steps
-        rows_a = E * A * T
-        if actor_kind == "gru":  # fc1 + 6 gate blocks + head
-            Pa = aspec.din * 64 + 6 * 64 * 64 + 64 * roll.K
-        else:
-            Pa = aspec.din * 64 + 64 * 64 + 64 * roll.K
-        flop_actor = rows_a * (2 * Pa + 2 * Pa + 2 * (Pa - aspec.din * 64))  # fwd + dW + dX
-        avg_actor_ms = sum(act_ms) / max(1, len(act_ms))
-        achieved = flop_actor / (avg_actor_ms * 1e-3) / 1e12 if avg_actor_ms > 0 else 0.0
+        units = total_envs * A * T * args.steps
+        wk = w.work()
+        act = _bound(wk["actor"], r["actor_ms"]) or dict(tflops=0.0)
+        achieved = act["tflops"]
+        desc = w.desc if not args.envs else f"{w.desc} [envs overridden to {E_glob}]"
         out = {
-            "metric": "env-steps/sec (agents x envs x steps), MAPPO full iteration", "value": units / dt,
+            "metric": "env-steps/sec (agents x envs x steps), MAPPO full iteration", "value": units / r["dt"],
             "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if N.load().cm_mfma_mode() == 0 else "bf16x3 (opt-in CM_MFMA=bf16x3: error-compensated bf16 MFMA products, fp32 accumulate and storage)",
             "data": "synthetic",
-            "config": {"workload": desc if not args.envs else f"{desc} [envs/GPU overridden to {E}]",
-                       "envs_per_gpu": E, "agents": A, "steps": T, "epochs": hp.epochs, "parallelism": f"env-sharded x{world}"},
-            "ppo_update_ms": phases[2], "ppo_update_ms_per_epoch": phases[2] / hp.epochs,
-            "phase_ms": {"rollout": phases[0], "value_pass_scan": phases[1], "update": phases[2]},
-            "kernel_ms": {"actor_fwd_bwd": avg_actor_ms, "critic_fwd_bwd": sum(cri_ms) / max(1, len(cri_ms))},
-            "roofline": {"kernel": "k_mlp<NCH,M_ACTOR> (cm_ppo_actor_fwd_bwd)" if actor_kind == "mlp" else
+            "config": {"workload": desc, "global_envs": total_envs, "envs_per_gpu": E, "agents": A, "steps": T, "epochs": hp.epochs,
+                       "parallelism": f"env-sharded x{world} ({args.scaling} scaling), one all-reduce per network and optimiser step"},
+            "ppo_update_ms": r["phase_ms"]["update"], "ppo_update_ms_per_epoch": r["phase_ms"]["update"] / hp.epochs,
+            "phase_ms": r["phase_ms"],
+            "kernel_ms": {"actor_fwd_bwd": r["actor_ms"], "critic_fwd_bwd": r["critic_ms"]},
+            "roofline": {"kernel": "k_mlp<NCH,M_ACTOR> (cm_ppo_actor_fwd_bwd)" if w.actor_kind == "mlp" else
                          "k_gru_chunk_fwd + k_gru_chunk_bwd (all TBPTT chunks of one epoch)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "flop_per_launch": flop_actor},
+                         "traffic": None, "flop_per_launch": wk["actor"]["flop"]},
+            # the other phases of the step against their own bounds (algorithmic work of SURVEY.md §8(d) / event time)
+            "phase_roofline": {"rollout": _bound(wk["rollout"], r["phase_ms"]["rollout"]),
+                               "value_pass_scan": _bound(wk["value_pass"], r["phase_ms"]["value_pass_scan"]),
+                               "critic_fwd_bwd": _bound(wk["critic"], r["critic_ms"]),
+                               "whole_step": _bound(dict(flop=wk["rollout"]["flop"] + wk["value_pass"]["flop"] + hp.epochs * (wk["actor"]["flop"] + wk["critic"]["flop"]),
+                                                         bytes=wk["rollout"]["bytes"] + wk["value_pass"]["bytes"] + hp.epochs * (wk["actor"]["bytes"] + wk["critic"]["bytes"])),
+                                                    r["ms_per_step"])},
         }
         # HBM bytes of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read
         # live here); tools/pmc_summary.py writes them to profiles/pmc_dominant_kernel.json
         pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
-        if os.path.exists(pmc_path) and args.workload == "cfg3" and not args.envs:
+        if os.path.exists(pmc_path) and args.workload == "cfg3" and not args.envs and world == 1:
             pmc = json.load(open(pmc_path))
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = pmc["source"]
             out["roofline"]["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
-            out["roofline"]["algorithmic_bytes_per_launch"] = rows_a * (4 * aspec.din + roll.K + 12)
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import reference_loop  # checker / baseline only -- never part of the measured path
-            Ec = args.cpu_envs
-            r = reference_loop.run(E=Ec, A=A, T=T)
-            out["cpu_baseline"] = {"value": r["agent_steps_per_s"], "unit": "agent-env-steps/s",
-                                   "cores": min(os.cpu_count() or 1, Ec + r["threads"]), "kind": "port",
-                                   "sample": f"one iteration of the reference-structured driver (oracle/reference_loop.py: "
-                                             f"process-per-env pipes, per-step python loops) at {Ec} envs x {A} agents x {T} steps, "
-                                             f"torch threads={r['threads']}; rollout {r['rollout_s']:.2f}s gae {r['gae_s']:.2f}s "
-                                             f"update {r['update_s']:.2f}s"}
+            out["roofline"]["algorithmic_bytes_per_launch"] = wk["actor"]["bytes"]
+    w.close()
+
+    if not args.no_extras and world > 1:
+        # the two messages of an optimiser step, timed alone (latency-bound: 33 KB / 116 KB at cfg 3), and a short weak-scaling leg
+        lat = {}
+        for nm, n in (("actor", w.aspec.nparams + N.NUM_STATS), ("critic", w.cspec.nparams + N.NUM_STATS)):
+            buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            for _ in range(20):
+                torch.distributed.all_reduce(buf, group=pg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                torch.distributed.all_reduce(buf, group=pg)
+            e1.record()
+            torch.cuda.synchronize()
+            lat[f"{nm}_{4 * n}B"] = 1e3 * e0.elapsed_time(e1) / 100
+        other = "weak" if args.scaling == "strong" else "strong"
+        if other == "weak":
+            w2 = Workload(args.workload, E_glob, rank * E_glob, dev, pg, world)
+            tot2 = world * E_glob
+        else:
+            f2, e2 = dist.shard(E_glob, rank, world)
+            w2 = Workload(args.workload, e2, f2, dev, pg, world)
+            tot2 = E_glob
+        r2 = w2.run(max(3, min(args.steps, 10)), 2)
+        w2.close()
+        if rank == 0:
+            out["allreduce_us"] = lat
+            out[f"{other}_scaling"] = {"value": tot2 * A * T * r2["steps"] / r2["dt"], "ms_per_step": r2["ms_per_step"],
+                                       "global_envs": tot2, "steps": r2["steps"], "phase_ms": r2["phase_ms"]}
+
+    if rank == 0 and world == 1 and not args.no_extras and not args.envs:
+        # the other BASELINE configs (parity-test cases) and the per-GPU shares of the sharded ones, a few steps each, after the
+        # timed region of the headline config
+        others, shares = {}, {}
+        full_ms = {args.workload: out["ms_per_step"]}
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            if name == args.workload:
+                continue
+            ww = Workload(name, WORKLOADS[name][0], 0, dev)
+            rr = ww.run(5, 2)
+            others[name] = dict(summarize(ww, rr), workload=ww.desc)
+            full_ms[name] = rr["ms_per_step"]
+            ww.close()
+        for name in ("cfg3", "cfg4"):  # the configs north_star shards over 8 GPUs
+            Eg = WORKLOADS[name][0]
+            rec = {}
+            for g in (2, 4, 8):
+                ww = Workload(name, Eg // g, 0, dev)
+                rr = ww.run(10, 3)
+                rec[f"1/{g} ({Eg // g} envs)"] = dict(ms_per_step=rr["ms_per_step"], phase_ms=rr["phase_ms"],
+                                                      speedup_bound=full_ms[name] / rr["ms_per_step"])
+                ww.close()
+            shares[name] = dict(full_ms_per_step=full_ms[name], shares=rec,
+                                note="one GPU's share timed on ONE GPU: full / share bounds the N-GPU speed-up before the all-reduces")
+        out["other_workloads"] = others
+        out["strong_scaling_shares"] = shares
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import reference_loop  # checker / baseline only -- never part of the measured path
+        Ec, cores = args.cpu_envs, os.cpu_count() or 1
+        sweep = sorted({1, min(8, cores), cores})
+        rc = reference_loop.run(E=Ec, A=A, T=T, thread_sweep=sweep)
+        th = rc["threads"]
+        out["cpu_baseline"] = {"value": rc["agent_steps_per_s"], "unit": "agent-env-steps/s",
+                               "cores": min(cores, Ec + max(th.values())), "kind": "port",
+                               "sample": f"one iteration of the reference-structured driver (oracle/reference_loop.py: "
+                                         f"process-per-env pipes, per-step python loops) at {Ec} envs x {A} agents x {T} steps on a "
+                                         f"{cores}-core host; torch intra-op threads swept over {sweep} per phase on a slice of the batch "
+                                         f"and the fastest kept (rollout {th['rollout']}, scan {th['gae']}, update {th['update']}; torch's "
+                                         f"default = all cores is the slowest for these tiny ops); rollout {rc['rollout_s']:.2f}s gae "
+                                         f"{rc['gae_s']:.2f}s update {rc['update_s']:.2f}s",
+                               "thread_probe_s": rc["thread_probes"]}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -8,9 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcleanmarl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"]
-# per-file flags: the wave-private actor kernel sits at the 256-register limit; LLVM's GCN pressure trackers keep its accumulators
-# out of scratch (62 -> 36 spilled registers, none of them accumulators).  Kept off the other translation units on purpose.
-FILE_FLAGS = {"cm_mlp_actor16.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]}
+FILE_FLAGS = {}  # per-file extra flags (none: the wave-private actor probe that needed some lives in tools/probes/actor16/)
 
 
 def sources():

@@ -77,10 +77,10 @@ def run(script, argv=None):
     elif single_env:
         the_env = environment(**dict(fac, index=env_offset))
     elif args.vector_env == "pipe":
-        venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
+        venv = PipeVectorEnv(E, dict(fac, synthetic=synth), index_offset=env_offset)
     else:
-        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None)
-    host_actor = HostActor(learner, A, False, device)
+        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None, index_offset=env_offset)
+    host_actor = HostActor(learner, A, False, device, row_offset=env_offset * A)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
     run_name = f"{RUN_PREFIX[script]}-{args.env_type}__{args.env_name}__{time_token}"

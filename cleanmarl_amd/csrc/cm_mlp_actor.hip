@@ -1,6 +1,5 @@
 // cm_mlp_actor.hip -- cm_ppo_actor_fwd_bwd (a8/a9, actor side)
 #include "cm_mlp_wide.h"
-#include "cm_mlp_actor16.h"
 
 #ifdef CM_PHASE_PROF
 unsigned long long* g_prof = nullptr;
@@ -46,16 +45,6 @@ extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, cons
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
-    if (cm_actor16_enabled() && cm_actor16_supports(a.din, a.H, a.L, a.dout, can_vec(a), a.PS)) {  // opt-in wave-private kernel (cm_mlp_actor16.hip)
-        A16Args w;
-        w.x = a.x; w.params = a.params; w.avail = a.avail; w.action = a.action; w.logp_old = a.logp_old; w.adv = a.adv; w.ep_len = a.ep_len;
-        w.partial = a.partial; w.rows = a.rows; w.x_stride = a.x_stride; w.avail_stride = a.avail_stride;
-        w.din = a.din; w.H = a.H; w.dout = a.dout; w.A = a.A; w.T = a.T; w.PS = a.PS;
-        w.clip_lo = a.clip_lo; w.clip_hi = a.clip_hi; w.clip_eps = a.clip_eps; w.ent_coef = a.ent_coef;
-        const int g16 = cm_actor16_launch(w, (hipStream_t)stream);
-        CM_CHECK_LAUNCH("cm_ppo_actor_fwd_bwd");
-        return finish_train(a, g16, P, grad_and_stats, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");
-    }
     const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     if (int rc = launch_train<M_ACTOR>(a, grid, lds_bytes, (hipStream_t)stream)) return rc;

@@ -35,8 +35,11 @@ RUN_PREFIX = {  # run-name strings of the four scripts (si
 class HostActor:
     """Actor.act for observations that live on the host (real envs, eval): stage -> cm_policy_act -> fetch."""
 
-    def __init__(self, learner, n_agents, recurrent, device):
+    def __init__(self, learner, n_agents, recurrent, device, row_offset=0):
+        """row_offset: global index of this rank's first (env, agent) row (= env_offset * A when the batch is env-sharded over
+        ranks): it enters the Philox key of the sampler, so ranks draw different uniforms for their shards."""
         self.L, self.A, self.recurrent, self.dev = learner, n_agents, recurrent, device
+        self.row_offset = int(row_offset)
         self.lib = N.load()
         self.calls = 0
         self.ws = None
@@ -53,7 +56,7 @@ class HostActor:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
             N.check(self.lib.cm_gru_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
-                                               N.ptr(self.L.actor), N.ptr(h), seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                               N.ptr(self.L.actor), N.ptr(h), seed, self.row_offset, self.calls, N.ptr(action), N.ptr(logp), 1,
                                                N.stream_ptr()), "cm_gru_policy_act")
         else:
             # eps < 0: argmax of the masked logits (build option; the reference always samples); eps > 0: COMA exploration
@@ -62,7 +65,7 @@ class HostActor:
             if need and (self.ws is None or self.ws.numel() < need):
                 self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             N.check(self.lib.cm_policy_act_ws(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
-                                              spec.dout, N.ptr(self.L.actor), mode, seed, 0, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                              spec.dout, N.ptr(self.L.actor), mode, seed, self.row_offset, self.calls, N.ptr(action), N.ptr(logp), 1,
                                               N.ptr(self.ws) if need else None, need, N.stream_ptr()), "cm_policy_act_ws")
         return action.cpu().numpy(), logp.cpu().numpy(), h
 
@@ -226,10 +229,10 @@ def run(script, argv=None):
     elif single_env:
         the_env = environment(**dict(fac, index=env_offset))  # cleanmarl/mappo.py:235-241: one in-process env
     elif args.vector_env == "pipe":
-        venv = PipeVectorEnv(E, dict(fac, synthetic=synth))
+        venv = PipeVectorEnv(E, dict(fac, synthetic=synth), index_offset=env_offset)
     else:
-        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None)
-    host_actor = HostActor(learner, A, recurrent, device)
+        venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None, index_offset=env_offset)
+    host_actor = HostActor(learner, A, recurrent, device, row_offset=env_offset * A)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
     run_name = f"{RUN_PREFIX[script]}-{args.env_type}__{args.env_name}__{time_token}"

@@ -18,10 +18,10 @@ import numpy as np
 from .vector import environment
 
 
-def _worker(conn, factory_args, lo, hi, names, shapes):
+def _worker(conn, factory_args, lo, hi, names, shapes, index_offset=0):
     shms = {k: shared_memory.SharedMemory(name=n) for k, n in names.items()}
     arr = {k: np.ndarray(shapes[k][0], dtype=shapes[k][1], buffer=shms[k].buf) for k in names}
-    envs = [environment(**dict(factory_args, index=i)) for i in range(lo, hi)]
+    envs = [environment(**dict(factory_args, index=index_offset + i)) for i in range(lo, hi)]
     try:
         while True:
             task = conn.recv()
@@ -57,8 +57,9 @@ def _worker(conn, factory_args, lo, hi, names, shapes):
 
 
 class ShmVectorEnv:
-    def __init__(self, n_envs, factory_args, n_workers=None):
-        probe = environment(**dict(factory_args, index=0))
+    def __init__(self, n_envs, factory_args, n_workers=None, index_offset=0):
+        """index_offset: global index of local env 0 (this rank's first env when the batch is env-sharded over ranks)."""
+        probe = environment(**dict(factory_args, index=index_offset))
         self.E, self.A = n_envs, probe.n_agents
         self.Do, self.Ds, self.K = probe.get_obs_size(), probe.get_state_size(), probe.get_action_size()
         probe.close()
@@ -77,7 +78,7 @@ class ShmVectorEnv:
             if lo == hi:
                 continue
             parent, child = Pipe()
-            p = Process(target=_worker, args=(child, factory_args, lo, hi, names, self.shapes), daemon=True)
+            p = Process(target=_worker, args=(child, factory_args, lo, hi, names, self.shapes, index_offset), daemon=True)
             p.start()
             self.conns.append(parent); self.procs.append(p)
 

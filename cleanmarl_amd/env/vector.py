@@ -29,10 +29,9 @@ def environment(env_type, env_name, env_family, agent_ids, kwargs=None, index=0,
     if env_type == "smaclite":
         mod = importlib.import_module("cleanmarl_amd.env.smaclite_wrapper")
         return mod.SMACliteWrapper(map_name=env_name, agent_ids=agent_ids, **kwargs)
-    if env_type == "lbf":  # the COMA scripts' third env type (cleanmarl/coma_multienvs.py:248-258)
-        mod = importlib.import_module("cleanmarl_amd.env.lbf_wrapper")
-        return mod.LBFWrapper(map_name=env_name, agent_ids=agent_ids, **kwargs)
-    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, lbf, synthetic[_cpu], synthetic_shape[_cpu])")
+    if env_type == "lbf":  # the COMA scripts' third env type (cleanmarl/coma_multienvs.py:248-258): SURVEY.md §2 row 8, out of scope
+        raise ValueError("env_type 'lbf' (level-based foraging) is outside this build's scope (SURVEY.md §2); use pz / smaclite / synthetic*")
+    raise ValueError(f"unknown env_type {env_type!r} (pz, smaclite, synthetic[_cpu], synthetic_shape[_cpu])")
 
 
 def env_worker(conn, factory_args):
@@ -58,14 +57,15 @@ def env_worker(conn, factory_args):
 
 
 class PipeVectorEnv:
-    """B daemon processes, one env each."""
+    """B daemon processes, one env each.  index_offset: global index of env 0 (the first env of this rank's shard when the
+    batch is env-sharded over ranks), so that index-keyed envs differ between ranks."""
 
-    def __init__(self, n, factory_args):
+    def __init__(self, n, factory_args, index_offset=0):
         self.n = n
         self.conns, self.procs = [], []
         for i in range(n):
             parent, child = Pipe()
-            p = Process(target=env_worker, args=(child, dict(factory_args, index=i)), daemon=True)
+            p = Process(target=env_worker, args=(child, dict(factory_args, index=index_offset + i)), daemon=True)
             p.start()
             self.conns.append(parent)
             self.procs.append(p)

@@ -45,11 +45,34 @@ def _mlp(din, hidden, n_layers, dout):
     return nn.Sequential(*layers)
 
 
+def _pick_threads(fn, sweep):
+    """Time fn() under each torch thread count of `sweep`; leave the fastest one set and return (best, {threads: seconds})."""
+    seen = {}
+    for n in sweep:
+        torch.set_num_threads(int(n))
+        t0 = time.perf_counter()
+        fn()
+        seen[int(n)] = time.perf_counter() - t0
+    best = min(seen, key=seen.get)
+    torch.set_num_threads(best)
+    return best, seen
+
+
 def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, clip=0.2, ent_coef=1e-3, lr=8e-4,
-        iterations=1):
+        iterations=1, thread_sweep=None):
     """One (or more) full training iteration(s) in the reference's loop structure.  Returns a dict with the
-    per-phase wall times, agent-steps/s and the final batch / params (for the numerics check)."""
+    per-phase wall times, agent-steps/s and the final batch / params (for the numerics check).
+    thread_sweep: torch intra-op thread counts to try, e.g. (1, 8, os.cpu_count()).  The TD(lambda) loop (single-row critic
+    calls) and the update (per-timestep graphs over E rows) are probed on a slice of the first iteration's batch -- 8 episodes for
+    the scan, one throw-away epoch on copies of the networks for the update -- and each phase then runs with ITS fastest count
+    (the probes are not part of the reported times).  The reference itself runs with torch's default (= all cores), which is
+    the slowest choice for these tiny ops on a many-core host; the baseline reported is the fair one."""
+    import copy
     torch.manual_seed(seed)
+    thr = {"rollout": torch.get_num_threads(), "gae": torch.get_num_threads(), "update": torch.get_num_threads()}
+    probes = {}
+    if thread_sweep:
+        thr["rollout"] = int(min(thread_sweep))  # [E*A, Do] forward per step: too small to split
     Do, Ds, K = 7 * A, 6 * A * A, 5
     actor = _mlp(Do, hidden, n_layers, K)
     critic = _mlp(Ds, hidden, n_layers, 1)
@@ -65,6 +88,7 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
     t_roll = t_gae = t_upd = 0.0
     out = {}
     for _ in range(iterations):
+        torch.set_num_threads(thr["rollout"])
         t0 = time.perf_counter()
         # ---------------- rollout: one pipe round trip per env per step
         eps = [dict(obs=[], actions=[], log_prob=[], reward=[], states=[], avail=[]) for _ in range(E)]
@@ -109,6 +133,15 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
             b_rew[i, :n] = e["reward"]; b_st[i, :n] = e["states"]; b_mask[i, :n] = True
         b_act = b_act.long(); b_av = b_av.bool()
         t1 = time.perf_counter()
+        if thread_sweep and "gae" not in probes:
+            def gae_probe():
+                with torch.no_grad():
+                    for i in range(min(E, 8)):
+                        for t in range(lens[i]):
+                            critic(b_st[i, t]); critic(b_st[i, t])
+            thr["gae"], probes["gae"] = _pick_threads(gae_probe, thread_sweep)
+        torch.set_num_threads(thr["gae"])
+        t1b = time.perf_counter()  # the probe is not part of any phase
         # ---------------- TD(lambda): per-episode reversed loop, single-row critic calls
         ret = torch.zeros(E, Tm, A); adv = torch.zeros(E, Tm, A)
         with torch.no_grad():
@@ -119,6 +152,18 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
                     ret[i, t] = last = b_rew[i, t] + gamma * (lam * last + (1 - lam) * nv)
                     adv[i, t] = ret[i, t] - critic(b_st[i, t])
         t2 = time.perf_counter()
+        if thread_sweep and "update" not in probes:
+            def upd_probe():
+                a2, c2 = copy.deepcopy(actor), copy.deepcopy(critic)
+                al = 0; cl = 0
+                for t in range(Tm):
+                    d = Categorical(logits=a2(b_obs[:, t]).masked_fill(~b_av[:, t], -1e9))
+                    al = al + (torch.exp(d.log_prob(b_act[:, t]) - b_lp[:, t]) * adv[:, t]).sum() + d.entropy().sum()
+                    cl = cl + nn.functional.mse_loss(c2(b_st[:, t]).expand(-1, A), ret[:, t])
+                al.backward(); cl.backward()
+            thr["update"], probes["update"] = _pick_threads(upd_probe, thread_sweep)
+        torch.set_num_threads(thr["update"])
+        t2b = time.perf_counter()
         # ---------------- update: epochs x T per-timestep graphs
         logs = []
         for _ep in range(epochs):
@@ -139,7 +184,7 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
             opt_a.step(); opt_c.step()
             logs.append((a_loss.item(), c_loss.item()))
         t3 = time.perf_counter()
-        t_roll += t1 - t0; t_gae += t2 - t1; t_upd += t3 - t2
+        t_roll += t1 - t0; t_gae += t2 - t1b; t_upd += t3 - t2b
         out = dict(batch=dict(obs=b_obs, actions=b_act, log_probs=b_lp, reward=b_rew, states=b_st, avail=b_av, mask=b_mask),
                    ret=ret, adv=adv, logs=logs)
     for c in conns:
@@ -150,5 +195,5 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
     out.update(init=init, actor=[p.detach().clone() for p in actor.parameters()],
                critic=[p.detach().clone() for p in critic.parameters()],
                rollout_s=t_roll, gae_s=t_gae, update_s=t_upd, total_s=total,
-               agent_steps_per_s=iterations * E * A * T / total, threads=torch.get_num_threads())
+               agent_steps_per_s=iterations * E * A * T / total, threads=thr, thread_probes=probes)
     return out

@@ -1,0 +1,143 @@
+"""Stand-ins for the optional env packages (pettingzoo, smaclite, gymnasium -- none is installable in the build image or
+on the GPU box) so that the adapters in cleanmarl_amd/env/ are EXECUTED by tests: `install(monkeypatch)` puts fake modules
+with the real packages' call surface into sys.modules (forked env workers inherit them).  The fakes are deterministic toy
+dynamics, not the real games; what is under test is the adapter contract of cleanmarl/env/pettingzoo_wrapper.py:33-101 and
+cleanmarl/env/smaclite_wrapper.py:12-60."""
+import sys
+import types
+
+import numpy as np
+
+
+class _Box:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n = int(n)
+
+    def sample(self):
+        return 0
+
+
+class FakeParallelEnv:
+    """pettingzoo ParallelEnv surface of mpe.simple_spread_v3: dict-keyed obs / rewards / terminations / truncations / infos,
+    truncation of every agent at max_cycles (observations still returned), and -- with terminate_at=k -- a TERMINATION at step
+    k that returns EMPTY observation and reward dicts, the case cleanmarl/env/pettingzoo_wrapper.py:58-64 handles."""
+
+    def __init__(self, N=3, max_cycles=25, terminate_at=None, n_actions=None, obs_dim=18, **_):
+        self.possible_agents = [f"agent_{i}" for i in range(N)]
+        self.agents = list(self.possible_agents)
+        self.max_cycles, self.terminate_at, self.obs_dim = int(max_cycles), terminate_at, int(obs_dim)
+        self.n_actions = list(n_actions) if n_actions is not None else [5] * N
+        self.t, self.x = 0, np.zeros((N, obs_dim))
+
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    def observation_space(self, agent):
+        return _Box((self.obs_dim,))
+
+    def action_space(self, agent):
+        return _Discrete(self.n_actions[self.possible_agents.index(agent)])
+
+    def _obs(self):
+        return {a: (self.x[i] + 0.01 * i).astype(np.float32) for i, a in enumerate(self.possible_agents)}
+
+    def reset(self, seed=None, options=None):
+        self.agents = list(self.possible_agents)
+        self.t = 0
+        self.x = np.full((len(self.agents), self.obs_dim), 0.0 if seed is None else float(seed))
+        return self._obs(), {a: {} for a in self.agents}
+
+    def step(self, actions):
+        assert set(actions) == set(self.possible_agents) and all(isinstance(v, int) for v in actions.values())
+        self.t += 1
+        self.x = self.x + np.array([[actions[a] + 1.0] for a in self.possible_agents])
+        if self.terminate_at is not None and self.t >= self.terminate_at:
+            self.agents = []
+            return {}, {}, {a: True for a in self.possible_agents}, {a: False for a in self.possible_agents}, {}
+        trunc = self.t >= self.max_cycles
+        rew = {a: -float(i + 1) * self.t for i, a in enumerate(self.possible_agents)}  # differs per agent: the adapter takes agent 0's
+        return (self._obs(), rew, {a: False for a in self.possible_agents}, {a: trunc for a in self.possible_agents},
+                {a: {"t": self.t} for a in self.possible_agents})
+
+    def close(self):
+        pass
+
+
+class FakeSMAC:
+    """smaclite env surface: list-of-arrays observations, team reward, get_state / get_avail_actions / obs_size / state_size /
+    n_agents on the unwrapped env, a tuple action space, info["battle_won"] at the end of a battle."""
+
+    def __init__(self, map_name, seed=0, win_at=None, **_):
+        self.map_name, self.n_agents, self.obs_size, self.state_size = map_name, 3, 30, 48
+        self.action_space = tuple(_Discrete(9) for _ in range(self.n_agents))
+        self.win_at, self.t, self.seed = win_at, 0, seed
+        self.unwrapped = self
+
+    def _obs(self):
+        return [np.full(self.obs_size, self.t + 0.1 * i, np.float32) for i in range(self.n_agents)]
+
+    def reset(self, seed=None, options=None):
+        self.t = 0
+        return self._obs(), {}
+
+    def step(self, actions):
+        assert len(actions) == self.n_agents and all(isinstance(a, int) for a in actions)
+        legal = self.get_avail_actions()
+        assert all(legal[i][a] for i, a in enumerate(actions)), "illegal action reached the env"
+        self.t += 1
+        won = self.win_at is not None and self.t >= self.win_at
+        return self._obs(), float(sum(actions)), won, False, {"battle_won": bool(won)}  # smaclite reports it on every step
+
+    def get_state(self):
+        return np.full(self.state_size, float(self.t), np.float32)
+
+    def get_avail_actions(self):
+        av = np.ones((self.n_agents, 9), np.int64)
+        av[:, 1 + self.t % 8] = 0  # one action is illegal, which one moves with time; action 0 always legal
+        return av.tolist()
+
+    def close(self):
+        pass
+
+
+class FakeTimeLimit:
+    """gymnasium.wrappers.TimeLimit: truncated = True once max_episode_steps steps were taken."""
+
+    def __init__(self, env, max_episode_steps):
+        self.env, self.max_episode_steps, self.n = env, int(max_episode_steps), 0
+        self.unwrapped, self.action_space = env.unwrapped, env.action_space
+
+    def reset(self, seed=None, options=None):
+        self.n = 0
+        return self.env.reset(seed=seed, options=options)
+
+    def step(self, actions):
+        obs, r, term, trunc, info = self.env.step(actions)
+        self.n += 1
+        return obs, r, term, trunc or self.n >= self.max_episode_steps, info
+
+    def close(self):
+        self.env.close()
+
+
+def install(monkeypatch):
+    """Put the fake packages into sys.modules for the duration of a test."""
+    pz, mpe, spread = types.ModuleType("pettingzoo"), types.ModuleType("pettingzoo.mpe"), types.ModuleType("pettingzoo.mpe.simple_spread_v3")
+    pz.__path__, mpe.__path__ = [], []
+    spread.parallel_env = FakeParallelEnv
+    gym, wrappers, smac = types.ModuleType("gymnasium"), types.ModuleType("gymnasium.wrappers"), types.ModuleType("smaclite")
+    gym.__path__ = []
+
+    def make(env_id, seed=0, **kw):
+        assert env_id.startswith("smaclite/") and env_id.endswith("-v0"), env_id
+        return FakeSMAC(env_id[len("smaclite/"):-3], seed=seed, **kw)
+    gym.make, wrappers.TimeLimit, gym.wrappers = make, FakeTimeLimit, wrappers
+    for name, mod in (("pettingzoo", pz), ("pettingzoo.mpe", mpe), ("pettingzoo.mpe.simple_spread_v3", spread),
+                      ("gymnasium", gym), ("gymnasium.wrappers", wrappers), ("smaclite", smac)):
+        monkeypatch.setitem(sys.modules, name, mod)

@@ -104,10 +104,22 @@ def test_bench_two_rank_launch_on_one_gpu():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["value"] > 0 and abs(out["value"] - 2 * 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    # strong scaling is the default (north_star: num_envs shards across the GPUs): the 96 envs are GLOBAL, 48 per rank
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["config"]["global_envs"] == 96 and out["config"]["envs_per_gpu"] == 48
+    assert out["value"] > 0 and abs(out["value"] - 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert out["roofline"]["frac"] > 0
+    # extra legs at N > 1: the two all-reduce messages timed alone and a short weak-scaling run (96 envs on EVERY rank)
+    assert len(out["allreduce_us"]) == 2 and all(v > 0 for v in out["allreduce_us"].values())
+    wk = out["weak_scaling"]
+    assert wk["global_envs"] == 192 and abs(wk["value"] - 192 * 3 * 128 / (wk["ms_per_step"] * 1e-3)) < 1e-6 * wk["value"]
+    cmd[cmd.index("--envs") + 1:cmd.index("--envs") + 2] = ["96", "--scaling", "weak", "--no-extras"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["config"]["global_envs"] == 192 and "strong_scaling" not in out
+    assert abs(out["value"] - 2 * 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 
 def _coma_worker(rank, world, port, gold, out):
@@ -221,7 +233,7 @@ def test_bench_contract_single_gpu():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
-    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "strong"
     assert "4096 envs x 8 agents x 128 steps" in out["config"]["workload"] and "model" not in out["config"]
     assert abs(out["value"] - 4096 * 8 * 128 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     rf = out["roofline"]
@@ -231,3 +243,11 @@ def test_bench_contract_single_gpu():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "envs" in cb["sample"]
     assert out["value"] > 50 * cb["value"]  # north-star: >= 50x the reference-structured CPU path
+    # every BASELINE config is in the driver-run line, and the per-GPU shares of the sharded ones
+    assert set(out["other_workloads"]) == {"cfg2", "cfg4", "cfg5"}
+    assert all(v["ms_per_step"] > 0 and 0 < v["roofline_frac"] < 1 for v in out["other_workloads"].values())
+    assert set(out["strong_scaling_shares"]) == {"cfg3", "cfg4"}
+    sh = out["strong_scaling_shares"]["cfg3"]["shares"]["1/8 (512 envs)"]
+    assert 1.0 < sh["speedup_bound"] < 8.5
+    pr = out["phase_roofline"]
+    assert set(pr) == {"rollout", "value_pass_scan", "critic_fwd_bwd", "whole_step"} and all(0 < v["frac"] < 1 for v in pr.values())

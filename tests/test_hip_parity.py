@@ -765,25 +765,6 @@ def test_policy_act_greedy_is_the_argmax_of_the_masked_logits():
         assert _err(logp.cpu().numpy(), lp_all.gather(-1, a[:, None])[:, 0].numpy()) <= TOL
 
 
-def test_optin_wave_private_actor_kernel_matches_the_default(tmp_path):
-    """CM_ACTOR_KERNEL=wave16 (csrc/cm_mlp_actor16.hip, opt-in, slower than the default: profiles/r01_l_wave16_actor.txt) must produce the
-    default kernel's gradient + statistics row on identical inputs (ragged episodes, masked actions, 16 actions, partial tiles).  The choice
-    is read once per process, hence the two subprocesses."""
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = os.path.join(root, "tools", "probes", "actor16_check.py")
-    env = dict(os.environ, A16_SMALL="1")
-    env.pop("CM_ACTOR_KERNEL", None)
-    ref, out = str(tmp_path / "ref.pt"), str(tmp_path / "w16.pt")
-    subprocess.run([sys.executable, script, ref], check=True, env=env, capture_output=True, timeout=600)
-    r = subprocess.run([sys.executable, script, out, ref], check=True, env=dict(env, CM_ACTOR_KERNEL="wave16"), capture_output=True, text=True, timeout=600)
-    errs = [float(m) for m in re.findall(r"max rel err vs \S+ ([0-9.eE+-]+)", r.stdout)]
-    assert len(errs) == 4, r.stdout + r.stderr
-    assert max(errs) < 1e-5, r.stdout  # fp32 re-association only
-
-
 @pytest.mark.parametrize("kind", ["Adam", "AdamW", "SGD", "RMSprop"])
 def test_optimiser_step_matches_torch_at_size_boundaries(kind):
     """cm_grad_norm_clip_adam against torch.optim + clip_grad_norm_ (cleanmarl/mappo_multienvs.py:584-594) on sizes around the switch

@@ -128,53 +128,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.cm_mlp_param_count(56, 64, 1, 5) == 56 * 64 + 64 + 64 * 64 + 64 + 5 * 64 + 5
 
 
-def test_lbf_adapter_semantics_with_stub_gymnasium(monkeypatch):
-    """cleanmarl_amd/env/lbf_wrapper.py against a stand-in gymnasium/lbforaging (neither is installed here): team reward
-    aggregation, state = concatenated observations, id one-hots, availability padding to the widest action space, and the
-    forced truncation at the step limit (contract of cleanmarl/env/lbf.py:24-75)."""
-    import sys
-    import types
-
-    class Disc:
-        def __init__(self, n): self.n = n
-        def sample(self): return 0
-
-    class Box:
-        def __init__(self, d): self.shape = (d,)
-
-    class Core:
-        n_agents, _max_episode_steps = 3, 4
-        def __init__(self):
-            self.action_space = [Disc(6), Disc(4), Disc(6)]
-            self.observation_space = [Box(5), Box(5), Box(5)]
-            self.unwrapped, self.t = self, 0
-        def reset(self, seed=None):
-            self.t = 0
-            return [np.full(5, i, float) for i in range(3)], {}
-        def step(self, actions):
-            self.t += 1
-            return [np.full(5, 10 * self.t + i, float) for i in range(3)], [1.0, 2.0, 3.0], self.t >= 4, False, {"t": self.t}
-        def close(self): pass
-
-    gym = types.ModuleType("gymnasium")
-    gym.make = lambda name, max_episode_steps=None, **k: Core()
-    spaces = types.ModuleType("gymnasium.spaces")
-    spaces.flatdim = lambda sp: sp.n if hasattr(sp, "n") else int(np.prod(sp.shape))
-    wrappers = types.ModuleType("gymnasium.wrappers")
-    wrappers.TimeLimit = lambda env, max_episode_steps=None: env
-    for name, mod in (("gymnasium", gym), ("gymnasium.spaces", spaces), ("gymnasium.wrappers", wrappers),
-                      ("lbforaging", types.ModuleType("lbforaging"))):
-        monkeypatch.setitem(sys.modules, name, mod)
-    from cleanmarl_amd.env.vector import environment
-    env = environment("lbf", "Foraging-8x8-3p-2f-v3", "mpe", True, kwargs=dict(time_limit=4))
-    assert (env.n_agents, env.get_obs_size(), env.get_state_size(), env.get_action_size()) == (3, 8, 15, 6)
-    obs, _ = env.reset()
-    assert obs.shape == (3, 8) and (obs[:, 5:] == np.eye(3)).all() and (env.get_state() == np.repeat([0.0, 1.0, 2.0], 5)).all()
-    av = env.get_avail_actions()
-    assert av.tolist() == [[1] * 6, [1, 1, 1, 1, 0, 0], [1] * 6]
-    for t in range(1, 5):
-        obs, r, done, trunc, info = env.step([0, 1, 2])
-        assert float(r) == 6.0 and done == (t == 4) and trunc == (t == 4)
-    mean_env = environment("lbf", "x", "mpe", False, kwargs=dict(time_limit=4, reward_aggr="mean"))
-    mean_env.reset()
-    assert float(mean_env.step([0, 0, 0])[1]) == 2.0 and mean_env.get_obs_size() == 5
+def test_rank_shards_of_host_vector_envs_are_distinct_and_tile_the_global_batch():
+    """with the batch env-sharded over ranks, rank r's vector env must own the GLOBAL env indices
+    [env_offset, env_offset + E_local) -- not 0..E_local-1 again -- for both the pipe and the shared-memory flavour."""
+    from cleanmarl_amd.env.shm_vector import ShmVectorEnv
+    from cleanmarl_amd.env.vector import PipeVectorEnv
+    A, T = 2, 4
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=5,
+               synthetic=dict(agents=A, steps=T))
+    full = PipeVectorEnv(4, fac)
+    want = np.stack([c["obs"] for c in full.reset_all()])
+    full.close()
+    assert not np.allclose(want[:2], want[2:])  # index-keyed envs: different indices give different episodes
+    for off in (0, 2):
+        p = PipeVectorEnv(2, fac, index_offset=off)
+        got = np.stack([c["obs"] for c in p.reset_all()])
+        p.close()
+        assert np.allclose(got, want[off:off + 2])
+        s = ShmVectorEnv(2, fac, n_workers=2, index_offset=off)
+        s._all("reset")
+        got = s.arr["obs"].copy()
+        s.close()
+        assert np.allclose(got, want[off:off + 2])
