@@ -85,7 +85,7 @@ class Workload:
         L.update(b)
         if evts is not None:
             e[3].record()
-            evts.append(e)
+            evts.append(e + [getattr(L, "critic_span", None)])
 
     def barrier(self):
         if self.world > 1:
@@ -117,17 +117,23 @@ class Workload:
             tt = torch.tensor([dt], dtype=torch.float64, device=L.device)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=self.pg)
             dt = float(tt.item())
-        phases = [0.0, 0.0, 0.0]
+        # update = the longer of the two halves: actor epochs on the launch stream (e2 -> e3), critic epochs on their own stream
+        # (e2 -> end of the last critic step; they overlap the NEXT step's rollout, learner.PPOLearner.update)
+        phases = [0.0, 0.0, 0.0, 0.0]
         for e in evts:
             for i in range(3):
                 phases[i] += e[i].elapsed_time(e[i + 1])
+            if e[4] is not None:
+                phases[3] += e[2].elapsed_time(e[4][1])
         phases = [p / max(1, len(evts)) for p in phases]
+        phases[2], actor_half = max(phases[2], phases[3]), phases[2]
         act_ms = [s.elapsed_time(e) for (k, s, e) in L.events if k == "actor"]
         cri_ms = [s.elapsed_time(e) for (k, s, e) in L.events if k == "critic"]
         L.events = None
         mean = lambda v: sum(v) / max(1, len(v))
         return dict(dt=dt, steps=steps, ms_per_step=1e3 * dt / steps, phase_ms=dict(rollout=phases[0], value_pass_scan=phases[1],
-                    update=phases[2]), actor_ms=mean(act_ms), critic_ms=mean(cri_ms))
+                    update=phases[2], update_actor_stream=actor_half, update_critic_stream=phases[3]),
+                    actor_ms=mean(act_ms), critic_ms=mean(cri_ms))
 
     # ---- algorithmic work per launch (weights, MFMA-tile padding and recomputation are NOT counted)
     def work(self):

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcleanmarl_hip.so")
+LIB_PATH = os.environ.get("CM_LIB_PATH") or os.path.join(HERE, "libcleanmarl_hip.so")  # CM_LIB_PATH: probe builds (tools/probes)
 
 NUM_STATS = 8
 STAT_PG, STAT_ENT, STAT_KL, STAT_CLIP, STAT_VLOSS, STAT_COUNT = range(6)
@@ -27,6 +27,8 @@ SIGNATURES = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (_i, []),
     "cm_mfma_mode": (_i, []),
+    "cm_stream_create_low_priority": (_p, []),
+    "cm_stream_destroy": (_i, [_p]),
     "cm_mlp_param_count": (_l, [_i, _i, _i, _i]),
     "cm_gru_param_count": (_l, [_i, _i, _i]),
     "cm_mlp_forward": (_i, [_p, _l, _i, _i, _i, _i, _p, _p, _p, _p]),
@@ -121,3 +123,12 @@ def stream_ptr(stream=None):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return C.c_void_p(s.cuda_stream)
+
+
+def low_priority_stream(device):
+    """torch view (ExternalStream) of a lowest-priority HIP stream created by the library; lives for the process."""
+    import torch
+    h = load().cm_stream_create_low_priority()
+    if not h:
+        raise NativeError("cm_stream_create_low_priority failed: " + (load().cm_last_error() or b"?").decode())
+    return torch.cuda.ExternalStream(h, device=device)

@@ -27,3 +27,18 @@ extern "C" int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, 
 extern "C" int64_t cm_gru_param_count(int din, int hidden, int dout) {
     return (int64_t)din * hidden + hidden + 6LL * hidden * hidden + 6LL * hidden + (int64_t)hidden * dout + dout;
 }
+
+// lowest-priority stream for slack work (see include/cleanmarl_hip.h)
+extern "C" cm_stream_t cm_stream_create_low_priority(void) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; }
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+    if (e != hipSuccess) { cm_set_error("cm_stream_create_low_priority: %s", hipGetErrorString(e)); return nullptr; }
+    return (cm_stream_t)s;
+}
+extern "C" int cm_stream_destroy(cm_stream_t stream) {
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) CM_FAIL(-2, "cm_stream_destroy: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     long* obase = reinterpret_cast<long*>(elm + TM * 2 + TM);  // [TM] obs row base (elements), -1 = dead row (8-byte aligned: +TM pad)
     long* sbase = obase + TM;                          // [TM] state row base
     float* rscr = reinterpret_cast<float*>(sbase + TM);  // [2][TM] reward partials
+    float* ubuf = rscr + 2 * TM;                         // [4][TM] uniforms of four steps
 
     for (int i = tid; i < 16 * HP; i += NTHREADS) {
         const int k = i / HP, c = i % HP;
@@ -195,15 +196,17 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 a.reward[(long)(e0 + tid) * T + (t - 1)] = r;
             }
             PH(2);
-            // the step's uniform does not depend on the logits: issue the Philox rounds here so they interleave with
-            // the MFMA chain below instead of extending the serial sampling phase
-            float u_row = 0.0f;
-            if (tid < RT) {
-                const int el = tid / A, i = tid - el * A;
-                const unsigned long long gr = (unsigned long long)((a.env_offset + e0 + el) * A + i);
-                const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
-                                                (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
-                u_row = cm_u01(rnd.x);
+            // the uniforms do not depend on the logits: every 4th step the four waves draw the uniforms of the next four steps (wave w:
+            // step t + w, thread = row) -- ten Philox rounds of quarter-rate integer multiplies on ONE wave per step were ~15 % of it
+            if ((t & 3) == 0) {
+                const int r = tid & 63, tq = tid >> 6;
+                if (r < RT) {
+                    const int el = r / A, i = r - el * A;
+                    const unsigned long long gr = (unsigned long long)((a.env_offset + e0 + el) * A + i);
+                    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)(t + tq), CM_STREAM_ACT,
+                                                    (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                    ubuf[tq * TM + r] = cm_u01(rnd.x);
+                }
             }
             // ---------------- actor forward, layer 0
             f32x16 acc;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                 const long e = e0 + el;
                 if (e < a.E) {
                     int chosen; float lpv;
+                    const float u_row = ubuf[(t & 3) * TM + tid];
                     if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + tid * 8, K, u_row, a.act_eps, &chosen, &lpv);
                     else cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
                     const long o = (e * A + i) * (long)T + t;
@@ -294,6 +298,316 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     PH_FLUSH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-tile form of the same rollout for SMALL env counts (one GPU's share of a sharded batch, config 2): the 64-row kernel
+// above puts floor(64/A) envs on a workgroup, so 512 envs x 8 agents occupy 64 of the 256 CUs and every step is a serial
+// chain over 64 rows (6 barriers, a 32x32 MFMA tile per wave and layer, a thread-per-row softmax).  Here a workgroup owns
+// 16 (env, agent) rows -- 4x the workgroups -- and each step is cut to the work of 16 rows:
+//   * obs / reward partials: 16 lanes per row (lane j = entity j), min / count over the lanes with DPP row rotations;
+//   * layers on v_mfma_f32_16x16x4_f32, wave w = hidden columns 16w..16w+15 of all 16 rows (16 MFMAs x 32 cycles per layer
+//     instead of 32 x 64).  k is fed in the order the 32x32x2 form consumes it ({8j+i, 8j+4+i}, i = 0..3), so that -- the
+//     MFMA being an fmaf chain over k -- the logits come out bit-identical to the 64-row kernel and the per-step kernels;
+//   * head: every wave computes the 16x16 logit tile (same routine as k_mlp<M_ACT>) and keeps row 4g+w of lane group g:
+//     the K logits of a row sit in the 16 lanes of a DPP row, softmax / inverse-CDF sample run there (max, exp, serial-order
+//     prefix sums by row shifts: same summation order as cm_categorical_sample), no LDS round trip and no barrier;
+//   * 4 barriers per step, ~49 KB of LDS: three workgroups per CU.
+constexpr int TS = 16;  // rows per small tile
+
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {  // lanes shifted in from outside the 16-lane row read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// all-reduce over the 16 lanes of a DPP row (row_ror:8,4,2,1 = 0x128, 0x124, 0x122, 0x121)
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, dpp_f<0x128>(v)); v = fminf(v, dpp_f<0x124>(v)); v = fminf(v, dpp_f<0x122>(v)); return fminf(v, dpp_f<0x121>(v));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); return fmaxf(v, dpp_f<0x121>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // exact for the small integer counts it is used on
+    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); return v + dpp_f<0x121>(v);
+}
+__device__ __forceinline__ int row16_imin(int v) {
+    v = min(v, dpp_i<0x128>(v)); v = min(v, dpp_i<0x124>(v)); v = min(v, dpp_i<0x122>(v)); return min(v, dpp_i<0x121>(v));
+}
+__device__ __forceinline__ int row16_imax(int v) {
+    v = max(v, dpp_i<0x128>(v)); v = max(v, dpp_i<0x124>(v)); v = max(v, dpp_i<0x122>(v)); return max(v, dpp_i<0x121>(v));
+}
+// lane n of a row <- x_0 + x_1 + ... + x_n summed LEFT TO RIGHT (the order of the serial sampler), for n < K; row_shr:1 = 0x111
+__device__ __forceinline__ float row16_serial_prefix(float x, int n, int K) {
+    float cum = x;
+    for (int i = 1; i < K; ++i) {
+        const float t = dpp_f<0x111>(cum);
+        if (n == i) cum = t + x;
+    }
+    return cum;
+}
+// value of lane K-1 handed down to lanes 0..K-2 of the row (row_shl:1 = 0x101)
+__device__ __forceinline__ float row16_from_lane(float v, int n, int K) {
+    for (int i = K - 2; i >= 0; --i) {
+        const float t = dpp_f<0x101>(v);
+        if (n == i) v = t;
+    }
+    return v;
+}
+
+// acc[16 rows x 16 cols] += A[16 rows][8*kb] * B[16 rows(n)][8*kb]^T on the 16x16x4 MFMA, k in the order of rowpar_nt:
+// lane group g supplies k = 8j + {0,4,1,5}[g] to the first MFMA of a block and + 2 to the second.
+__device__ __forceinline__ void tile16_nt(f32x4& acc, const float* As, const float* Bs, int kb) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float4* ap = reinterpret_cast<const float4*>(As + n * LDT + 4 * (g & 1));
+    const float4* bp = reinterpret_cast<const float4*>(Bs + n * LDT + 4 * (g & 1));
+    const bool lo = g < 2;
+    float4 a = ap[0], b = bp[0];
+    for (int j = 0; j < kb; ++j) {
+        float4 an = a, bn = b;
+        if (j + 1 < kb) { an = ap[2 * (j + 1)]; bn = bp[2 * (j + 1)]; }
+        acc = mfma16(lo ? a.x : a.y, lo ? b.x : b.y, acc);
+        acc = mfma16(lo ? a.z : a.w, lo ? b.z : b.w, acc);
+        a = an; b = bn;
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, g16 = lane >> 4;
+    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    const int EPT = TS / A, RT = EPT * A;  // envs / valid rows per tile
+    const int Ds = 6 * A * A;
+    float* W0s = smem;                    // [HP][LDT]
+    float* Ws = W0s + HP * LDT;           // [HP][LDT]
+    float* wouts = Ws + HP * LDT;         // [16][WLD], rows >= K zero
+    float* b0s = wouts + 16 * WLD;
+    float* b1s = b0s + HP;
+    float* bos = b1s + HP;                // [16]
+    float* Xs = bos + 16;                 // [TS][LDT] obs tile; aliased by H1 once layer 0 has consumed it
+    float* H0 = Xs + TS * LDT;            // [TS][LDT]
+    float* epos = H0 + TS * LDT;          // [TS][2]
+    float* evel = epos + TS * 2;
+    float* elm = evel + TS * 2;
+    long* obase = reinterpret_cast<long*>(elm + TS * 2);  // [TS] obs row base (elements), -1 = dead row
+    long* sbase = obase + TS;
+    float* rscr = reinterpret_cast<float*>(sbase + TS);   // [2][TS] reward partials
+
+    for (int i = tid; i < 16 * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        wouts[k * WLD + c] = (c < H && k < K) ? a.params[off.Wout + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) {
+        b0s[i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
+        b1s[i] = (i < H && L > 0) ? a.params[off.bl(0) + i] : 0.0f;
+    }
+    if (tid < 16) bos[tid] = (tid < K) ? a.params[off.bout + tid] : 0.0f;
+    stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
+    if (L > 0) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const int orow = tid >> 4, oq = tid & 15;  // obs phase: 16 lanes per row
+    const int srow = 4 * g16 + wave;           // sampling phase: lane group g of wave w owns row 4g + w
+    const bool vecw = (din % 4 == 0) && ((6 * A) % 4 == 0);
+    PH_DECL
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();
+        if (tid < TS) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
+            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            if (live) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+        // geometry of this thread's obs-phase row and sampling-phase row
+        const int o_el = orow / A, o_i = orow - o_el * A;
+        const bool o_live = orow < RT && (e0 + o_el) < a.E;
+        const int s_el = srow / A, s_i = srow - s_el * A;
+        const bool s_live = srow < RT && (e0 + s_el) < a.E;
+        const unsigned long long s_gr = (unsigned long long)((a.env_offset + e0 + s_el) * A + s_i);
+        const long s_out = ((long)(e0 + s_el) * A + s_i) * (long)T;
+        // nearest-agent distance of landmark o_i and collisions of agent o_i from the CURRENT positions: lane j = agent j
+        auto reward_partials = [&]() {
+            const float* pos = epos + o_el * 2 * A;
+            float d = 3.0e38f, c = 0.0f;
+            if (o_live && oq < A) {
+                const float lx = elm[2 * orow], ly = elm[2 * orow + 1];
+                const float qx = pos[2 * o_i], qy = pos[2 * o_i + 1];
+                const float dx = pos[2 * oq] - lx, dy = pos[2 * oq + 1] - ly;
+                d = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+                if (oq > o_i) {
+                    const float cx = qx - pos[2 * oq], cy = qy - pos[2 * oq + 1];
+                    if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < COLLIDE) c = 1.0f;
+                }
+            }
+            d = row16_min(d); c = row16_sum(c);
+            if (oq == 0 && orow < RT) { rscr[orow] = d; rscr[TS + orow] = c; }
+        };
+        auto reward_write = [&](int t_prev) {
+            if (tid < EPT && e0 + tid < a.E) {
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) r -= rscr[tid * A + l];
+                for (int l = 0; l < A; ++l) r -= rscr[TS + tid * A + l];
+                a.reward[(long)(e0 + tid) * T + t_prev] = r;
+            }
+        };
+        float u16 = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            PH(0);
+            if (t > 0) reward_partials();  // reward of step t-1: positions after its physics update
+            // ---------------- observations of step t -> Xs: lane oq handles entity oq (landmark, other agent, id)
+            {
+                float* xr = Xs + orow * LDT;
+                if (o_live) {
+                    const float* pos = epos + o_el * 2 * A; const float* vel = evel + o_el * 2 * A; const float* lm = elm + o_el * 2 * A;
+                    const float px = pos[2 * o_i], py = pos[2 * o_i + 1];
+                    if (oq == 0) { xr[0] = vel[2 * o_i]; xr[1] = vel[2 * o_i + 1]; xr[2] = px; xr[3] = py; }
+                    const int j = oq;
+                    if (j < A) {
+                        xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                        if (j != o_i) {
+                            const int jj = j < o_i ? j : j - 1;
+                            xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
+                            xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                        }
+                        if (a.agent_ids) xr[6 * A + j] = (j == o_i) ? 1.0f : 0.0f;
+                    }
+                    for (int c = din + oq; c < KC; c += 16) xr[c] = 0.0f;  // MFMA padding (H1 recycles this buffer)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC / 16; ++j) xr[16 * j + oq] = 0.0f;
+                }
+            }
+            __syncthreads();
+            PH(1);
+            // ---------------- rollout-buffer writes (coalesced along the feature axis)
+            if (vecw) {  // <= 16 x 16 obs quads and <= 16 x 15 state quads: at most one of each per thread
+                const int nq = din >> 2, ns = (6 * A) >> 2;
+                {
+                    const int r = tid / nq, c4 = tid - r * nq;
+                    if (r < RT && obase[r] >= 0)
+                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * din + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                }
+                {
+                    const int r = tid / ns, c4 = tid - r * ns;
+                    if (r < RT && sbase[r] >= 0)
+                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * Ds + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                }
+            } else {
+                for (int idx = tid; idx < RT * din; idx += NTHREADS) {
+                    const int r = idx / din, c = idx - r * din;
+                    const long ob = obase[r];
+                    if (ob >= 0) a.obs[ob + (long)t * din + c] = Xs[r * LDT + c];
+                }
+                for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
+                    const int r = idx / (6 * A), c = idx - r * 6 * A;
+                    const long sb = sbase[r];
+                    if (sb >= 0) a.state[sb + (long)t * Ds + c] = Xs[r * LDT + c];
+                }
+            }
+            if (t > 0) reward_write(t - 1);
+            // The uniforms do not depend on the logits and ten Philox rounds are ~2000 cycles of quarter-rate integer multiplies: the 16
+            // lanes of a row's group draw the uniforms of 16 consecutive steps at once (lane n: step t + n) every 16th step, and each
+            // step fetches its own with one ds_bpermute issued here, far ahead of the sampler that reads it.
+            if ((t & 15) == 0) {
+                const cm_u4 rnd = cm_philox4x32((uint32_t)s_gr, (uint32_t)(s_gr >> 32), (uint32_t)(t + n16), CM_STREAM_ACT,
+                                                (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                u16 = cm_u01(rnd.x);
+            }
+            const float u_row = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * ((lane & 48) | (t & 15)), __builtin_bit_cast(int, u16)));
+            PH(2);
+            // ---------------- actor forward, layer 0: wave = hidden columns 16w..16w+15
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            tile16_nt(acc, Xs, W0s + 16 * wave * LDT, (din + 7) >> 3);
+            {
+                const float bias = b0s[16 * wave + n16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) H0[(4 * g16 + q) * LDT + 16 * wave + n16] = fmaxf(acc[q] + bias, 0.0f);
+            }
+            __syncthreads();
+            PH(3);
+            const float* HL = H0;
+            if (L > 0) {  // hidden layer; H1 aliases Xs (every wave is past its layer-0 reads and its buffer writes)
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                tile16_nt(acc, H0, Ws + 16 * wave * LDT, HP / 8);
+                const float bias = b1s[16 * wave + n16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Xs[(4 * g16 + q) * LDT + 16 * wave + n16] = fmaxf(acc[q] + bias, 0.0f);
+                HL = Xs;
+                __syncthreads();
+            }
+            PH(4);
+            // ---------------- head: the whole 16 x 16 logit tile per wave, row 4g + w kept by lane group g
+            const f32x4 lg = head_logits_mfma(HL, wouts);
+            const float zraw = wave == 0 ? lg[0] : (wave == 1 ? lg[1] : (wave == 2 ? lg[2] : lg[3]));
+            const bool kin = n16 < K;
+            const float z = kin ? zraw + bos[n16] : -INFINITY;
+            PH(5);
+            // ---------------- Categorical sample + log_prob in the 16 lanes of the row (arithmetic of cm_categorical_sample[_eps])
+            const float m = row16_max(z);
+            const float ex = kin ? expf(z - m) : 0.0f;
+            const bool av = kin && z > -5e8f;
+            const float ssum = row16_from_lane(row16_serial_prefix(ex, n16, K), n16, K);  // s on lanes 0..K-1
+            int chosen; float lpv;
+            if (a.act_eps > 0.0f) {
+                const float navail = row16_sum(av ? 1.0f : 0.0f);
+                const float ca = (1.0f - a.act_eps) / ssum, cb = a.act_eps / fmaxf(navail, 1.0f);
+                const float p = av ? ca * ex + cb : 0.0f;
+                const float cum = row16_serial_prefix(p, n16, K);
+                chosen = row16_imin((av && u_row < cum) ? n16 : 99);
+                const int last = row16_imax(av ? n16 : 0);
+                if (chosen == 99) chosen = last;
+                lpv = logf(row16_max(n16 == chosen ? p : -INFINITY));
+            } else {
+                const float cum = row16_serial_prefix(ex, n16, K);
+                chosen = row16_imin((av && u_row * ssum < cum) ? n16 : 99);
+                const int last = row16_imax(av ? n16 : 0);
+                if (chosen == 99) chosen = last;
+                const float zc = row16_max(n16 == chosen ? z : -INFINITY);
+                lpv = zc - (m + logf(ssum));
+            }
+            if (n16 == 0 && s_live) {
+                a.action[s_out + t] = chosen;
+                a.logp[s_out + t] = lpv;
+                // point-mass physics (cm_env.hip k_env_step)
+                const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
+                const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);
+                const float vx = evel[2 * srow] * (1.0f - DAMP) + ux * DT;
+                const float vy = evel[2 * srow + 1] * (1.0f - DAMP) + uy * DT;
+                evel[2 * srow] = vx; evel[2 * srow + 1] = vy;
+                epos[2 * srow] += vx * DT; epos[2 * srow + 1] += vy * DT;
+            }
+            PH(6);  // the barrier at the top of the next step orders the physics update before its readers
+        }
+        __syncthreads();
+        reward_partials();
+        __syncthreads();
+        reward_write(T - 1);
+        if (tid < RT) {  // final env state back to global (pos | vel | landmarks)
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            if (e < a.E) {
+                float* es = a.env_state + e * 6 * A;
+                es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+            }
+        }
+    }
+    PH_FLUSH;
+}
+
 }  // namespace
 
 extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int n_hidden_layers) {
@@ -317,7 +631,23 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
 #endif
     const int EPT = TM / A;
     const int ntiles = (E + EPT - 1) / EPT;
-    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM + 4 * TM + 2 * TM;
+    // Few 64-row tiles (a GPU's share of a sharded batch, config 2) leave most CUs idle and every step a 64-row serial chain: below
+    // 1.5 tiles per CU the 16-row form runs instead (same arithmetic; CM_ROLLOUT_TILE=16 / 64 forces one for A/B runs and tests)
+    const char* forced_s = getenv("CM_ROLLOUT_TILE");  // read per launch (tests flip it inside one process)
+    const int forced = forced_s ? atoi(forced_s) : 0;
+    const bool can16 = A <= TS;
+    const bool use16 = can16 && (forced == 16 || (forced != 64 && ntiles < 384));
+    if (use16) {
+        const int EPT16 = TS / A;
+        const int nt16 = (E + EPT16 - 1) / EPT16;
+        const size_t lds16 = ((size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 16 + (size_t)TS * LDT * 2 + TS * 2 * 3 + 4 * TS + 2 * TS) * sizeof(float);
+        const int grid16 = nt16 < 768 ? nt16 : 768;  // ~49 KB of LDS: three workgroups per CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(k_rollout_spread16, dim3(grid16), dim3(NTHREADS), lds16, (hipStream_t)stream, a);
+        CM_CHECK_LAUNCH("cm_rollout_spread");
+        return 0;
+    }
+    const size_t lds_floats = (size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + TM + 4 * TM + 2 * TM + 4 * TM;
     const size_t lds_bytes = lds_floats * sizeof(float);
     const int grid = ntiles < 512 ? ntiles : 512;  // <= 80 KB of LDS: two workgroups per CU overlap each other's latencies
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

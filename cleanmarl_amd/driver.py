@@ -259,6 +259,10 @@ def run(script, argv=None):
                             episode=roll.episode if roll is not None else 0), args.checkpoint)
     iteration = 0
     while step < args.total_timesteps:
+        if not device_env:
+            # host rollouts allocate a fresh batch per iteration: the previous one (still read by the critic epochs on their own
+            # stream, learner.update) must be finished with before its memory goes back to the allocator
+            learner.wait_critic()
         if device_env:
             b = roll.collect(learner.actor, actor_spec)
             rew = b.reward.sum(1).cpu().tolist()

@@ -11,6 +11,7 @@ import ctypes as C
 import torch
 
 from . import _native as N
+from . import dist
 from .learner import LazyRecords, _to_host_async, DeviceBatch, PPOLearner
 
 _GOLD = 0x9E3779B97F4A7C15
@@ -55,12 +56,13 @@ class GRUPPOLearner(PPOLearner):
         if self._critic_stream is None:
             self._critic_stream = torch.cuda.Stream(device=self.device)
         side = self._critic_stream
+        self.wait_critic()
         side.wait_stream(main)
         for ep in range(nE):
             with torch.cuda.stream(side):
                 sc = N.stream_ptr()
                 self._timed("critic", self.critic_pass, b, sc)
-                self._allreduce(self.g_critic)
+                dist.allreduce_sum_(self.g_critic, self.pg_c, self.world)  # own communicator: never queues ahead of a chunk's message
                 self._adam(self.critic, self.g_critic, self.opt_c, 1, sc)
                 rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
                 rec_c[ep, N.NUM_STATS] = self.norms[1]
@@ -122,14 +124,19 @@ class GRUSyntheticRollout:
         self.agent_ids = bool(agent_ids)
         self.Do, self.Ds = 6 * A + (A if agent_ids else 0), 6 * A * A
         self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
-        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
-        self.batch.avail.fill_(1)
-        self.batch.ep_len.fill_(T)
+        # two buffers used alternately: the learner's critic epochs (own stream, learner.py) may still read episode i's states and
+        # returns while episode i + 1 is being written
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+        for bb in self.batches:
+            bb.avail.fill_(1)
+            bb.ep_len.fill_(T)
+        self.batch = self.batches[0]  # the most recently collected one
         self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
         self.h = None
         self.episode = 0
 
     def collect(self, actor_flat, actor_spec, fused=None):
+        self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         can_fuse = bool(lib.cm_gru_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden))

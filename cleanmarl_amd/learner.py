@@ -234,7 +234,18 @@ class PPOLearner:
         self.g_actor = self.gbuf[:Pa + N.NUM_STATS]
         self.g_critic = self.gbuf[Pa + N.NUM_STATS:]
         self.norms = torch.zeros(2, dtype=torch.float32, device=device)
-        self.ws = None  # sized on first use (the critic workspace depends on the batch shape)
+        self.ws = None    # actor pass workspace, sized on first use
+        self.ws_c = None  # critic pass / value pass workspace (its own buffer: the critic epochs run on their own stream)
+        # The critic's epochs only need the returns of THIS batch; the next rollout only needs the updated actor.  update() therefore
+        # enqueues the critic epochs on a second stream and does not join it: the join is the first reader of the critic, i.e. the value
+        # pass of the next iteration (wait_critic()).  With the rollouts double-buffered (rollout.py) the rollout of iteration i + 1
+        # runs under the critic epochs of iteration i -- it is a latency chain that leaves most of the chip idle.
+        self._critic_stream = None
+        self._critic_done = None
+        self.critic_span = None  # bench.py: (start, end) timing events of the last update's critic epochs (set when self.events is a list)
+        # the critic's all-reduces get their own communicator: collectives issued from two streams on ONE communicator are ordered
+        # by the library's internal stream, which would put the critic's message in front of the actor's next one
+        self.pg_c = torch.distributed.new_group() if (world_size > 1 and process_group is not None) else process_group
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
@@ -269,8 +280,9 @@ class PPOLearner:
         x = b.state if self.algo == "mappo" else b.obs
         rows = E * T * Av
         self._ensure_ws(b)
+        self.wait_critic()  # the critic epochs of the previous update ran on their own stream (under this batch's rollout)
         N.check(lib.cm_mlp_forward_ws(N.ptr(x), rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
-                                      N.ptr(self.values), N.ptr(self.ws), self.ws.numel(), s), "cm_mlp_forward_ws")
+                                      N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_ws")
         N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
                                       hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
         if hp.normalize_advantage:
@@ -304,10 +316,19 @@ class PPOLearner:
         need = self.lib.cm_critic_workspace_bytes(b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, c.din, c.hidden, c.n_layers)
         need = max(need, self.lib.cm_mlp_forward_workspace_bytes(b.E * b.T * (1 if self.algo == "mappo" else b.A), c.din, c.hidden,
                                                                  c.n_layers, 1))
+        if self.ws_c is None or self.ws_c.numel() < need:
+            self.wait_critic()  # the old buffer may still be in use on the critic stream
+            self.ws_c = torch.empty(need, dtype=torch.uint8, device=self.device)
         if a.kind == "mlp":
-            need = max(need, self.lib.cm_ppo_actor_workspace_bytes(b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout))
-        if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            need = self.lib.cm_ppo_actor_workspace_bytes(b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout)
+            if self.ws is None or self.ws.numel() < need:
+                self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+
+    def wait_critic(self):
+        """Make the current stream wait for the critic epochs of the last update() (they run on their own stream and are not joined
+        there).  Called by every reader of the critic parameters / optimiser state: the value pass, state_dict(), single passes."""
+        if self._critic_done is not None:
+            torch.cuda.current_stream().wait_event(self._critic_done)
 
     def critic_pass(self, b, s, g=None):
         """g: [Pc + 8] gradient + statistics buffer to fill (default self.g_critic)."""
@@ -316,7 +337,7 @@ class PPOLearner:
         x = b.state if self.algo == "mappo" else b.obs
         N.check(self.lib.cm_critic_fwd_bwd(N.ptr(x), N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
                                            0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
-                                           N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws), self.ws.numel(), s),
+                                           N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), s),
                 "cm_critic_fwd_bwd")
 
     def actor_pass(self, b, s, g=None):
@@ -329,62 +350,126 @@ class PPOLearner:
                                               N.ptr(self.g_actor if g is None else g), N.ptr(self.ws), self.ws.numel(), s),
                 "cm_ppo_actor_fwd_bwd")
 
+    def overlap_critic(self, b):
+        """Schedule of update(): 0 = both networks interleaved on the current stream; 2 = the critic's epochs on a second,
+        LOWEST-priority stream released at the start of the update and not joined there -- its kernels take the compute units
+        the actor's kernels and, above all, the NEXT rollout leave idle (the rollout is a latency chain on a fraction of the chip);
+        1 = the same stream released only when the actor's epochs are done (kept for A/B runs: it loses to 2 everywhere).
+        Measured (profiles/r02_critic_overlap_schedules.txt, ms per iteration, schedule 0 / 1 / 2): config 3 at 512 envs (one GPU's
+        share of 8) 1.81 / 1.60 / 1.56, 1024 envs 2.92 / 2.98 / 2.77, 4096 envs 9.51 / 9.53 / 9.31; config 4 at 256 envs 4.10 / 4.19 /
+        3.91; config 2 1.44 / 1.30 / 1.32.  Default: 2 up to 2^21 rows, 0 above -- at full size the gain is 2 % and the actor kernel,
+        the one the roofline is quoted on, would be timed with a second kernel beside it (1.87 -> 2.2 ms per launch).
+        CM_CRITIC_OVERLAP=0 / 1 / 2 forces a schedule."""
+        import os
+        v = os.environ.get("CM_CRITIC_OVERLAP")
+        if v in ("0", "1", "2"):
+            return int(v)
+        return 2 if b.E * b.A * b.T <= (1 << 21) else 0
+
     def update(self, b, keep_grads=False):
-        """`epochs` full-batch PPO steps (cleanmarl/mappo_multienvs.py:521-594).
-        Returns a list of per-epoch dicts (one host sync at the end)."""
+        """`epochs` full-batch PPO steps (cleanmarl/mappo_multienvs.py:521-594).  The two networks are independent (separate losses,
+        separate optimisers, :341-343): per network the sums and the order of its optimiser steps are those of the reference's
+        interleaved loop, whichever schedule runs:
+          * large batch: actor pass, critic pass, Adam, Adam per epoch on the current stream; N > 1: each network's all-reduce is
+            issued right after its pass and waited for only where that network's optimiser step is due (the actor's message travels
+            under the critic pass, the critic's under the next epoch's actor pass);
+          * small batch (overlap_critic): the actor's epochs on the current stream, then the critic's epochs on a second stream that
+            is NOT joined here -- the caller's next rollout overlaps them, the next value pass waits for them (wait_critic()).
+        Returns per-epoch records (LazyRecords: no host wait)."""
         hp, s = self.hp, N.stream_ptr()
         Pa, Pc = self.actor.numel(), self.critic.numel()
         nE0 = int(hp.epochs)
-        rec = torch.zeros(nE0, 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
-        # one [actor grads | 8 | critic grads | 8] row per epoch: the statistics survive the next epoch without per-epoch copies,
-        # the norms are written by the Adam kernel straight into `rec`; row 0 is self.gbuf (what single passes and tests read)
         if self.gbuf_rows.shape[0] < nE0:
             raise N.NativeError(f"epochs={nE0} exceeds the {self.gbuf_rows.shape[0]} gradient rows allocated at construction")
-        kept = []
-        if self.world > 1:
-            # N > 1: the two networks are independent, so each one's all-reduce is issued right after its pass and waited for only where
-            # its optimiser step is due -- the actor's message travels under the critic pass, the critic's under the NEXT epoch's actor
-            # pass (its Adam step is deferred to just before the next critic pass).  Same sums, same order of updates per network; only
-            # the last critic message of an update is exposed.  Issue order is identical on every rank.
-            kept_a, kept_c = [], []
-            pending = None
+        self._ensure_ws(b)
+        self.wait_critic()
+        main = torch.cuda.current_stream()
+        overlap = 0 if keep_grads else self.overlap_critic(b)
+        # one [actor grads | 8 | critic grads | 8] row per epoch: the statistics survive the next epoch without per-epoch copies,
+        # the norms are written by the Adam kernel straight into `rec`; row 0 is self.gbuf (what single passes and tests read)
+        rec = torch.zeros(nE0, 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
+        kept_a, kept_c = [], []
+        timed = self.events is not None
+        self.critic_span = None
 
-            def finish_critic(p):
-                work, epi, gc = p
-                work.wait()
-                self._adam(self.critic, gc, self.opt_c, 1, s, out_norm=rec[epi, 2 * N.NUM_STATS + 1:])
-                if keep_grads:
-                    kept_c.append((gc[:Pc].clone(), self.critic.clone()))
+        def actor_step(ep, wa):
+            g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
+            if wa is not None:
+                wa.wait()
+            self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
+            if keep_grads:
+                kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
 
+        def critic_step(ep, wc, sc):
+            g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
+            if wc is not None:
+                wc.wait()
+            self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
+            if keep_grads:
+                kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
+
+        if not overlap:
+            pending = None  # the critic's optimiser step of the previous epoch, due before the next critic pass
             for ep in range(nE0):
                 g = self.gbuf_rows[ep]
-                g_actor, g_critic = g[:Pa + N.NUM_STATS], g[Pa + N.NUM_STATS:]
-                self._timed("actor", self.actor_pass, b, s, g_actor)
-                wa = dist.allreduce_sum_async(g_actor, self.pg)
+                self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS])
+                wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if self.world > 1 else None
                 if pending is not None:
-                    finish_critic(pending)
-                self._timed("critic", self.critic_pass, b, s, g_critic)
-                pending = (dist.allreduce_sum_async(g_critic, self.pg), ep, g_critic)
-                wa.wait()
-                self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
-                if keep_grads:
-                    kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
+                    critic_step(*pending, s)
+                self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:])
+                wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if self.world > 1 else None
+                actor_step(ep, wa)
+                if self.world > 1:
+                    pending = (ep, wc)
+                else:
+                    critic_step(ep, None, s)
             if pending is not None:
-                finish_critic(pending)
-            kept = [(ka[0], kc[0], ka[1], kc[1]) for ka, kc in zip(kept_a, kept_c)]
-        for ep in range(nE0 if self.world == 1 else 0):
-            g = self.gbuf_rows[ep]
-            g_actor, g_critic = g[:Pa + N.NUM_STATS], g[Pa + N.NUM_STATS:]
-            self._timed("actor", self.actor_pass, b, s, g_actor)
-            self._timed("critic", self.critic_pass, b, s, g_critic)
-            self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
-            self._adam(self.critic, g_critic, self.opt_c, 1, s, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
-            if keep_grads:
-                kept.append((g_actor[:Pa].clone(), g_critic[:Pc].clone(), self.actor.clone(), self.critic.clone()))
-        # two strided copies per update instead of three small ones per epoch
-        rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
-        rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+                critic_step(*pending, s)
+            rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
+            rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+            host, ev, attach = _to_host_async(self._ring, rec)  # no host wait here: see LazyRecords
+        else:
+            if self._critic_stream is None:
+                self._critic_stream = N.low_priority_stream(self.device)
+            side = self._critic_stream
+            rec.record_stream(side)
+
+            def actor_epochs():
+                for ep in range(nE0):
+                    g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
+                    self._timed("actor", self.actor_pass, b, s, g_actor)
+                    actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self.world > 1 else None)
+                rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
+
+            def critic_epochs():
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sc = N.stream_ptr()
+                    if timed:
+                        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        c0.record()
+                    for ep in range(nE0):
+                        g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
+                        self._timed("critic", self.critic_pass, b, sc, g_critic)
+                        critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self.world > 1 else None, sc)
+                    rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+                    if timed:
+                        c1.record()
+                        self.critic_span = (c0, c1)
+
+            if overlap == 2:  # released now, lowest priority: they take the compute units the actor's kernels and the next rollout leave idle
+                critic_epochs()
+                actor_epochs()
+            else:             # released when the actor's epochs are done: they run under the next rollout only
+                actor_epochs()
+                critic_epochs()
+            side.wait_stream(main)  # the statistics need both halves; they leave on the critic stream, `main` never waits for them
+            with torch.cuda.stream(side):
+                host, ev, attach = _to_host_async(self._ring, rec)
+                self._critic_done = torch.cuda.Event()
+                self._critic_done.record(side)
         nE, ent_coef = int(hp.epochs), hp.entropy_coef
+        kept = [(ka[0], kc[0], ka[1], kc[1]) for ka, kc in zip(kept_a, kept_c)]
 
         def build(r):
             out = []
@@ -400,7 +485,6 @@ class PPOLearner:
                     d.update(actor_grads=kept[ep][0], critic_grads=kept[ep][1], actor_after=kept[ep][2], critic_after=kept[ep][3])
                 out.append(d)
             return out
-        host, ev, attach = _to_host_async(self._ring, rec)  # no host wait here: see LazyRecords
         out = LazyRecords(nE, host, ev, build)
         attach(out)
         return out
@@ -412,6 +496,7 @@ class PPOLearner:
     # ------------------------------------------------------------------ checkpointing (README TODO of the reference)
     def state_dict(self):
         """Flat parameters + Adam moments + step counters (CPU tensors; torch.save-able)."""
+        self.wait_critic()
         return dict(algo=self.algo, actor_spec=vars(self.actor_spec), critic_spec=vars(self.critic_spec),
                     actor=self.actor.cpu(), critic=self.critic.cpu(),
                     opt_a=dict(m=self.opt_a.m.cpu(), v=self.opt_a.v.cpu(), step=self.opt_a.step),
@@ -420,6 +505,7 @@ class PPOLearner:
     def load_state_dict(self, sd):
         if sd["algo"] != self.algo or sd["actor_spec"] != vars(self.actor_spec) or sd["critic_spec"] != vars(self.critic_spec):
             raise N.NativeError("checkpoint was written for a different algorithm / network shape")
+        self.wait_critic()
         self.actor.copy_(sd["actor"]); self.critic.copy_(sd["critic"])
         for opt, o in ((self.opt_a, sd["opt_a"]), (self.opt_c, sd["opt_c"])):
             opt.m.copy_(o["m"]); opt.v.copy_(o["v"]); opt.step = int(o["step"])

@@ -26,9 +26,13 @@ class SyntheticSpreadRollout:
         self.Ds = 6 * A * A
         self.seed, self.env_offset = int(seed), int(env_offset)
         self.device = torch.device(device)
-        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
-        self.batch.avail.fill_(1)
-        self.batch.ep_len.fill_(T)
+        # two buffers used alternately: the learner's critic epochs (own stream, learner.py) may still read episode i's states and
+        # returns while episode i + 1 is being written
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+        for bb in self.batches:
+            bb.avail.fill_(1)
+            bb.ep_len.fill_(T)
+        self.batch = self.batches[0]  # the most recently collected one
         self.env_state = torch.zeros(E, 6 * A, dtype=torch.float32, device=self.device)
         self.episode = 0
 
@@ -37,6 +41,7 @@ class SyntheticSpreadRollout:
         current stream; returns the filled DeviceBatch without synchronising.
         fused=None picks the single-launch persistent kernel (cm_rollout_spread) whenever the shape allows,
         else T x (cm_policy_act + cm_synth_env_step); both produce the same rollout for the same seeds."""
+        self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         can_fuse = actor_spec.kind == "mlp" and bool(lib.cm_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden,
@@ -88,12 +93,15 @@ class SyntheticShapeRollout:
         self.obs_raw, self.agent_ids, self.avail_p = obs_raw, bool(agent_ids), float(avail_p)
         self.Do, self.Ds = obs_raw + (A if agent_ids else 0), state_dim
         self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
-        self.batch = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device)
-        self.batch.ep_len.fill_(T)
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]  # see SyntheticSpreadRollout
+        for bb in self.batches:
+            bb.ep_len.fill_(T)
+        self.batch = self.batches[0]
         self.h = None
         self.episode = 0
 
     def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
+        self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         need = 0

@@ -58,6 +58,12 @@ int cm_version(void);
 /* GEMM arithmetic of the PPO training passes: 0 = exact fp32 MFMA (default), 1 = error-compensated bf16 (environment variable
  * CM_MFMA=bf16x3, read once per process; ~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8). */
 int cm_mfma_mode(void);
+/* A HIP stream of the LOWEST priority the device offers (hipStreamCreateWithPriority, non-blocking), for work that has slack and
+ * should only fill compute units the caller's main stream leaves idle: the critic epochs of iteration i run on it under the rollout
+ * of iteration i + 1 (cleanmarl_amd/learner.py).  The reference has no counterpart (single CPU thread, mappo_multienvs.py:521-594).
+ * Returns NULL and sets cm_last_error() on failure; destroy with cm_stream_destroy. */
+cm_stream_t cm_stream_create_low_priority(void);
+int cm_stream_destroy(cm_stream_t stream);
 /* number of floats in a flat MLP parameter buffer */
 int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout);
 int64_t cm_gru_param_count(int din, int hidden, int dout);

@@ -358,11 +358,14 @@ def test_wide_actor_rollout_and_training_run_end_to_end(env_type, tmp_path, monk
     assert out["training_step"] >= 3 and "eval/ep_reward" in {t for t, _, _ in out["history"]}
 
 
+@pytest.mark.parametrize("tile", [64, 16])
 @pytest.mark.parametrize("E,A,T,H,L", [(37, 8, 12, 64, 1), (50, 3, 9, 64, 1), (10, 5, 6, 32, 0)])
-def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L):
-    """cm_rollout_spread (one persistent launch) == reset + T x (cm_policy_act, cm_synth_env_step)."""
+def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L, tile, monkeypatch):
+    """cm_rollout_spread (one persistent launch; both tilings: 64-row workgroup tiles and the 16-row form small env counts take)
+    == reset + T x (cm_policy_act, cm_synth_env_step)."""
     from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
     from cleanmarl_amd.rollout import SyntheticSpreadRollout
+    monkeypatch.setenv("CM_ROLLOUT_TILE", str(tile))
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
     ra = SyntheticSpreadRollout(E, A, T, seed=7, device=dev, env_offset=123)

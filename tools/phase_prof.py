@@ -38,7 +38,7 @@ if which == "actor":
                                                   E, A, T, Do, 64, 1, K, N.ptr(p), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "actor")
 elif which == "rollout":
     from cleanmarl_amd.rollout import SyntheticSpreadRollout
-    prof = torch.zeros(512, 16, dtype=torch.int64, device=dev)
+    prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
     lib.cm_prof_set_buffer(C.c_void_p(prof.data_ptr()))
     spec = NetSpec(Do, 64, 1, K)
     p = flatten_params(init_params_like_torch(spec), dev)
@@ -61,9 +61,13 @@ ms = e0.elapsed_time(e1)
 ph = prof.double().mean(0).cpu()
 tot = float(ph.sum())
 if which == "rollout":
-    ph = prof.double().mean(0).cpu(); tot = float(ph.sum())
-    print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase (512 WGs, 1 tile each):")
-    for i, n in enumerate(["barrier_top", "obs+reward_partials", "buffer_writes", "fwd_mlp", "head_logits(mfma)", "sample+physics"]):
+    used = prof[(prof.sum(1) > 0)]
+    ph = used.double().mean(0).cpu(); tot = float(ph.sum())
+    names = ["barrier_top", "obs+reward_partials", "buffer_writes", "fwd_mlp", "head_logits(mfma)", "sample+physics"]
+    if os.environ.get("CM_ROLLOUT_TILE") == "16" or (os.environ.get("CM_ROLLOUT_TILE") != "64" and (E + 64 // A - 1) // (64 // A) < 384):
+        names = ["barrier_top", "reward_partials+obs", "buffer_writes+philox", "layer0", "layer1", "head(mfma)", "sample+physics"]
+    print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase ({used.shape[0]} WGs):")
+    for i, n in enumerate(names):
         print(f"  {n:24s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
     print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
     sys.exit(0)
