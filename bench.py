@@ -330,7 +330,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import reference_loop  # checker / baseline only -- never part of the measured path
         Ec, cores = args.cpu_envs, os.cpu_count() or 1
-        sweep = sorted({1, min(8, cores), cores})
+        sweep = sorted({1, min(8, cores), min(32, cores)})  # never all cores: 256 intra-op threads took 470 s for ONE probe epoch
         rc = reference_loop.run(E=Ec, A=A, T=T, thread_sweep=sweep)
         th = rc["threads"]
         out["cpu_baseline"] = {"value": rc["agent_steps_per_s"], "unit": "agent-env-steps/s",

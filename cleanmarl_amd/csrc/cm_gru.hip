@@ -16,6 +16,9 @@
 // per workgroup, then folded by k_reduce_partials.  Time is inherently sequential here; parallelism is over
 // sequences only (SURVEY.md §7 "hard parts" (e)).
 #include "cm_mlp_train.h"
+#ifdef CM_PHASE_PROF
+extern unsigned long long* g_prof;
+#endif
 
 namespace {
 
@@ -49,16 +52,19 @@ struct GruArgs {
     // act mode
     const float* x; long x_stride; const uint8_t* av; long av_stride; long rows; float* h;
     unsigned long long seed; long row_offset; int t; int* action_out; float* logp_out; long out_stride;
+    unsigned long long* prof;  // CM_PHASE_PROF builds only
 };
 
 // gate non-linearities on the hardware exp (v_exp_f32, ~1 ulp): 48 transcendental evaluations per lane per step make
 // the libm versions (~30 instructions each) a visible part of the sequential per-step latency
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }  // v_rcp_f32: 1 ulp, one instruction
 __device__ __forceinline__ float tanhf_(float x) {
     const float e = __expf(-2.0f * fabsf(x));           // in (0, 1]: no overflow
-    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, x);
 }
+
+#include "cm_gru_step2.h"
 
 // LDS carve: 8 activation/weight buffers + head weights + per-row scratch + biases
 struct GruLds { float *b[8], *wouts, *ls, *b1, *bih, *bhh, *b2, *red; };
@@ -614,21 +620,20 @@ struct GruRollArgs {
     float* obs; float* state; int* action; float* logp; float* reward;
 };
 constexpr float GR_DAMP = 0.25f, GR_DT = 0.1f, GR_ACCEL = 5.0f, GR_COLLIDE = 0.3f;  // cm_env.hip / cm_rollout.hip constants
-constexpr int G32R_EXTRA_FLOATS = T32 * 8 + 3 * T32 * 2 + 2 * T32 + 4 * T32 + 16;  // ls, pos/vel/landmarks, reward partials, 2 x long[32]
+constexpr int G32R_LDS_FLOATS = 4 * T32 * LDT + 8 * HP + KMAX + 64 + T32 * 8 + 3 * T32 * 2 + 2 * T32 + 4 * T32 + 16;  // 4 tiles, head weights, ls, pos/vel/landmarks, reward partials, 2 x long[32]
 
-__global__ __launch_bounds__(NTHREADS) void k_gru32_rollout(const GruRollArgs a) {
+__global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KJ = 2, KP = 8;
     const GruOff off = gru_offsets(a.din, a.H, a.K);
-    float* Wt[7];
     float* p = smem;
-    for (int i = 0; i < 7; ++i) { Wt[i] = p; p += HP * LDT; }
-    float* XA = p; p += T32 * LDT;
+    float* XA = p; p += T32 * LDT;   // obs tile
+    float* X1 = p; p += T32 * LDT;   // x1
     float* hp = p; p += T32 * LDT;
     float* hn = p; p += T32 * LDT;
     GruLds L = {};
     L.wouts = p; p += KP * HP;
-    L.b1 = p; p += HP; L.bih = p; p += 3 * HP; L.bhh = p; p += 3 * HP; L.b2 = p; p += KMAX;
+    L.b2 = p; p += KMAX;
     L.red = p; p += 64;
     float* ls = p; p += T32 * 8;
     float* epos = p; p += T32 * 2;
@@ -641,21 +646,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_rollout(const GruRollArgs a)
     const int hrow = tid >> 2, hq = tid & 3;
     const int A = a.A, T = a.T, K = a.K, H = a.H, din = a.din;
     const int EPT = T32 / A, RT = EPT * A, Ds = 6 * A * A;
-    stage_rows(Wt[0], a.params + off.W1, 0, H, din, 0, din);
-#pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-        stage_rows(Wt[1 + q], a.params + off.Wih + q * H * H, 0, H, H, 0, H);
-        stage_rows(Wt[4 + q], a.params + off.Whh + q * H * H, 0, H, H, 0, H);
-    }
+    G2W w;  // the seven weight blocks: this wave's 16 hidden columns in registers for the whole episode (cm_gru_step2.h)
+    g2_load_weights<false>(w, a.params, off, din, H);
     for (int i = tid; i < KP * HP; i += NTHREADS) {
         const int k = i / HP, c = i % HP;
         L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
-    }
-    for (int i = tid; i < HP; i += NTHREADS) L.b1[i] = (i < H) ? a.params[off.b1 + i] : 0.0f;
-    for (int i = tid; i < 3 * HP; i += NTHREADS) {
-        const int gg = i / HP, c = i % HP;
-        L.bih[i] = (c < H) ? a.params[off.bih + gg * H + c] : 0.0f;
-        L.bhh[i] = (c < H) ? a.params[off.bhh + gg * H + c] : 0.0f;
     }
     for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
 
@@ -754,8 +749,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gru32_rollout(const GruRollArgs a)
                                                 (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
                 u_row = cm_u01(rnd.x);
             }
-            // ---- GRU step (its first barrier orders the obs tile and the buffer-write reads before x1 overwrites XA)
-            gru32_step<false>(Wt, XA, hp, hn, L.b1, L.bih, L.bhh, din, H, 0, T32, nullptr);
+            // ---- GRU step: the obs tile is complete since the barrier above, h_{t-1} since the end of the previous step
+            gru2_step<false>(w, XA, X1, hp, hn, nullptr, nullptr, nullptr, nullptr, din, H);
             if (hrow < T32) {
                 unsigned char avb[KJ] = {1, 1};
                 float zreg[KJ];
@@ -1358,6 +1353,8 @@ int gru_check(const char* who, int din, int H, int K) {
     return 0;
 }
 
+#include "cm_gru_v2.h"
+
 }  // namespace
 
 static size_t gru_ps(int din, int hidden, int K) {
@@ -1366,7 +1363,8 @@ static size_t gru_ps(int din, int hidden, int K) {
 
 extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int n_actions, int chunk_len) {
     const size_t R = (size_t)E * A;
-    return ((size_t)chunk_len * R * (WS_ACT + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
+    // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
+    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
 }
 
 extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
@@ -1386,8 +1384,11 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     a.E = E; a.A = A; a.T = T; a.t0 = t0; a.t1 = t1; a.din = din; a.H = hidden; a.K = n_actions;
     a.params = params; a.h_in = h_in; a.h_out = h_out;
     a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip; a.ent_coef = (float)entropy_coef;
-    a.ws_act = (float*)ws; a.ws_dl = a.ws_act + (size_t)CL * R * WS_ACT; a.partial = a.ws_dl + (size_t)CL * R * WS_DL;
+    a.ws_act = (float*)ws; a.ws_dl = a.ws_act + (size_t)CL * R * WS2; a.partial = a.ws_dl + (size_t)CL * R * WS_DL;
     a.PS = (int)gru_ps(din, hidden, n_actions);
+#ifdef CM_PHASE_PROF
+    a.prof = g_prof;
+#endif
     const int grid = grid_for((long)R);
     const size_t lds = gru_lds_bytes(n_actions);
     const bool wv = gru_wvec(params, hidden);
@@ -1400,12 +1401,30 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     // otherwise the 64-row streaming kernels (same workspace format)
     // 32-row sweeps pay off while the 64-row tiling leaves CUs idle or barely filled (measured: 5k and 20k sequences faster,
     // 82k sequences slower than the 64-row kernels); above 512 64-row tiles the streaming 64-row kernels take over
-    const char* tile_env = getenv("CM_GRU_TILE");  // test hook: CM_GRU_TILE=64 forces the 64-row kernels at any batch size
-    const bool force64 = tile_env && atoi(tile_env) == 64;
+    const char* tile_env = getenv("CM_GRU_TILE");  // test hook: CM_GRU_TILE=64 forces the 64-row kernels at any batch size,
+    const bool force64 = tile_env && atoi(tile_env) == 64;  // CM_GRU_TILE=32 the first-generation 32-row sweeps (default: cm_gru_v2.h)
+    const bool force_v1 = tile_env && atoi(tile_env) == 32;
     const bool fwd32 = !force64 && din <= KC && (long)R <= 512L * TM;
     const long nt32 = ((long)R + T32 - 1) / T32;
     const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
     const int KP32 = n_actions <= 8 ? 8 : KMAX;
+    if (fwd32 && !force_v1 && n_actions <= KP2) {  // second-generation sweeps: weights in registers, head outside the recurrence
+        const size_t lf = gru2_fwd_lds_bytes(), lb = gru2_bwd_lds_bytes();
+        if (wv) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf);
+            hipLaunchKernelGGL(k_gru2_fwd<true>, dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf);
+            hipLaunchKernelGGL(k_gru2_fwd<false>, dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a);
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);
+        CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
+        const int64_t P2 = cm_gru_param_count(din, hidden, n_actions);
+        MlpArgs m2 = {};
+        m2.partial = a.partial; m2.PS = a.PS;
+        return finish_train(m2, grid32, P2, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
+    }
     if (fwd32) {
         const size_t lds32 = gru32_lds_bytes(KP32);
         if (n_actions <= 8) {
@@ -1481,7 +1500,7 @@ extern "C" int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int 
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
     const int EPT = T32 / A;
     const int ntiles = (E + EPT - 1) / EPT;
-    const size_t lds = (size_t)(G32_LDS_FLOATS + G32R_EXTRA_FLOATS) * sizeof(float);
+    const size_t lds = (size_t)G32R_LDS_FLOATS * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_gru32_rollout, dim3(ntiles < 256 ? ntiles : 256), dim3(NTHREADS), lds, (hipStream_t)stream, a);
     CM_CHECK_LAUNCH("cm_gru_rollout_spread");

@@ -1,0 +1,118 @@
+// cm_gru_step2.h -- the recurrent GRU step of the second-generation kernels (included by cm_gru.hip inside its anonymous namespace,
+// after sigmoidf_ / tanhf_; used by k_gru2_fwd in cm_gru_v2.h and by the fused rollout k_gru32_rollout).
+#pragma once
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for this wave's outstanding global stores
+// (s_waitcnt vmcnt(0)); the per-step workspace stores are never read inside the step loops, and waiting for their
+// acknowledgement at the next barrier cost ~1400 cycles per step (profiles/r02_phase_gru_v2.txt, "barrier_top").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The recurrent step, "column-quarter" form: wave w owns hidden columns 16w .. 16w+15 of ALL three gates for the tile's 32 rows
+// (two 16-row blocks on v_mfma_f32_16x16x4_f32).  r, z, n and h' of a (row, column) are then produced by ONE lane from its own
+// accumulators -- no hand-over of gates between waves, two LDS barriers per step (x1 complete, h' complete) -- and the matrix work is
+// the same on every wave (fc1 + six 32 x 16 x 64 products = 6.7 k cycles, the balanced minimum for a 32-row tile on one CU).
+// The six gate blocks + fc1 are 112 registers per lane: w[4j + i] = W[(16w + n) * ld + 16j + 4g + i] for lane (n = lane & 15,
+// g = lane >> 4), the B operand of MFMA (j, i); the A operand is one 16-byte LDS read per four MFMAs and is shared by the three
+// products that multiply the same activations.
+struct G2W { float w1[16], xr[16], xz[16], xn[16], hr[16], hz[16], hn[16]; float b1, br, bz, bin, bhn; };
+template <bool VEC>
+__device__ __forceinline__ void load_nt16_regs(float (&w)[16], const float* W, int c0, int nrows, int ld, int ncols) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int c = c0 + n;
+    const float* p = W + (long)c * ld + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (VEC) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nrows && 16 * j + 4 * g < ncols) v = *reinterpret_cast<const float4*>(p + 16 * j);
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[4 * j + i] = (c < nrows && 16 * j + 4 * g + i < ncols) ? p[16 * j + i] : 0.0f;
+        }
+    }
+}
+template <bool WV>
+__device__ __forceinline__ void g2_load_weights(G2W& w, const float* params, const GruOff& off, int din, int H) {
+    const int wave = threadIdx.x >> 6, c0 = 16 * wave, c = c0 + (threadIdx.x & 15);
+    load_nt16_regs<false>(w.w1, params + off.W1, c0, H, din, din);
+    load_nt16_regs<WV>(w.xr, params + off.Wih, c0, H, H, H);
+    load_nt16_regs<WV>(w.xz, params + off.Wih + H * H, c0, H, H, H);
+    load_nt16_regs<WV>(w.xn, params + off.Wih + 2 * H * H, c0, H, H, H);
+    load_nt16_regs<WV>(w.hr, params + off.Whh, c0, H, H, H);
+    load_nt16_regs<WV>(w.hz, params + off.Whh + H * H, c0, H, H, H);
+    load_nt16_regs<WV>(w.hn, params + off.Whh + 2 * H * H, c0, H, H, H);
+    const bool ok = c < H;
+    w.b1 = ok ? params[off.b1 + c] : 0.0f;
+    w.br = ok ? params[off.bih + c] + params[off.bhh + c] : 0.0f;            // same association as the first-generation kernels
+    w.bz = ok ? params[off.bih + H + c] + params[off.bhh + H + c] : 0.0f;
+    w.bin = ok ? params[off.bih + 2 * H + c] : 0.0f;
+    w.bhn = ok ? params[off.bhh + 2 * H + c] : 0.0f;
+}
+// three products that share their A operand: acc_p[rb] += A[16 rb + ..][16 kb] * W_p^T, p = 0..2, rb = 0..1 (six independent chains)
+__device__ __forceinline__ void g2_prod3(f32x4 (&a0)[2], f32x4 (&a1)[2], f32x4 (&a2)[2], const float* As,
+                                         const float (&w0)[16], const float (&w1)[16], const float (&w2)[16]) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float4* ap0 = reinterpret_cast<const float4*>(As + n * LDT + 4 * g);
+    const float4* ap1 = reinterpret_cast<const float4*>(As + (16 + n) * LDT + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 x = ap0[4 * j], y = ap1[4 * j];
+#define CM_G2_K(c, i) do { \
+        a0[0] = mfma16(x.c, w0[4 * j + i], a0[0]); a1[0] = mfma16(x.c, w1[4 * j + i], a1[0]); a2[0] = mfma16(x.c, w2[4 * j + i], a2[0]); \
+        a0[1] = mfma16(y.c, w0[4 * j + i], a0[1]); a1[1] = mfma16(y.c, w1[4 * j + i], a1[1]); a2[1] = mfma16(y.c, w2[4 * j + i], a2[1]); } while (0)
+        CM_G2_K(x, 0); CM_G2_K(y, 1); CM_G2_K(z, 2); CM_G2_K(w, 3);
+#undef CM_G2_K
+    }
+}
+__device__ __forceinline__ void g2_prod1(f32x4 (&a0)[2], const float* As, const float (&w0)[16], int kb16) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float4* ap0 = reinterpret_cast<const float4*>(As + n * LDT + 4 * g);
+    const float4* ap1 = reinterpret_cast<const float4*>(As + (16 + n) * LDT + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < kb16) {
+            const float4 x = ap0[4 * j], y = ap1[4 * j];
+            a0[0] = mfma16(x.x, w0[4 * j], a0[0]); a0[1] = mfma16(y.x, w0[4 * j], a0[1]);
+            a0[0] = mfma16(x.y, w0[4 * j + 1], a0[0]); a0[1] = mfma16(y.y, w0[4 * j + 1], a0[1]);
+            a0[0] = mfma16(x.z, w0[4 * j + 2], a0[0]); a0[1] = mfma16(y.z, w0[4 * j + 2], a0[1]);
+            a0[0] = mfma16(x.w, w0[4 * j + 3], a0[0]); a0[1] = mfma16(y.w, w0[4 * j + 3], a0[1]);
+        }
+    }
+}
+// One step.  In: X0 = obs tile [32][LDT] (zero padded to 64 columns), hp = h_{t-1}.  Out: X1 = x1, hn = h'; with SAVE also the
+// tiles r, z, n, W_hn h + b_hn (SR, SZ, SN, SG) that the backward sweep needs.  Barriers: the caller's barrier BEFORE the call must
+// cover X0 / hp (and the previous readers of X1 / S* / hn); the function ends with the barrier that completes hn and the tiles.
+template <bool SAVE>
+__device__ __forceinline__ void gru2_step(const G2W& w, const float* X0, float* X1, const float* hp, float* hn,
+                                          float* SR, float* SZ, float* SN, float* SG, int din, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int col = 16 * wave + n;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a1[2] = {zero, zero};
+    g2_prod1(a1, X0, w.w1, (din + 15) >> 4);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X1[(16 * rb + 4 * g + q) * LDT + col] = fmaxf(a1[rb][q] + w.b1, 0.0f);
+    f32x4 hr[2] = {zero, zero}, hz[2] = {zero, zero}, hnn[2] = {zero, zero};
+    g2_prod3(hr, hz, hnn, hp, w.hr, w.hz, w.hn);   // does not depend on x1: in flight while the other waves finish theirs
+    lds_barrier();                                  // x1 complete
+    f32x4 xr[2] = {zero, zero}, xz[2] = {zero, zero}, xn[2] = {zero, zero};
+    g2_prod3(xr, xz, xn, X1, w.xr, w.xz, w.xn);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = (16 * rb + 4 * g + q) * LDT + col;
+            const float r = sigmoidf_((xr[rb][q] + hr[rb][q]) + w.br);
+            const float z = sigmoidf_((xz[rb][q] + hz[rb][q]) + w.bz);
+            const float ghn = hnn[rb][q] + w.bhn;
+            const float nn = tanhf_(xn[rb][q] + w.bin + r * ghn);
+            hn[o] = (col < H) ? (1.0f - z) * nn + z * hp[o] : 0.0f;
+            if (SAVE) { SR[o] = r; SZ[o] = z; SN[o] = nn; SG[o] = ghn; }
+        }
+    lds_barrier();                                  // h' (and the saved tiles) complete
+}
+

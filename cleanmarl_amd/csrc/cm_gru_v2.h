@@ -1,0 +1,523 @@
+// cm_gru_v2.h -- second generation of the 32-row TBPTT sweeps (included by cm_gru.hip inside its anonymous namespace).
+//
+// Same arithmetic as k_gru32_chunk_fwd / k_gru32_chunk_bwd (reference: cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620); what
+// changes is where things live, because at config 5 the sweeps are a latency chain (5120 sequences = 160 workgroups on 256 CUs, one
+// per CU, time strictly sequential), not a throughput problem:
+//   * WEIGHTS IN REGISTERS.  Every gate block is the B operand of a 32x32x2 MFMA whose lane (n = lane & 31, h = lane >> 5) always
+//     supplies the same 32 weights; a wave keeps the blocks it multiplies with in VGPRs for the whole chunk (forward: 4 blocks =
+//     114 registers, backward: 3 transposed blocks = 96).  No weight tile in LDS, no per-step staging, half the LDS reads per MFMA,
+//     and LDS is free for what follows.
+//   * ROW-MAJOR WORKSPACE STORES.  r, z, n, W_hn h go through LDS tiles and leave as 16-byte stores (12 per thread and step instead
+//     of 64 scattered 4-byte stores from the accumulator layout, which were 2.4 us of the 11.6 us forward step).
+//   * THE HEAD LEAVES THE RECURRENCE.  logits -> PPO loss -> dlogits, the fc2 weight gradient and the head's contribution to dh
+//     ((dlogits W2) .* (h' > 0)) depend on h'_t only, not on the chain: the forward kernel computes them AFTER its step loop for two
+//     steps at a time on the MFMA (64 (row, step) items per pass) and hands the backward sweep a ready dh_head[s] tile in the
+//     workspace.  The backward step loses its head phase (2 barriers, a 128-thread VALU GEMV) and its weight staging (6 barriers).
+//   * 4 barriers per step in both sweeps (were 7 / 12).
+// Limits: K <= 16 actions, din <= 64, H <= 64 (the dispatcher keeps the first-generation kernels for anything else).
+// Workspace: 7 slots per (step, row): x1 | r | z | n | W_hn h + b_hn | h' | dh_head.
+#pragma once
+
+#ifdef CM_PHASE_PROF
+#define PH2_FLUSH(base) do { if (a.prof && threadIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) a.prof[(size_t)((base) + blockIdx.x) * 16 + i_] = ph_[i_]; } } while (0)
+#else
+#define PH2_FLUSH(base)
+#endif
+constexpr int WS2 = 7 * HP;
+constexpr int KP2 = 16;  // padded head width of the v2 kernels
+
+// B-operand register image, "nt" form (Y = A W^T): w[4j + i] = W[(n0 + r) * ld + 8j + 4h + i], zero outside [nrows) x [ncols)
+template <bool VEC>
+__device__ __forceinline__ void load_nt_regs(float (&w)[32], const float* W, int n0, int nrows, int ld, int ncols) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int n = n0 + r;
+    const float* p = W + (long)n * ld + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (VEC) {  // ld % 4 == 0, 16-byte aligned base, ncols % 4 == 0
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < nrows && 8 * j + 4 * h < ncols) v = *reinterpret_cast<const float4*>(p + 8 * j);
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[4 * j + i] = (n < nrows && 8 * j + 4 * h + i < ncols) ? p[8 * j + i] : 0.0f;
+        }
+    }
+}
+// "tn" form (dX = dZ W): w[4j + q] = W[(8j + 4h + q) * ld + c0 + r], zero outside [nrows) x [ncols)
+__device__ __forceinline__ void load_tn_regs(float (&w)[32], const float* W, int c0, int nrows, int ld, int ncols) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int c = c0 + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 8 * j + 4 * h + q;
+            w[4 * j + q] = (n < nrows && c < ncols) ? W[(long)n * ld + c] : 0.0f;
+        }
+}
+// acc[32 rows x 32 cols] += A[32 rows][8 kb] * (register image); k order identical to rowpar_nt / rowpar_tn
+__device__ __forceinline__ void rowpar_rb(f32x16& acc, const float* As, const float (&w)[32], int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float4* ap = reinterpret_cast<const float4*>(As + r * LDT + 4 * h);
+    float4 a = ap[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < kb) {
+            float4 an = a;
+            if (j + 1 < kb) an = ap[2 * (j + 1)];
+            acc = mfma32(a.x, w[4 * j], acc);
+            acc = mfma32(a.y, w[4 * j + 1], acc);
+            acc = mfma32(a.z, w[4 * j + 2], acc);
+            acc = mfma32(a.w, w[4 * j + 3], acc);
+            a = an;
+        }
+    }
+}
+
+constexpr int g2f_lds_floats() { return 8 * T32 * LDT + TM * LDT + KP2 * WLD + 2 * TM * KP2 + KMAX + 2 * NTHREADS; }
+inline size_t gru2_fwd_lds_bytes() { return (size_t)g2f_lds_floats() * sizeof(float); }
+
+template <bool WV>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* X0 = p; p += T32 * LDT;   // obs tile of the step
+    float* X1 = p; p += T32 * LDT;   // x1 = relu(fc1(obs))
+    float* hp = p; p += T32 * LDT;   // h_{t-1}
+    float* hn = p; p += T32 * LDT;   // h_t
+    float* SR = p; p += T32 * LDT;
+    float* SZ = p; p += T32 * LDT;
+    float* SN = p; p += T32 * LDT;
+    float* SG = p; p += T32 * LDT;   // W_hn h + b_hn
+    float* HB = p; p += TM * LDT;    // head pass: relu(h') of two steps (64 items), then dh_head
+    float* wouts = p; p += KP2 * WLD;
+    float* ls = p; p += TM * KP2;    // logits of the 64 items
+    float* ls2 = p; p += TM * KP2;   // dlogits of the 64 items
+    float* b2 = p; p += KMAX;
+    float* red = p;                  // 2 * NTHREADS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, g = wave >> 1, h = lane >> 5, lc = lane & 31;  // head pass: wave (g, wn) = items 32 g .., columns 32 wn ..
+    const int col = 32 * wn + lc;
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    // ---- one-time: this wave's weight columns -> registers, head weights + biases -> LDS
+    G2W w;
+    g2_load_weights<WV>(w, a.params, off, din, H);
+    for (int i = tid; i < KP2 * WLD; i += NTHREADS) {
+        const int k = i / WLD, c = i % WLD;
+        wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < KMAX; i += NTHREADS) b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+
+    PH_DECL
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
+    f32x4 accWo = {0.f, 0.f, 0.f, 0.f};  // dW2[k = 4 (lane >> 4) + q][hidden column 16 wave + (lane & 15)]
+    float dbo = 0.f;
+    const long ntiles = (R + T32 - 1) / T32;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * T32;
+        __syncthreads();
+        for (int i = tid; i < T32 * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+        }
+        X32 xr;
+        x32_load(xr, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
+        x32_store(X0, xr);
+        if (CL > 1) x32_load(xr, a.obs + (long)(a.t0 + 1) * din, row0, R, (long)T * din, din);
+        // ================================================================ the recurrence: 3 barriers per step (gru2_step)
+        for (int s = 0; s < CL; ++s) {
+            const int t = a.t0 + s;
+            lds_barrier();  // X0 = obs(t), hp = h_{t-1}; the previous step's stores have read X1 / S* / hn
+            PH(0);
+            gru2_step<true>(w, X0, X1, hp, hn, SR, SZ, SN, SG, din, H);
+            PH(1);
+            // obs(t + 1) (requested a step ago) -> X0: every read of obs(t) is two barriers back.  obs(t + 2) is requested BEFORE this
+            // step's workspace stores: queued behind those 12 KB per wave the loads stalled the wave for ~1400 cycles at issue
+            if (s + 1 < CL) x32_store(X0, xr);
+            if (s + 2 < CL) x32_load(xr, a.obs + (long)(t + 2) * din, row0, R, (long)T * din, din);
+            {   // six row-major tiles leave as 16-byte stores
+                float* wsS = a.ws_act + ((long)s * R + row0) * WS2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                    if (row0 + r < R) {
+                        float* wp = wsS + (long)r * WS2 + c4;
+                        const int o = r * LDT + c4;
+                        *reinterpret_cast<float4*>(wp) = *reinterpret_cast<const float4*>(X1 + o);
+                        *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(SR + o);
+                        *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(SZ + o);
+                        *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(SN + o);
+                        *reinterpret_cast<float4*>(wp + 4 * HP) = *reinterpret_cast<const float4*>(SG + o);
+                        *reinterpret_cast<float4*>(wp + 5 * HP) = *reinterpret_cast<const float4*>(hn + o);
+                    }
+                }
+            }
+            float* tmp = hp; hp = hn; hn = tmp;
+            PH(5);
+        }
+        __syncthreads();
+        if (a.h_out)
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+            }
+        // ================================================================ the head, two steps (64 (row, step) items) per pass
+        const int hrow = tid >> 2, hq = tid & 3;   // PPO math: 4 lanes per item
+        const int irow = hrow & 31;                // tile row of the item
+        const long grow = row0 + irow;
+        const bool rvalid = grow < R;
+        const int e_row = rvalid ? (int)(grow / a.A) : 0;
+        const int ag = (int)(grow - (long)e_row * a.A);
+        const int eplen = rvalid ? a.ep_len[e_row] : 0;
+        const float invA = 1.0f / (float)a.A;
+        // relu(h') tiles of a pass are requested one pass ahead (they come back from L2: ~3400 cycles if waited for in place)
+        float4 hpre[4];
+        auto head_load = [&](int sA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + NTHREADS * q, it = idx >> 4, c4 = (idx & 15) * 4;
+                const int ss = sA + (it >> 5), r = it & 31;
+                hpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ss < CL && row0 + r < R) hpre[q] = *reinterpret_cast<const float4*>(a.ws_act + ((long)ss * R + row0 + r) * WS2 + 5 * HP + c4);
+            }
+        };
+        head_load(0);  // the rows were written by this workgroup: the __syncthreads() above made them visible
+        for (int s0 = 0; s0 < CL; s0 += 2) {
+            const int s_it = s0 + (hrow >> 5), t_it = a.t0 + s_it;
+            const bool ivalid = rvalid && s_it < CL;
+            // per-item inputs (latency hides under the MFMA below)
+            unsigned char avb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                avb[j] = 1;
+                if (ivalid && 4 * j + hq < K) avb[j] = a.avail[(grow * T + t_it) * K + 4 * j + hq];
+            }
+            const long o = grow * T + t_it;
+            const int act = ivalid ? a.action[o] : 0;
+            const float lpo = ivalid ? a.logp_old[o] : 0.f, advv = ivalid ? a.adv[o] : 0.f;
+            lds_barrier();  // HB / ls / ls2 of the previous pass are dead
+            PH(6);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + NTHREADS * q, it = idx >> 4, c4 = (idx & 15) * 4;
+                float4 v = hpre[q];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<float4*>(HB + it * LDT + c4) = v;
+            }
+            if (s0 + 2 < CL) head_load(s0 + 2);
+            lds_barrier();
+            PH(7);
+            {   // logits on the 16x16x4 MFMA: wave w = items 16w..16w+15
+                const f32x4 lg = head_logits_mfma(HB + 16 * wave * LDT, wouts);
+                const int n = lane & 15, g4 = lane >> 4;
+                const float bias = b2[n];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * KP2 + n] = lg[q] + bias;
+            }
+            lds_barrier();
+            PH(8);
+            {   // PPO clipped-surrogate head (arithmetic of k_gru32_chunk_fwd): statistics + dlogits -> ls2
+                float zreg[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zreg[j] = (4 * j + hq < K && avb[j]) ? ls[hrow * KP2 + 4 * j + hq] : -1e9f;
+                const bool valid = ivalid && t_it < eplen;
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
+                m = quad_max(m);
+                float ssum = 0.0f, pj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
+                ssum = quad_sum(ssum);
+                const float lse = m + logf(ssum), rs = 1.0f / ssum;
+                float ent = 0.f, lpa = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (4 * j + hq < K) {
+                    const float lp = zreg[j] - lse;
+                    pj[j] *= rs; ent -= pj[j] * lp;
+                    if (4 * j + hq == act) lpa = lp;
+                }
+                ent = quad_sum(ent); lpa = quad_sum(lpa);
+                const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
+                const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                float gsel;
+                if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
+                if (valid && hq == 0) {
+                    st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
+                    st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
+                    if (ag == 0) st_cnt += 1.f;
+                }
+                const float gr = gsel * ratio;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * j + hq;
+                    float d = 0.f;
+                    if (k < K && valid && zreg[j] > -5e8f) {
+                        const float lp = zreg[j] - lse;
+                        d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
+                    }
+                    ls2[hrow * KP2 + k] = d;
+                }
+            }
+            lds_barrier();
+            PH(9);
+            // fc2 gradient: dW2 += dlogits^T relu(h') over the 64 items (wave = 16 hidden columns), db2 += column sums
+            colred_head16<KP2>(accWo, ls2, 0, HB + 16 * wave);
+            {
+                const int k = tid & 15, part = tid >> 4;
+                float sb = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sb += ls2[(part * 4 + r) * KP2 + k];
+                dbo += sb;
+            }
+            // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .., columns 32 wn ..
+            f32x16 dh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dh[i] = 0.0f;
+            head_bwd_mfma<KP2>(dh, ls2 + 32 * g * KP2, wouts + 32 * wn);
+            lds_barrier();  // every read of HB (fc2 gradient) is done: it becomes the dh_head tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float* q = HB + (32 * g + (i & 3) + 8 * (i >> 2) + 4 * h) * LDT + col;
+                *q = (*q > 0.0f) ? dh[i] : 0.0f;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + NTHREADS * q, it = idx >> 4, c4 = (idx & 15) * 4;
+                const int ss = s0 + (it >> 5), r = it & 31;
+                if (ss < CL && row0 + r < R)
+                    *reinterpret_cast<float4*>(a.ws_act + ((long)ss * R + row0 + r) * WS2 + 6 * HP + c4) = *reinterpret_cast<const float4*>(HB + it * LDT + c4);
+            }
+            PH(10);
+        }
+    }
+    PH2_FLUSH(0);
+    // ================================ this workgroup's partial row: fc2 gradient + statistics (the rest comes from k_gru2_bwd)
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+    {
+        const int n = lane & 15, g4 = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g4 + r, c = 16 * wave + n;
+            if (k < K && c < H) out[off.W2 + k * H + c] = accWo[r];
+        }
+    }
+    __syncthreads();
+    red[tid] = dbo;  // [16 parts][16 k]
+    __syncthreads();
+    if (tid < K) {
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sb += red[q * 16 + tid];
+        out[off.b2 + tid] = sb;
+    }
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = cm_wave_sum(sv6[q]);
+        if (lane == 0) red[q * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < CM_NUM_STATS) {
+        float v = 0.f;
+        if (tid < 6) v = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+        out[off.P + tid] = v;
+    }
+}
+
+// transposed tiles [64 columns][32 rows] with row stride LTT: the operands of the weight-gradient MFMAs (contraction over the tile's
+// rows) come out of them as 16-byte reads, four MFMAs per pair of reads, instead of two 4-byte reads per MFMA
+constexpr int LTT = 36;
+// acc[32 (n) x 32 (k)] += sum over the 32 rows of Z[row][n0 + i] * X[row][k0 + j], both operands from TRANSPOSED tiles
+__device__ __forceinline__ void colred32t(f32x16& acc, const float* ZT_n0, const float* XT_k0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float4* ap = reinterpret_cast<const float4*>(ZT_n0 + r * LTT + 4 * h);
+    const float4* bp = reinterpret_cast<const float4*>(XT_k0 + r * LTT + 4 * h);
+#pragma unroll
+    for (int j = 0; j < T32 / 8; ++j) {
+        const float4 a = ap[2 * j], b = bp[2 * j];
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+    }
+}
+inline size_t gru2_bwd_lds_bytes() { return (size_t)(5 * T32 * LDT + 7 * HP * LTT + 2 * NTHREADS) * sizeof(float); }
+
+__global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* DH = p; p += T32 * LDT;    // row-major [32][LDT]: dh carried backwards; G0..G3 = the four pre-activation gradients
+    float* G0 = p; p += T32 * LDT;
+    float* G1 = p; p += T32 * LDT;
+    float* G2 = p; p += T32 * LDT;
+    float* G3 = p; p += T32 * LDT;
+    float* G0T = p; p += HP * LTT;    // the same four, x1 (then dx1), h_{t-1} and the obs tile TRANSPOSED [64][LTT]
+    float* G1T = p; p += HP * LTT;
+    float* G2T = p; p += HP * LTT;
+    float* G3T = p; p += HP * LTT;
+    float* A1T = p; p += HP * LTT;
+    float* HPT = p; p += HP * LTT;
+    float* OBT = p; p += HP * LTT;
+    float* red = p;                   // 2 * NTHREADS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, role = wave >> 1, h = lane >> 5, lc = lane & 31;
+    const int H = a.H, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const int col = 32 * wn + lc;
+    const int ec = tid & 63, er0 = 8 * (tid >> 6);  // elementwise phase: this thread owns column ec of rows er0 .. er0 + 7
+    // role 0: dx1 = sum_q dG_i[q] W_ih[q]; role 1: dh_prev = sum_q dG_h[q] W_hh[q] -- this wave's 32 columns of the three blocks
+    float wG[3][32];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) load_tn_regs(wG[q], a.params + (role == 0 ? off.Wih : off.Whh) + q * H * H, 32 * wn, H, H, H);
+
+    f32x16 accW1, accWih[3], accWhh[3];
+    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        accW1[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { accWih[q][i] = 0.f; accWhh[q][i] = 0.f; }
+    }
+    PH_DECL
+    const long ntiles = (R + T32 - 1) / T32;
+    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], dhh[8], ob[8]; } P;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * T32;
+        // everything a step reads from HBM is requested one step AHEAD, under the MFMA phases of the step before
+        auto load_pre = [&](int s) {
+            const float* wsS = a.ws_act + ((long)s * R + row0) * WS2;
+            const float* ob = a.obs + (long)(a.t0 + s) * din;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = er0 + e;
+                const bool rok = row0 + r < R;
+                const float* w = wsS + (long)r * WS2;
+                P.x1[e] = P.rr[e] = P.zz[e] = P.nn[e] = P.ghn[e] = P.hprev[e] = P.dhh[e] = P.ob[e] = 0.0f;
+                if (rok && ec < H) {
+                    P.x1[e] = w[ec]; P.rr[e] = w[HP + ec]; P.zz[e] = w[2 * HP + ec]; P.nn[e] = w[3 * HP + ec]; P.ghn[e] = w[4 * HP + ec];
+                    P.dhh[e] = w[6 * HP + ec];
+                    if (s > 0) P.hprev[e] = a.ws_act[((long)(s - 1) * R + row0 + r) * WS2 + 5 * HP + ec];
+                    else if (a.h_in) P.hprev[e] = a.h_in[(row0 + r) * H + ec];
+                }
+                if (rok && ec < din) P.ob[e] = ob[(row0 + r) * (long)T * din + ec];
+            }
+        };
+        __syncthreads();
+        for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
+        load_pre(CL - 1);
+        for (int s = CL - 1; s >= 0; --s) {
+            lds_barrier();  // the previous step's fc1 gradient has read A1T / OBT, its dh_prev is in DH
+            PH(0);
+            // ---- gate derivatives (elementwise); dh = carried dh + the head's share of this step (k_gru2_fwd)
+            {
+                float v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int o = (er0 + e) * LDT + ec;
+                    const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e];
+                    const float dh = DH[o] + P.dhh[e];
+                    const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
+                    const float dn_pre = dn * (1.0f - nn * nn);
+                    const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+                    const float dz_pre = dzg * zz * (1.0f - zz);
+                    v0[e] = dr_pre; v1[e] = dz_pre; v2[e] = dn_pre; v3[e] = dn_pre * rr;
+                    G0[o] = v0[e]; G1[o] = v1[e]; G2[o] = v2[e]; G3[o] = v3[e];
+                    DH[o] = dh * zz;
+                }
+                const int ot = ec * LTT + er0;
+#define CM_ST8(dst, v) do { *reinterpret_cast<float4*>(dst + ot) = make_float4(v[0], v[1], v[2], v[3]); \
+                            *reinterpret_cast<float4*>(dst + ot + 4) = make_float4(v[4], v[5], v[6], v[7]); } while (0)
+                CM_ST8(G0T, v0); CM_ST8(G1T, v1); CM_ST8(G2T, v2); CM_ST8(G3T, v3);
+                CM_ST8(A1T, P.x1); CM_ST8(HPT, P.hprev); CM_ST8(OBT, P.ob);
+#undef CM_ST8
+                // bias gradients = column sums: this thread already holds 8 rows of its column
+                dbg[0] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
+                dbg[1] += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
+                dbg[2] += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
+                dbg[3] += ((v3[0] + v3[1]) + (v3[2] + v3[3])) + ((v3[4] + v3[5]) + (v3[6] + v3[7]));
+            }
+            lds_barrier();
+            PH(1);
+            if (s > 0) load_pre(s - 1);
+            // ---- weight gradients of the gates: wave (role, wn) owns the (n-half = role, k-half = wn) tile of every block
+            colred32t(accWih[0], G0T + 32 * role * LTT, A1T + 32 * wn * LTT);
+            colred32t(accWih[1], G1T + 32 * role * LTT, A1T + 32 * wn * LTT);
+            colred32t(accWih[2], G2T + 32 * role * LTT, A1T + 32 * wn * LTT);
+            colred32t(accWhh[0], G0T + 32 * role * LTT, HPT + 32 * wn * LTT);
+            colred32t(accWhh[1], G1T + 32 * role * LTT, HPT + 32 * wn * LTT);
+            colred32t(accWhh[2], G3T + 32 * role * LTT, HPT + 32 * wn * LTT);
+            PH(2);
+            // ---- data path, weights from registers: no staging, no barrier between the gates
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            rowpar_rb(acc, G0, wG[0], HP / 8);
+            rowpar_rb(acc, G1, wG[1], HP / 8);
+            rowpar_rb(acc, role == 0 ? G2 : G3, wG[2], HP / 8);
+            PH(3);
+            lds_barrier();  // every wave is done with A1T (x1) and G*
+            PH(4);
+            if (role == 0) {  // dx1 through relu', written transposed: accumulator rows (i & 3) + 8 (i >> 2) + 4 h are 4 consecutive ones
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4* t = reinterpret_cast<float4*>(A1T + col * LTT + 8 * q + 4 * h);
+                    const float4 x = *t;
+                    *t = make_float4(x.x > 0.f ? acc[4 * q] : 0.f, x.y > 0.f ? acc[4 * q + 1] : 0.f,
+                                     x.z > 0.f ? acc[4 * q + 2] : 0.f, x.w > 0.f ? acc[4 * q + 3] : 0.f);
+                }
+            } else {          // dh_{t-1}
+#pragma unroll
+                for (int i = 0; i < 16; ++i) DH[((i & 3) + 8 * (i >> 2) + 4 * h) * LDT + col] += acc[i];
+            }
+            lds_barrier();
+            PH(5);
+            // ---- fc1 weight gradient + its bias
+            colred32t(accW1, A1T + 32 * role * LTT, OBT + 32 * wn * LTT);
+            {
+                const float4 u = *reinterpret_cast<const float4*>(A1T + ec * LTT + er0), w4 = *reinterpret_cast<const float4*>(A1T + ec * LTT + er0 + 4);
+                db1 += ((u.x + u.y) + (u.z + u.w)) + ((w4.x + w4.y) + (w4.z + w4.w));
+            }
+            PH(6);
+        }
+    }
+    PH2_FLUSH(512);
+    // ================================ partial gradient of this workgroup (fc2 + statistics were written by k_gru2_fwd)
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = 32 * role + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (n < H && col < din) out[off.W1 + n * din + col] = accW1[i];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (n < H && col < H) {
+                out[off.Wih + (q * H + n) * H + col] = accWih[q][i];
+                out[off.Whh + (q * H + n) * H + col] = accWhh[q][i];
+            }
+        }
+    }
+    {   // column-sum biases: 4 row parts per column (thread = column ec, rows er0 ..)
+        float vals[5] = {db1, dbg[0], dbg[1], dbg[2], dbg[3]};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            __syncthreads();
+            red[(tid >> 6) * HP + (tid & 63)] = vals[q];
+            __syncthreads();
+            if (tid < H) {
+                const float sv = red[tid] + red[HP + tid] + red[2 * HP + tid] + red[3 * HP + tid];
+                if (q == 0) out[off.b1 + tid] = sv;
+                else if (q == 1) { out[off.bih + tid] = sv; out[off.bhh + tid] = sv; }
+                else if (q == 2) { out[off.bih + H + tid] = sv; out[off.bhh + H + tid] = sv; }
+                else if (q == 3) out[off.bih + 2 * H + tid] = sv;
+                else out[off.bhh + 2 * H + tid] = sv;
+            }
+        }
+    }
+}

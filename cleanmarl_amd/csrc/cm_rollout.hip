@@ -313,6 +313,9 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
 //     prefix sums by row shifts: same summation order as cm_categorical_sample), no LDS round trip and no barrier;
 //   * 4 barriers per step, ~49 KB of LDS: three workgroups per CU.
 constexpr int TS = 16;  // rows per small tile
+#ifndef RO16_ABL
+#define RO16_ABL 0  // probe builds only (tools/probes/rollout16_ablate.sh): bit mask of step phases compiled out
+#endif
 
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {  // lanes shifted in from outside the 16-lane row read 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -465,9 +468,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
         for (int t = 0; t < T; ++t) {
             __syncthreads();
             PH(0);
-            if (t > 0) reward_partials();  // reward of step t-1: positions after its physics update
+            if (t > 0 && !(RO16_ABL & 4)) reward_partials();  // reward of step t-1: positions after its physics update
             // ---------------- observations of step t -> Xs: lane oq handles entity oq (landmark, other agent, id)
-            {
+            if (!(RO16_ABL & 8) || t == 0) {
                 float* xr = Xs + orow * LDT;
                 if (o_live) {
                     const float* pos = epos + o_el * 2 * A; const float* vel = evel + o_el * 2 * A; const float* lm = elm + o_el * 2 * A;
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             __syncthreads();
             PH(1);
             // ---------------- rollout-buffer writes (coalesced along the feature axis)
-            if (vecw) {  // <= 16 x 16 obs quads and <= 16 x 15 state quads: at most one of each per thread
+            if (RO16_ABL & 1) {
+            } else if (vecw) {  // <= 16 x 16 obs quads and <= 16 x 15 state quads: at most one of each per thread
                 const int nq = din >> 2, ns = (6 * A) >> 2;
                 {
                     const int r = tid / nq, c4 = tid - r * nq;
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
                     if (sb >= 0) a.state[sb + (long)t * Ds + c] = Xs[r * LDT + c];
                 }
             }
-            if (t > 0) reward_write(t - 1);
+            if (t > 0 && !(RO16_ABL & 4)) reward_write(t - 1);
             // The uniforms do not depend on the logits and ten Philox rounds are ~2000 cycles of quarter-rate integer multiplies: the 16
             // lanes of a row's group draw the uniforms of 16 consecutive steps at once (lane n: step t + n) every 16th step, and each
             // step fetches its own with one ds_bpermute issued here, far ahead of the sampler that reads it.
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             PH(2);
             // ---------------- actor forward, layer 0: wave = hidden columns 16w..16w+15
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            tile16_nt(acc, Xs, W0s + 16 * wave * LDT, (din + 7) >> 3);
+            if (!(RO16_ABL & 64)) tile16_nt(acc, Xs, W0s + 16 * wave * LDT, (din + 7) >> 3);
             {
                 const float bias = b0s[16 * wave + n16];
 #pragma unroll
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             const float* HL = H0;
             if (L > 0) {  // hidden layer; H1 aliases Xs (every wave is past its layer-0 reads and its buffer writes)
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                tile16_nt(acc, H0, Ws + 16 * wave * LDT, HP / 8);
+                if (!(RO16_ABL & 16)) tile16_nt(acc, H0, Ws + 16 * wave * LDT, HP / 8);
                 const float bias = b1s[16 * wave + n16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Xs[(4 * g16 + q) * LDT + 16 * wave + n16] = fmaxf(acc[q] + bias, 0.0f);
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             }
             PH(4);
             // ---------------- head: the whole 16 x 16 logit tile per wave, row 4g + w kept by lane group g
-            const f32x4 lg = head_logits_mfma(HL, wouts);
+            const f32x4 lg = (RO16_ABL & 32) ? f32x4{HL[n16], HL[n16 + 1], HL[n16 + 2], HL[n16 + 3]} : head_logits_mfma(HL, wouts);
             const float zraw = wave == 0 ? lg[0] : (wave == 1 ? lg[1] : (wave == 2 ? lg[2] : lg[3]));
             const bool kin = n16 < K;
             const float z = kin ? zraw + bos[n16] : -INFINITY;
@@ -560,7 +564,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             const bool av = kin && z > -5e8f;
             const float ssum = row16_from_lane(row16_serial_prefix(ex, n16, K), n16, K);  // s on lanes 0..K-1
             int chosen; float lpv;
-            if (a.act_eps > 0.0f) {
+            if (RO16_ABL & 2) {
+                chosen = (int)(m * 0.0f + u_row * 4.0f); lpv = z;
+            } else if (a.act_eps > 0.0f) {
                 const float navail = row16_sum(av ? 1.0f : 0.0f);
                 const float ca = (1.0f - a.act_eps) / ssum, cb = a.act_eps / fmaxf(navail, 1.0f);
                 const float p = av ? ca * ex + cb : 0.0f;
@@ -578,8 +584,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
                 lpv = zc - (m + logf(ssum));
             }
             if (n16 == 0 && s_live) {
-                a.action[s_out + t] = chosen;
-                a.logp[s_out + t] = lpv;
+                if (!(RO16_ABL & 1)) { a.action[s_out + t] = chosen; a.logp[s_out + t] = lpv; }
                 // point-mass physics (cm_env.hip k_env_step)
                 const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
                 const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);

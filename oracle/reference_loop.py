@@ -156,7 +156,7 @@ def run(E, A, T, hidden=64, n_layers=1, epochs=3, seed=1, gamma=0.99, lam=0.95, 
             def upd_probe():
                 a2, c2 = copy.deepcopy(actor), copy.deepcopy(critic)
                 al = 0; cl = 0
-                for t in range(Tm):
+                for t in range(0, Tm, 8):  # every 8th time step: the probe only ranks the thread counts
                     d = Categorical(logits=a2(b_obs[:, t]).masked_fill(~b_av[:, t], -1e9))
                     al = al + (torch.exp(d.log_prob(b_act[:, t]) - b_lp[:, t]) * adv[:, t]).sum() + d.entropy().sum()
                     cl = cl + nn.functional.mse_loss(c2(b_st[:, t]).expand(-1, A), ret[:, t])

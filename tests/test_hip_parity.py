@@ -423,13 +423,13 @@ def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H):
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
 
-@pytest.mark.parametrize("tile", ["auto", "64"])
+@pytest.mark.parametrize("tile", ["auto", "32", "64"])
 @pytest.mark.parametrize("name,algo", GRU_CASES)
 def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile, monkeypatch):
     # "auto" takes the 32-row forward / backward sweeps at this batch size; CM_GRU_TILE=64 (read per call) forces the 64-row
     # streaming kernels that large batches and K > 8 heads use, so both tilings are pinned to the reference goldens
-    if tile == "64":
-        monkeypatch.setenv("CM_GRU_TILE", "64")
+    if tile != "auto":
+        monkeypatch.setenv("CM_GRU_TILE", tile)
     else:
         monkeypatch.delenv("CM_GRU_TILE", raising=False)
     """cm_gru_actor_chunk_fwd_bwd + TBPTT schedule vs the unmodified reference's mappo/ippo_lstm_multienvs.py."""
@@ -470,7 +470,7 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
     assert k == len(z["actor_grads"])
 
 
-@pytest.mark.parametrize("tile", ["auto", "64"])
+@pytest.mark.parametrize("tile", ["auto", "32", "64"])
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,tb", [("ippo", 11, 4, 13, 37, 50, 17, 64, 5), ("mappo", 9, 3, 10, 21, 54, 5, 48, 4),
                                                       ("mappo", 40, 5, 12, 35, 150, 5, 64, 10)])
 def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile, monkeypatch):
@@ -479,8 +479,8 @@ def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile,
     from oracle import restatement as R
     from cleanmarl_amd.gru import GRUPPOLearner
     from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, init_params_like_torch
-    if tile == "64":
-        monkeypatch.setenv("CM_GRU_TILE", "64")
+    if tile != "auto":
+        monkeypatch.setenv("CM_GRU_TILE", tile)
     else:
         monkeypatch.delenv("CM_GRU_TILE", raising=False)
     torch.manual_seed(2)

@@ -36,6 +36,24 @@ if which == "actor":
     ws = torch.empty(lib.cm_mlp_train_workspace_bytes(Do, 64, 1, K), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_ppo_actor_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lp), N.ptr(adv), N.ptr(ep_len),
                                                   E, A, T, Do, 64, 1, K, N.ptr(p), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "actor")
+elif which == "gru":  # one TBPTT chunk of config 5 through the second-generation sweeps (cm_gru_v2.h)
+    E, A, T, K = 1024, 5, 128, 5
+    if len(sys.argv) > 3:
+        E, A = int(sys.argv[2]), int(sys.argv[3])
+    Do = 7 * A
+    prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
+    lib.cm_prof_set_buffer(C.c_void_p(prof.data_ptr()))
+    spec = NetSpec(Do, 64, 0, K, "gru")
+    p = flatten_params(init_params_like_torch(spec), dev)
+    obs = torch.randn(E, A, T, Do, device=dev); avail = torch.ones(E, A, T, K, dtype=torch.uint8, device=dev)
+    act = torch.randint(0, K, (E, A, T), dtype=torch.int32, device=dev); lp = -torch.rand(E, A, T, device=dev) - 1.0
+    adv = torch.randn(E, A, T, device=dev)
+    ep_len = torch.full((E,), T, dtype=torch.int32, device=dev)
+    g = torch.zeros(spec.nparams + 8, device=dev)
+    ws = torch.empty(lib.cm_gru_workspace_bytes(E, A, Do, 64, K, 10), dtype=torch.uint8, device=dev)
+    h0 = torch.zeros(E * A, 64, device=dev); h1 = torch.zeros(E * A, 64, device=dev)
+    run = lambda: N.check(lib.cm_gru_actor_chunk_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lp), N.ptr(adv), N.ptr(ep_len), E, A, T, 10, 20, Do,
+                                                        64, K, N.ptr(p), N.ptr(h0), N.ptr(h1), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "gru chunk")
 elif which == "rollout":
     from cleanmarl_amd.rollout import SyntheticSpreadRollout
     prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
@@ -60,6 +78,21 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 ph = prof.double().mean(0).cpu()
 tot = float(ph.sum())
+if which == "gru":
+    CL = 10
+    for name, base, per, names in (("k_gru2_fwd", 0, CL, ["barrier_top", "gru2_step (fc1, 6 products, gates)", "-", "-", "-", "workspace stores",
+                                                         "head: barrier", "head: load h'", "head: logits", "head: ppo math", "head: dW2 + dh_head + store"]),
+                                   ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives", "weight gradients (6 colred)", "data path (3 blocks, reg B)",
+                                                          "barrier", "dx1 / dh write", "fc1 gradient"])):
+        rows = prof[base:base + 512]
+        used = rows[rows.sum(1) > 0].double()
+        ph = used.mean(0).cpu(); tot = float(ph.sum())
+        print(f"{name}: {used.shape[0]} workgroups, cycles per step (head phases: per 2-step pass) -- fwd+bwd launch pair {ms:.3f} ms")
+        for i, n in enumerate(names):
+            div = per if not n.startswith("head") else per / 2
+            print(f"  {n:34s} {float(ph[i]) / div:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+        print(f"  total cycles/WG {tot:.0f}")
+    sys.exit(0)
 if which == "rollout":
     used = prof[(prof.sum(1) > 0)]
     ph = used.double().mean(0).cpu(); tot = float(ph.sum())

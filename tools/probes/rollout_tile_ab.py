@@ -35,7 +35,7 @@ def run(E, A, T, tile, reps=0):
     return out, ms
 
 
-for (E, A, T) in [(37, 8, 12), (50, 3, 9), (10, 5, 6), (512, 8, 128)]:
+for (E, A, T) in ([] if os.environ.get("RO16_ONLY_TIME") else [(37, 8, 12), (50, 3, 9), (10, 5, 6), (512, 8, 128)]):
     a, _ = run(E, A, T, 64)
     b, _ = run(E, A, T, 16)
     same = {k: bool(torch.equal(a[k], b[k])) for k in a}
