@@ -90,8 +90,8 @@ class Args:
     """ [build] number of actions of --env_type=synthetic_shape (action 0 is always available)"""
     synthetic_avail_p: float = 0.7
     """ [build] availability probability of the other actions of --env_type=synthetic_shape"""
-    vector_env: str = "shm"
-    """ [build] host-env vectorisation: shm (shared-memory, batched step per worker) or pipe (the reference's one process + Pipe per env)"""
+    vector_env: str = "pinned"
+    """ [build] host-env vectorisation: pinned (shared-memory workers whose blocks are page-locked and copied straight into the device rollout buffer), shm (the same workers, host-side collation) or pipe (the reference's one process + Pipe per env)"""
     env_workers: int = 0
     """ [build] worker processes of the shm vector env (0 = one per host core, at most one per env)"""
     checkpoint: str = ""
@@ -182,7 +182,7 @@ class ComaArgs:
     synthetic_state: int = 243
     synthetic_actions: int = 17
     synthetic_avail_p: float = 0.7
-    vector_env: str = "shm"
+    vector_env: str = "pinned"
     env_workers: int = 0
     checkpoint: str = ""
     checkpoint_every: int = 0

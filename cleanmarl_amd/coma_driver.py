@@ -66,7 +66,7 @@ def run(script, argv=None):
     learner = COMALearner(actor_spec, critic_spec, A, COMAHParams.from_args(args), device, a_init, c_init, pg, world)
 
     device_env = args.env_type in ("synthetic", "synthetic_shape")
-    venv = roll = the_env = None
+    venv = roll = the_env = pinned = None
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
@@ -80,6 +80,9 @@ def run(script, argv=None):
         venv = PipeVectorEnv(E, dict(fac, synthetic=synth), index_offset=env_offset)
     else:
         venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None, index_offset=env_offset)
+        if args.vector_env == "pinned":  # default: the workers' shared blocks are page-locked and copied straight into the device buffer
+            from .host_rollout import PinnedHostRollout
+            pinned = PinnedHostRollout(venv, learner, False, device, row_offset=env_offset * A)
     host_actor = HostActor(learner, A, False, device, row_offset=env_offset * A)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
@@ -115,8 +118,11 @@ def run(script, argv=None):
         elif single_env:
             b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, False, device, explore=epsilon)
         else:
-            collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
-            b, stats = collect(venv, host_actor, E, A, args.seed + training_step, False, device, explore=epsilon)
+            if pinned is not None:
+                b, stats = pinned.collect(args.seed + training_step, eps=epsilon)
+            else:
+                collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
+                b, stats = collect(venv, host_actor, E, A, args.seed + training_step, False, device, explore=epsilon)
         n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
         if world > 1:
             torch.distributed.all_reduce(n_steps, group=pg)
@@ -176,6 +182,8 @@ def run(script, argv=None):
         import wandb
         wandb.finish()
     eval_env.close()
+    if pinned is not None:
+        pinned.close()
     if venv:
         venv.close()
     if the_env is not None:

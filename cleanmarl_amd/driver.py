@@ -213,7 +213,7 @@ def run(script, argv=None):
         learner = PPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
 
     device_env = args.env_type in ("synthetic", "synthetic_shape")
-    venv = roll = the_env = None
+    venv = roll = the_env = pinned = None
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
@@ -232,6 +232,9 @@ def run(script, argv=None):
         venv = PipeVectorEnv(E, dict(fac, synthetic=synth), index_offset=env_offset)
     else:
         venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None, index_offset=env_offset)
+        if args.vector_env == "pinned":  # default: the workers' shared blocks are page-locked and copied straight into the device buffer
+            from .host_rollout import PinnedHostRollout
+            pinned = PinnedHostRollout(venv, learner, recurrent, device, row_offset=env_offset * A)
     host_actor = HostActor(learner, A, recurrent, device, row_offset=env_offset * A)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
@@ -270,8 +273,11 @@ def run(script, argv=None):
         elif single_env:
             b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, recurrent, device)
         else:
-            collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
-            b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
+            if pinned is not None:
+                b, stats = pinned.collect(args.seed + training_step)
+            else:
+                collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
+                b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
         n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
         if world > 1:
             torch.distributed.all_reduce(n_steps, group=pg)
@@ -334,6 +340,8 @@ def run(script, argv=None):
         import wandb
         wandb.finish()
     eval_env.close()
+    if pinned is not None:
+        pinned.close()
     if venv:
         venv.close()
     if the_env is not None:

@@ -98,7 +98,7 @@ def test_checkpoint_resume_is_bit_exact(tmp_path, monkeypatch):
     assert torch.equal(res["learner"].opt_a.v, full["learner"].opt_a.v)
 
 
-@pytest.mark.parametrize("vector_env", ["pipe", "shm"])
+@pytest.mark.parametrize("vector_env", ["pipe", "shm", "pinned"])
 def test_config1_pz_simple_spread_end_to_end(vector_env, tmp_path, monkeypatch):
     """BASELINE.json configs[0] verbatim -- `mappo_multienvs.py --env_type=pz --env_family=mpe --env_name=simple_spread_v3`, 4 envs --
     through the PettingZoo adapter (stand-in package, tests/stub_envs.py: pettingzoo is not installable here), the vector env, the
@@ -132,3 +132,75 @@ def test_smaclite_adapter_end_to_end(tmp_path, monkeypatch):
     assert TAGS <= tags and {"rollout/battle_won", "eval/battle_won", "rollout/ep_length"} <= tags
     assert all(math.isfinite(v) for _, v, _ in out["history"])
     assert [v for t, v, _ in out["history"] if t == "rollout/ep_length"][0] == 150.0  # TimeLimit(150)
+
+
+def _host_learner(A, Do, Ds, K, recurrent, dev):
+    import torch
+    from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner
+    from cleanmarl_amd.gru import GRUPPOLearner
+    torch.manual_seed(4)
+    aspec = NetSpec(Do, 64, 0 if recurrent else 1, K, "gru" if recurrent else "mlp")
+    cspec = NetSpec(Ds, 64, 1, 1)
+    return (GRUPPOLearner if recurrent else PPOLearner)("mappo", aspec, cspec, A, HParams(), dev)
+
+
+@pytest.mark.parametrize("recurrent", [False, True])
+def test_pinned_host_rollout_equals_host_collated_path(recurrent):
+    """env workers' shared blocks page-locked, steps copied straight into the device rollout buffer and sampled
+    there in place (cleanmarl_amd/host_rollout.py) == the host-collated shared-memory path (driver.host_rollout_shm), bit for bit:
+    same envs, same actor, same Philox keys (all envs alive => same row indices)."""
+    import torch
+    from cleanmarl_amd.driver import HostActor, host_rollout_shm
+    from cleanmarl_amd.env.shm_vector import ShmVectorEnv
+    from cleanmarl_amd.host_rollout import PinnedHostRollout
+    dev = torch.device("cuda:0")
+    E, A, T = 12, 3, 9
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=5, synthetic=dict(agents=A, steps=T))
+    L = _host_learner(A, 7 * A, 6 * A * A, 5, recurrent, dev)
+    v1 = ShmVectorEnv(E, fac, n_workers=3)
+    b1, s1 = host_rollout_shm(v1, HostActor(L, A, recurrent, dev, row_offset=7), E, A, 11, recurrent, dev)
+    v1.close()
+    v2 = ShmVectorEnv(E, fac, n_workers=3)
+    pr = PinnedHostRollout(v2, L, recurrent, dev, row_offset=7, t_cap=4)  # t_cap 4 < T: the buffer grows twice
+    b2, s2 = pr.collect(11)
+    b3, s3 = pr.collect(12)  # a second episode through the same pinned blocks (other seed => other actions)
+    pr.close(); v2.close()
+    torch.cuda.synchronize()
+    for k in ("obs", "state", "avail", "action", "logp", "reward", "ep_len"):
+        assert torch.equal(getattr(b1, k), getattr(b2, k)), k
+    assert s1["ep_len"] == s2["ep_len"] == [T] * E and s1["ep_reward"] == pytest.approx(s2["ep_reward"], abs=1e-5)
+    assert b3.obs.shape == b2.obs.shape and b3.ep_len.tolist() == [T] * E and not torch.equal(b3.action, b2.action)
+
+
+def test_pinned_host_rollout_ragged_episodes_replay():
+    """Episodes of different lengths: the device-built batch is zero beyond each episode's end and, replayed on the CPU twin of the
+    env with the recorded actions, reproduces every observation, state and reward."""
+    import numpy as np
+    import torch
+    from cleanmarl_amd.env.shm_vector import ShmVectorEnv
+    from cleanmarl_amd.env.synthetic import SyntheticSpreadEnv
+    from cleanmarl_amd.host_rollout import PinnedHostRollout
+    dev = torch.device("cuda:0")
+    E, A, T = 10, 2, 11
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=3,
+               synthetic=dict(agents=A, steps=T, ragged=True))
+    L = _host_learner(A, 7 * A, 6 * A * A, 5, False, dev)
+    v = ShmVectorEnv(E, fac, n_workers=4, index_offset=20)
+    pr = PinnedHostRollout(v, L, False, dev, row_offset=20 * A)
+    b, st = pr.collect(1)
+    pr.close(); v.close()
+    torch.cuda.synchronize()
+    assert b.T == T and st["ep_len"] == [max(1, T - (20 + e) % 4) for e in range(E)] and b.ep_len.tolist() == st["ep_len"]
+    for e in range(E):
+        n = st["ep_len"][e]
+        env = SyntheticSpreadEnv(A, True, max_cycles=n, seed=3, env_index=20 + e)
+        o, _ = env.reset()
+        for t in range(n):
+            assert np.allclose(b.obs[e, :, t].cpu().numpy(), o) and np.allclose(b.state[e, t].cpu().numpy(), env.get_state())
+            assert b.avail[e, :, t].all()
+            o, r, d, tr, _ = env.step(b.action[e, :, t].cpu().numpy())
+            assert abs(b.reward[e, t].item() - r) < 1e-5
+        assert d or tr
+        for k in ("obs", "avail", "action", "logp"):
+            assert not getattr(b, k)[e, :, n:].any(), k
+        assert not b.state[e, n:].any() and not b.reward[e, n:].any()
