@@ -27,6 +27,13 @@ SIGNATURES = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (_i, []),
     "cm_mfma_mode": (_i, []),
+    "cm_mlp_forward_ld": (_i, [_p, _l, _l, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "cm_w0_image_bytes": (_sz, [_i, _i]),
+    "cm_policy_act_episode_ld": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p, _sz, _p]),
+    "cm_ppo_actor_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),
+    "cm_critic_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_rollout_spread_ld": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _l, _p, _l, _p, _p, _p, _p]),
+    "cm_shape_env_fill_ld": (_i, [_i, _i, _i, _i, _i, _i, _i, _d, _u64, _l, _l, _p, _l, _p, _l, _p, _p]),
     "cm_stream_create_low_priority": (_p, []),
     "cm_stream_destroy": (_i, [_p]),
     "cm_mlp_param_count": (_l, [_i, _i, _i, _i]),

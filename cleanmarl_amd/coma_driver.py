@@ -70,10 +70,10 @@ def run(script, argv=None):
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
-                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset)
+                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset, pad=False)
     elif device_env:
         roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
-                                      env_offset=env_offset)
+                                      env_offset=env_offset, pad=False)  # COMA's kernels read contiguous rows
     elif single_env:
         the_env = environment(**dict(fac, index=env_offset))
     elif args.vector_env == "pipe":
@@ -82,7 +82,7 @@ def run(script, argv=None):
         venv = ShmVectorEnv(E, dict(fac, synthetic=synth), n_workers=args.env_workers or None, index_offset=env_offset)
         if args.vector_env == "pinned":  # default: the workers' shared blocks are page-locked and copied straight into the device buffer
             from .host_rollout import PinnedHostRollout
-            pinned = PinnedHostRollout(venv, learner, False, device, row_offset=env_offset * A)
+            pinned = PinnedHostRollout(venv, learner, False, device, row_offset=env_offset * A, pad=False)
     host_actor = HostActor(learner, A, False, device, row_offset=env_offset * A)
 
     time_token = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")

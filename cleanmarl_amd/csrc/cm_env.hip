@@ -125,7 +125,8 @@ __device__ __forceinline__ float normal01(uint32_t a, uint32_t b) {  // Box-Mull
 
 __global__ __launch_bounds__(256) void k_shape_fill(int E, int A, int T, int obs_raw, int agent_ids, int Ds, int K, float avail_p,
                                                     unsigned long long seed, long env_offset, long episode,
-                                                    float* __restrict__ obs, float* __restrict__ state, uint8_t* __restrict__ avail) {
+                                                    float* __restrict__ obs, float* __restrict__ state, uint8_t* __restrict__ avail,
+                                                    long obs_ld, long state_ld) {
     const int Do = obs_raw + (agent_ids ? A : 0);
     const long n_obs = (long)E * A * T * Do, n_state = (long)E * T * Ds, n_av = (long)E * A * T * K;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -138,12 +139,12 @@ __global__ __launch_bounds__(256) void k_shape_fill(int E, int A, int T, int obs
                 const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)(t * A + ag), 0x100u + (uint32_t)f, k0, k1);
                 v = normal01(w.x, w.y);
             } else v = (f - obs_raw == ag) ? 1.0f : 0.0f;
-            obs[i] = v;
+            obs[r * obs_ld + f] = v;  // r = (env, agent, t) row; padding columns beyond Do stay untouched (zero)
         } else if (i < n_obs + n_state) {
             const long j = i - n_obs; const int f = (int)(j % Ds); const long r = j / Ds; const int t = (int)(r % T);
             const unsigned long long ge = (unsigned long long)(env_offset + r / T);
             const cm_u4 w = cm_philox4x32((uint32_t)ge, (uint32_t)episode, (uint32_t)t, 0x40000000u + (uint32_t)f, k0, k1);
-            state[j] = normal01(w.x, w.y);
+            state[r * state_ld + f] = normal01(w.x, w.y);
         } else {
             const long j = i - n_obs - n_state; const int k = (int)(j % K); const long r = j / K; const int t = (int)(r % T);
             const long ea = r / T; const int ag = (int)(ea % A); const unsigned long long ge = (unsigned long long)(env_offset + ea / A);
@@ -169,14 +170,21 @@ __global__ __launch_bounds__(256) void k_shape_reward(int E, int A, int T, int K
 
 }  // namespace
 
+extern "C" int cm_shape_env_fill_ld(int E, int A, int T, int obs_raw, int agent_ids, int state_dim, int n_actions, double avail_p,
+                                    uint64_t seed, int64_t env_offset, int64_t episode, float* obs, int64_t obs_ld, float* state,
+                                    int64_t state_ld, uint8_t* avail, cm_stream_t stream) {
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_raw > 0 && state_dim > 0 && n_actions > 0, "cm_shape_env_fill: bad dims");
+    CM_REQUIRE(obs_ld >= obs_raw + (agent_ids ? A : 0) && state_ld >= state_dim, "cm_shape_env_fill: leading dimensions below the widths");
+    hipLaunchKernelGGL(k_shape_fill, dim3(2048), dim3(256), 0, (hipStream_t)stream, E, A, T, obs_raw, agent_ids, state_dim, n_actions,
+                       (float)avail_p, (unsigned long long)seed, (long)env_offset, (long)episode, obs, state, avail, (long)obs_ld, (long)state_ld);
+    CM_CHECK_LAUNCH("cm_shape_env_fill");
+    return 0;
+}
 extern "C" int cm_shape_env_fill(int E, int A, int T, int obs_raw, int agent_ids, int state_dim, int n_actions, double avail_p,
                                  uint64_t seed, int64_t env_offset, int64_t episode, float* obs, float* state, uint8_t* avail,
                                  cm_stream_t stream) {
-    CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_raw > 0 && state_dim > 0 && n_actions > 0, "cm_shape_env_fill: bad dims");
-    hipLaunchKernelGGL(k_shape_fill, dim3(2048), dim3(256), 0, (hipStream_t)stream, E, A, T, obs_raw, agent_ids, state_dim, n_actions,
-                       (float)avail_p, (unsigned long long)seed, (long)env_offset, (long)episode, obs, state, avail);
-    CM_CHECK_LAUNCH("cm_shape_env_fill");
-    return 0;
+    return cm_shape_env_fill_ld(E, A, T, obs_raw, agent_ids, state_dim, n_actions, avail_p, seed, env_offset, episode, obs,
+                                obs_raw + (agent_ids ? A : 0), state, state_dim, avail, stream);
 }
 
 extern "C" int cm_shape_env_reward(int E, int A, int T, int n_actions, uint64_t seed, int64_t env_offset, int64_t episode,

@@ -16,15 +16,15 @@ extern "C" size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int
     return train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
 }
 
-extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
-                                    const float* logp_old, const float* adv, const int32_t* ep_len,
+extern "C" int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                                       const float* logp_old, const float* adv, const int32_t* ep_len,
                                     int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                                     const float* params, double ppo_clip, double entropy_coef,
                                     float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
-    CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_ppo_actor_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
+    CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_ld >= din, "cm_ppo_actor_fwd_bwd: bad dims E=%d A=%d T=%d ld=%lld din=%d", E, A, T, (long long)obs_ld, din);
     if (wide_shape(hidden, n_hidden_layers)) {  // layered schedule (cm_mlp_wide.h)
         MlpArgs a = {};
-        a.x = obs; a.x_stride = din; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+        a.x = obs; a.x_stride = obs_ld; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
         a.params = params; a.avail = avail; a.avail_stride = n_actions;
         a.action = action; a.logp_old = logp_old; a.adv = adv; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
         a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip;
@@ -36,12 +36,13 @@ extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, cons
     CM_REQUIRE(ws && ws_bytes >= need, "cm_ppo_actor_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     const int64_t P = cm_mlp_param_count(din, hidden, n_hidden_layers, n_actions);
     MlpArgs a = {};
-    a.x = obs; a.x_stride = din; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.x = obs; a.x_stride = obs_ld; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.avail = avail; a.avail_stride = n_actions;
     a.action = action; a.logp_old = logp_old; a.adv = adv; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
     a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip;
     a.ent_coef = (float)entropy_coef;
     a.partial = (float*)ws; a.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
+    prep_w0_image(a, train_w0_scratch(ws, P), w0_image_floats(a.din, a.H), (hipStream_t)stream);
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
@@ -52,3 +53,11 @@ extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, cons
     return finish_train(a, grid, P, grad_and_stats, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");
 }
 
+extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
+                                    const float* logp_old, const float* adv, const int32_t* ep_len,
+                                    int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                                    const float* params, double ppo_clip, double entropy_coef,
+                                    float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    return cm_ppo_actor_fwd_bwd_ld(obs, din, avail, action, logp_old, adv, ep_len, E, A, T, din, hidden, n_hidden_layers, n_actions, params, ppo_clip,
+                                   entropy_coef, grad_and_stats, ws, ws_bytes, stream);
+}

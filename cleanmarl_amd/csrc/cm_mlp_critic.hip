@@ -7,19 +7,26 @@ extern "C" size_t cm_critic_workspace_bytes(int E, int A, int T, int per_agent, 
     return split_ws_bytes(rows, din, hidden, n_hidden_layers, 1);
 }
 
-extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,
-                                 int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
-                                 const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
-                                 cm_stream_t stream) {
+extern "C" int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
+                                    int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                                    const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                    cm_stream_t stream) {
+    CM_REQUIRE(x_ld >= din, "cm_critic_fwd_bwd: leading dimension %lld < din %d", (long long)x_ld, din);
     const bool wide = wide_shape(hidden, n_hidden_layers);  // layered schedule (cm_mlp_wide.h)
     if (!wide) if (int rc = check_shapes("cm_critic_fwd_bwd", din, hidden, n_hidden_layers, 1)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_critic_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
     const long rows = per_agent ? (long)E * A * T : (long)E * T;
     if (int rc = check_rows("cm_critic_fwd_bwd", rows)) return rc;
     MlpArgs a = {};
-    a.x = x; a.x_stride = din; a.rows = rows;
+    a.x = x; a.x_stride = x_ld; a.rows = rows;
     a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = 1;
     a.params = params; a.ret = ret; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = per_agent ? 1 : 0;
     if (wide) return wide_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
     return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
+}
+extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,
+                                 int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                                 const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                 cm_stream_t stream) {
+    return cm_critic_fwd_bwd_ld(x, din, ret, ep_len, E, A, T, per_agent, din, hidden, n_hidden_layers, params, grad_and_stats, ws, ws_bytes, stream);
 }

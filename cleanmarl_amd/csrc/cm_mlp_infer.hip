@@ -1,33 +1,47 @@
 // cm_mlp_infer.hip -- C-ABI entry points of the forward-only MLP kernels (a3/a4/a5)
 #include "cm_mlp_wide.h"
 
-extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
-                              const float* params, const uint8_t* avail, float* y, cm_stream_t stream) {
+static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                          const float* params, const uint8_t* avail, float* y, cm_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
     if (int rc = check_shapes("cm_mlp_forward", din, hidden, n_hidden_layers, dout)) return rc;
+    CM_REQUIRE(x_ld >= din, "cm_mlp_forward: leading dimension %lld < din %d", (long long)x_ld, din);
     if (rows <= 0) return 0;
     MlpArgs a = {};
-    a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
+    a.x = x; a.x_stride = x_ld; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
+    prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);  // no workspace: W0 chunks on 4-byte loads where unaligned
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_mlp_forward");
     return 0;
 }
+extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                              const float* params, const uint8_t* avail, float* y, cm_stream_t stream) {
+    return mlp_forward_ld(x, din, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream);
+}
 
 /* cm_mlp_forward with a caller workspace: also covers the shapes of the layered schedule (hidden 65..256, any depth), whose
  * activations live in the workspace.  cm_mlp_forward_workspace_bytes is 0 for shapes the fused kernel covers. */
 extern "C" size_t cm_mlp_forward_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout) {
-    return wide_shape(hidden, n_hidden_layers) ? wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, false) : 0;
+    return wide_shape(hidden, n_hidden_layers) ? wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, false)
+                                              : w0_image_floats(din, hidden) * sizeof(float);  // optional: the padded W0 image of the _ld form
 }
+/* bytes of the optional scratch of the *_ld inference entry points (padded W0 image; 0 when W0 is not streamed or its rows are aligned) */
+extern "C" size_t cm_w0_image_bytes(int din, int hidden) { return w0_image_floats(din, hidden) * sizeof(float); }
 
-extern "C" int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+extern "C" int cm_mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                                  const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
-    if (!wide_shape(hidden, n_hidden_layers)) return cm_mlp_forward(x, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream);
+    if (!wide_shape(hidden, n_hidden_layers)) return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream, ws, ws_bytes);
+    CM_REQUIRE(x_ld >= din, "cm_mlp_forward_ld: leading dimension %lld < din %d", (long long)x_ld, din);
     if (rows <= 0) return 0;
     MlpArgs a = {};
-    a.x = x; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
+    a.x = x; a.x_stride = x_ld; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
     return wide_forward(a, ws, ws_bytes, (hipStream_t)stream, "cm_mlp_forward_ws");
+}
+extern "C" int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                                 const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    return cm_mlp_forward_ld(x, din, rows, din, hidden, n_hidden_layers, dout, params, avail, y, ws, ws_bytes, stream);
 }
 
 extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
@@ -113,19 +127,25 @@ extern "C" int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint
 /* Act for EVERY step of an episode in one launch when the observations do not depend on the actions (e.g. the shape
  * env): x is [n_seq][T][din] contiguous, avail [n_seq][T][K]; row (s, t) draws Philox(seed, row_offset + s, t), i.e.
  * exactly what T calls of cm_policy_act with t = 0..T-1 draw.  Outputs action / logp [n_seq][T]. */
-extern "C" int cm_policy_act_episode(const float* x, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
-                                     int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
-                                     int32_t* action, float* logp, cm_stream_t stream) {
+extern "C" int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
+                                        int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
+                                        int32_t* action, float* logp, void* ws, size_t ws_bytes, cm_stream_t stream) {
     if (int rc = check_shapes("cm_policy_act_episode", din, hidden, n_hidden_layers, n_actions)) return rc;
-    CM_REQUIRE(T > 0, "cm_policy_act_episode: T=%d", T);
+    CM_REQUIRE(T > 0 && x_ld >= din, "cm_policy_act_episode: T=%d ld=%lld din=%d", T, (long long)x_ld, din);
     if (n_seq <= 0) return 0;
     if (int rc = check_rows("cm_policy_act_episode", n_seq * T)) return rc;
     MlpArgs a = {};
-    a.x = x; a.x_stride = din; a.rows = n_seq * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.x = x; a.x_stride = x_ld; a.rows = n_seq * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.avail = avail; a.avail_stride = n_actions;
     a.seed = seed; a.row_offset = row_offset; a.t = 0; a.t_decode = T; a.action_out = action; a.logp_out = logp; a.out_stride = 1;
+    prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     launch_infer<M_ACT>(a, grid_for(a.rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_episode");
     return 0;
+}
+extern "C" int cm_policy_act_episode(const float* x, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
+                                     int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
+                                     int32_t* action, float* logp, cm_stream_t stream) {
+    return cm_policy_act_episode_ld(x, din, avail, n_seq, T, din, hidden, n_hidden_layers, n_actions, params, seed, row_offset, action, logp, nullptr, 0, stream);
 }

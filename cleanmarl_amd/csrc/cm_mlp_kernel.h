@@ -63,6 +63,10 @@ struct MlpArgs {
     float* dz0;  // training kernels instantiated with NCH == 0: layer-0 pre-activation gradient [rows][HP] goes to HBM
                  // and the layer-0 weight gradient is computed by the streaming kernel k_dw0_stream instead
     unsigned long long* prof;  // CM_PHASE_PROF builds only: [grid][16] cycle counters
+    // zero-padded image of W0 with a leading dimension that is a multiple of 4 floats ([H][w0_ld], built per call by prep_w0_image):
+    // set when W0 is STREAMED (din > 64) and its rows are not 16-byte aligned (din % 4 != 0) while the input's rows are (*_ld entry
+    // points) -- the streamed chunks then come from this image on 16-byte loads instead of 16 4-byte loads per thread and tile
+    const float* w0p; int w0_ld;
 };
 
 struct Offsets {
@@ -430,7 +434,8 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
 // per-row inputs of the loss heads, fetched at the top of a tile so their HBM latency hides under the MFMA phases
 template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
 
-template <int NCH, int MODE, bool VEC, int LCAP, int KJ, bool BF = false>
+// VEC: 0 = 4-byte tile loads; 1 = 16-byte loads of the input rows and of streamed W0 chunks (can_vec)
+template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false>
 __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool TRAIN = (MODE >= M_ACTOR);
@@ -444,6 +449,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // compile-time for the training instantiations so the streaming paths (and their registers) vanish
     const bool w0_resident = (NCH > 0) ? (NCH == 1) : (nch == 1);
     const bool ws_resident = (LCAP == 1) || (L == 1);
+    const float* W0g = a.w0p ? a.w0p : a.params + off.W0;  // streamed W0 chunks (see MlpArgs::w0p); the LDS-resident form reads params
+    const int w0ld = a.w0p ? a.w0_ld : din;
     float* Xs = smem + lds.Xs;
     float* W0s = smem + lds.W0s;
     float* Ws = smem + lds.Ws;
@@ -500,8 +507,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     Tile16 pn;  // NCH == 1 training kernels: the NEXT tile's X, requested mid-tile (px is busy holding this tile's X for dW0)
     constexpr bool EARLY_NEXT = TRAIN && NCH == 1;
     if ((long)blockIdx.x < ntiles) {
-        tile_load<VEC>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
-        if (!w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
+        tile_load<(VEC != 0)>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
+        if (!w0_resident) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
     }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -530,8 +537,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         const bool rvalid = grow < (int)a.rows;
         for (int c = 0; c < nch; ++c) {
             __syncthreads();  // previous readers of Xs / W0s are done
-            tile_store<VEC, BF>(Xs, px);
-            if (!w0_resident) tile_store<VEC, BF>(W0s, pw);
+            tile_store<(VEC != 0), BF>(Xs, px);
+            if (!w0_resident) tile_store<(VEC == 1), BF>(W0s, pw);
             if (c == 0) {
                 // per-row head inputs: issued here, BEFORE the tile prefetch below (the compiler turns them into booleans right
                 // after the layer-0 loop; vmcnt waits are in issue order, so behind the prefetch they would drag it along)
@@ -562,8 +569,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 const bool again = TRAIN && NCH > 0 && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
                 const long r0n = last ? (again ? row0 : next_row0) : row0;
                 const int wn_ = min(KC, din - cn * KC);
-                tile_load<VEC>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
-                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, cn * KC, wn_);
+                tile_load<(VEC != 0)>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
+                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, cn * KC, wn_);
             }
             __syncthreads();
             PH(0);
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
         }
         PH(2);
-        if (EARLY_NEXT && L >= 1) tile_load<VEC>(pn, a.x, next_row0, a.rows, a.x_stride, 0, min(KC, din));
+        if (EARLY_NEXT && L >= 1) tile_load<(VEC != 0)>(pn, a.x, next_row0, a.rows, a.x_stride, 0, min(KC, din));
         // ================= head forward: 16x16x4 MFMA, wave w owns rows 16w..16w+15 (= the rows of its quad lanes) ====
         float* HL = smem + lds.Hs(L);
         {
@@ -915,12 +922,12 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 for (int c = 0; c < (NCH > 0 ? NCH : 0); ++c) {
                     if (NCH > 1 || L >= 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
                         __syncthreads();
-                        tile_store<VEC, BF>(Xs, px);
+                        tile_store<(VEC != 0), BF>(Xs, px);
                         const bool last = (c + 1 == NCH);
                         const int cn = last ? 0 : c + 1;
                         if (EARLY_NEXT) px = pn;  // already in flight since the head phase
-                        else tile_load<VEC>(px, a.x, last ? next_row0 : row0, a.rows, a.x_stride, cn * KC, min(KC, din - cn * KC));
-                        if (last && !w0_resident) tile_load<VEC>(pw, a.params + off.W0, 0, H, din, 0, min(KC, din));
+                        else tile_load<(VEC != 0)>(px, a.x, last ? next_row0 : row0, a.rows, a.x_stride, cn * KC, min(KC, din - cn * KC));
+                        if (last && !w0_resident) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
                         __syncthreads();
                     }
                     if (BF) colred_bf(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
@@ -1053,13 +1060,33 @@ inline int grid_for(long rows, int nch = 0) {
     return (int)(nt < cap ? nt : cap);
 }
 
-// 16-byte loads need 16-byte aligned rows of both the activations and W0 (row stride din)
+// 16-byte tile loads need 16-byte aligned rows of the input (leading dimension a multiple of 4 floats, >= din rounded up: the quad that
+// straddles din reads zero padding) AND of W0 wherever W0 is tile-loaded, i.e. streamed: its own rows when din % 4 == 0, else the
+// padded image of prep_w0_image; a single-chunk input (din <= 64) keeps W0 in LDS and never tile-loads it.
+inline bool x_rows_vec(const MlpArgs& a) {
+    return (a.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && a.x_stride >= (a.din + 3) / 4 * 4;
+}
 inline bool can_vec(const MlpArgs& a) {
-    return (a.din % 4 == 0) && (a.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
-           ((reinterpret_cast<uintptr_t>(a.params) & 15) == 0);
+    const bool w_ok = (a.din % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.params) & 15) == 0);
+    return x_rows_vec(a) && (w_ok || (a.din + KC - 1) / KC == 1 || a.w0p != nullptr);
+}
+inline size_t w0_image_floats(int din, int H) { return (din % 4 != 0 && din > KC) ? (size_t)H * ((din + 3) / 4 * 4) : 0; }
+__global__ void k_pad_w0(const float* __restrict__ w0, int H, int din, int ld, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H * ld) { const int n = i / ld, k = i - n * ld; out[i] = (k < din) ? w0[n * din + k] : 0.0f; }
+}
+// builds the image into `scratch` (>= w0_image_floats floats, 16-byte aligned) when it pays; otherwise leaves a.w0p = NULL
+inline void prep_w0_image(MlpArgs& a, float* scratch, size_t scratch_floats, hipStream_t s) {
+    a.w0p = nullptr; a.w0_ld = 0;
+    const size_t need = w0_image_floats(a.din, a.H);
+    if (!need || !x_rows_vec(a) || !scratch || scratch_floats < need || (reinterpret_cast<uintptr_t>(scratch) & 15)) return;
+    const int ld = (a.din + 3) / 4 * 4;
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
+    hipLaunchKernelGGL(k_pad_w0, dim3((a.H * ld + 255) / 256), dim3(256), 0, s, a.params + off.W0, a.H, a.din, ld, scratch);
+    a.w0p = scratch; a.w0_ld = ld;
 }
 
-template <int NCH, int MODE, bool VEC, int LCAP, int KJ, bool BF = false>
+template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false>
 inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
 #ifdef CM_PHASE_PROF
     // profiling build only (tools/phase_prof.py): CM_PROF_ONE_WG=1 pads LDS so that ONE workgroup fits a CU and halves the grid --
@@ -1081,14 +1108,14 @@ template <int NCH, int MODE>
 inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
     const bool vec = can_vec(a), l1 = a.L <= 1, k8 = a.dout <= 8;
     if constexpr ((MODE == M_ACTOR || MODE == M_CRITIC) && NCH <= 2) {
-        if (vec && l1 && k8 && mfma_bf16x3()) { launch_one<NCH, MODE, true, 1, 2, true>(a, grid, lds_bytes, s); return; }
+        if (vec && l1 && k8 && mfma_bf16x3()) { launch_one<NCH, MODE, 1, 1, 2, true>(a, grid, lds_bytes, s); return; }
     }
     if (vec) {
-        if (l1) { if (k8) launch_one<NCH, MODE, true, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 1, 8>(a, grid, lds_bytes, s); }
-        else    { if (k8) launch_one<NCH, MODE, true, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, true, 2, 8>(a, grid, lds_bytes, s); }
+        if (l1) { if (k8) launch_one<NCH, MODE, 1, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, 1, 1, 8>(a, grid, lds_bytes, s); }
+        else    { if (k8) launch_one<NCH, MODE, 1, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, 1, 2, 8>(a, grid, lds_bytes, s); }
     } else {
-        if (l1) { if (k8) launch_one<NCH, MODE, false, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, false, 1, 8>(a, grid, lds_bytes, s); }
-        else    { if (k8) launch_one<NCH, MODE, false, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, false, 2, 8>(a, grid, lds_bytes, s); }
+        if (l1) { if (k8) launch_one<NCH, MODE, 0, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, 0, 1, 8>(a, grid, lds_bytes, s); }
+        else    { if (k8) launch_one<NCH, MODE, 0, 2, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, 0, 2, 8>(a, grid, lds_bytes, s); }
     }
 }
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restr
                                                             long rows, int din, int H, long rows_per_wg,
                                                             float* __restrict__ partial, int PS2, int col0,
                                                             int ldz_ = HP, long ldx_ = 0) {
-    const long ldz = GEN ? ldz_ : HP, ldx = GEN ? ldx_ : din;
+    const long ldz = GEN ? ldz_ : HP, ldx = ldx_ ? ldx_ : din;  // ldx_: leading dimension of X when its rows are padded (*_ld entry points)
     const bool two = GEN ? (H > 32) : true;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const long row_lo = (long)blockIdx.x * rows_per_wg;
@@ -123,6 +123,7 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
     CM_REQUIRE(ws && ws_bytes >= need, "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     const int64_t P = cm_mlp_param_count(a.din, a.H, a.L, a.dout);
     a.partial = (float*)ws; a.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
+    prep_w0_image(a, train_w0_scratch(ws, P), w0_image_floats(a.din, a.H), s);
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
@@ -135,7 +136,7 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
         return finish_train(a, grid, P, grad_and_stats, s, who);
     }
     // ---- split schedule: fused kernel without dW0 (two workgroups per CU) ...
-    float* own = (float*)ws + (size_t)MAX_GRID * a.PS;
+    float* own = (float*)ws + (size_t)MAX_GRID * a.PS + w0_image_floats(a.din, a.H);
     if (!a.dz0) a.dz0 = own;  // the caller may want dZ0 for its own use (COMA's factored critic input)
     float* part2 = own + (size_t)a.rows * HP;
     const int grid = grid_for(a.rows, 0);
@@ -143,7 +144,7 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
     CM_CHECK_LAUNCH(who);
     if (int rc = finish_train(a, grid, P, grad_and_stats, s, who, a.H * a.din)) return rc;  // all but W0
     // ---- ... then the streaming layer-0 weight gradient
-    return stream_dw(a.dz0, a.x, a.rows, a.din, a.H, part2, grad_and_stats, s, who);
+    return stream_dw(a.dz0, a.x, a.rows, a.din, a.H, part2, grad_and_stats, s, who, HP, a.x_stride);
 }
 
 }  // namespace

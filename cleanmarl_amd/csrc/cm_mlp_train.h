@@ -9,8 +9,9 @@ extern unsigned long long* g_prof;
 inline size_t train_ws_bytes(int din, int hidden, int n_hidden_layers, int dout) {
     const int64_t P = cm_mlp_param_count(din, hidden, n_hidden_layers, dout);
     const size_t PS = (size_t)((P + CM_NUM_STATS + 63) / 64 * 64);
-    return (size_t)MAX_GRID * PS * sizeof(float);
+    return ((size_t)MAX_GRID * PS + w0_image_floats(din, hidden)) * sizeof(float);  // partial rows | padded W0 image (prep_w0_image)
 }
+inline float* train_w0_scratch(void* ws, int64_t P) { return (float*)ws + (size_t)MAX_GRID * (size_t)((P + CM_NUM_STATS + 63) / 64 * 64); }
 
 inline int finish_train(const MlpArgs& a, int grid, int64_t P, float* grad_and_stats, hipStream_t s, const char* who, int i0 = 0) {
     const int n = (int)(P + CM_NUM_STATS);

@@ -27,6 +27,7 @@ struct RolloutArgs {
     long env_offset, episode;
     const float* params; int din, H, L, K;
     float* obs; float* state; int* action; float* logp; float* reward;
+    long obs_ld, state_ld;  // leading dimensions of obs [E][A][T][obs_ld] / state [E][T][state_ld] (>= din / 6 A A; cm_rollout_spread_ld)
     unsigned long long* prof;
 };
 
@@ -71,7 +72,10 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     const int ntiles = (a.E + EPT - 1) / EPT;
     const int hrow = tid >> 2, hq = tid & 3;
     // 16-byte buffer stores need 4-float-aligned obs rows and state segments and <= 1024 / 768 quads per tile
-    const bool vecw = (din % 4 == 0) && ((6 * A) % 4 == 0) && (TM * (din >> 2) <= 4 * NTHREADS) && (TM * ((6 * A) >> 2) <= 3 * NTHREADS);
+    // (obs rows may be padded to a leading dimension that is a multiple of 4: the last quad then carries the tile's zero padding)
+    const int nq = (din + 3) >> 2, ns = (6 * A) >> 2;
+    const bool vo = (a.obs_ld % 4 == 0) && (4 * nq <= a.obs_ld) && (TM * nq <= 4 * NTHREADS);
+    const bool vs = ((6 * A) % 4 == 0) && (a.state_ld % 4 == 0) && (TM * ns <= 3 * NTHREADS);
     PH_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * EPT;
@@ -81,20 +85,19 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             const int el = tid / A, i = tid - el * A;
             const long e = e0 + el;
             const bool live = tid < RT && e < a.E;
-            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
-            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            obase[tid] = live ? (e * A + i) * (long)T * a.obs_ld : -1;
+            sbase[tid] = live ? e * (long)T * a.state_ld + (long)i * 6 * A : -1;
         }
         // 16-byte store slots of this thread: obs rows are din/4 quads wide, state segments 6A/4 quads (<= 4 / 3 slots)
         int oslot[4], sslot[3];
         {
-            const int nq = din >> 2, ns = (6 * A) >> 2;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = tid + NTHREADS * it;
                 const int r = idx / nq, c4 = idx - r * nq;
-                oslot[it] = (vecw && r < RT && e0 + r / A < a.E) ? ((r << 8) | c4) : -1;
-                const int r2 = idx / ns, c42 = idx - r2 * ns;
-                if (it < 3) sslot[it] = (vecw && r2 < RT && e0 + r2 / A < a.E) ? ((r2 << 8) | c42) : -1;
+                oslot[it] = (vo && r < RT && e0 + r / A < a.E) ? ((r << 8) | c4) : -1;
+                const int r2 = vs ? idx / ns : 0, c42 = idx - r2 * ns;
+                if (it < 3) sslot[it] = (vs && r2 < RT && e0 + r2 / A < a.E) ? ((r2 << 8) | c42) : -1;
             }
         }
         if (tid < RT) {
@@ -161,31 +164,38 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             __syncthreads();
             PH(1);
             // ---------------- rollout-buffer writes (coalesced along the feature axis)
-            if (vecw) {  // 16-byte stores: thread-private (row, quad-column) slots precomputed per tile
+            // 16-byte stores from thread-private (row, quad-column) slots precomputed per tile; otherwise 4-byte stores in a flat
+            // (row, column) enumeration: consecutive threads -> consecutive addresses of a row
+            if (vo) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
+                for (int it = 0; it < 4; ++it)
                     if (oslot[it] >= 0) {
                         const int r = oslot[it] >> 8, c4 = oslot[it] & 255;
-                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * din + 4 * c4) =
+                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * a.obs_ld + 4 * c4) =
                             *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
                     }
-                    if (it < 3 && sslot[it] >= 0) {
-                        const int r = sslot[it] >> 8, c4 = sslot[it] & 255;
-                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * Ds + 4 * c4) =
-                            *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
-                    }
-                }
-            } else {  // 4-byte stores, flat (row, column) enumeration: consecutive threads -> consecutive addresses of a row
-                const float inv_din = 1.0f / (float)din, inv_sw = 1.0f / (float)(6 * A);
+            } else {
+                const float inv_din = 1.0f / (float)din;
                 for (int idx = tid; idx < RT * din; idx += NTHREADS) {
                     const int r = (int)(((float)idx + 0.5f) * inv_din), c = idx - r * din;  // exact for idx < 2^22
                     const long ob = obase[r];
-                    if (ob >= 0) a.obs[ob + (long)t * din + c] = Xs[r * LDT + c];
+                    if (ob >= 0) a.obs[ob + (long)t * a.obs_ld + c] = Xs[r * LDT + c];
                 }
+            }
+            if (vs) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it)
+                    if (sslot[it] >= 0) {
+                        const int r = sslot[it] >> 8, c4 = sslot[it] & 255;
+                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * a.state_ld + 4 * c4) =
+                            *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                    }
+            } else {
+                const float inv_sw = 1.0f / (float)(6 * A);
                 for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
                     const int r = (int)(((float)idx + 0.5f) * inv_sw), c = idx - r * 6 * A;
                     const long sb = sbase[r];
-                    if (sb >= 0) a.state[sb + (long)t * Ds + c] = Xs[r * LDT + c];
+                    if (sb >= 0) a.state[sb + (long)t * a.state_ld + c] = Xs[r * LDT + c];
                 }
             }
             // team reward of step t-1 (its partials were produced in the obs phase from the post-physics positions)
@@ -410,7 +420,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
     const int ntiles = (a.E + EPT - 1) / EPT;
     const int orow = tid >> 4, oq = tid & 15;  // obs phase: 16 lanes per row
     const int srow = 4 * g16 + wave;           // sampling phase: lane group g of wave w owns row 4g + w
-    const bool vecw = (din % 4 == 0) && ((6 * A) % 4 == 0);
+    const int nq = (din + 3) >> 2, ns = (6 * A) >> 2;
+    const bool vo = (a.obs_ld % 4 == 0) && (4 * nq <= a.obs_ld);                 // TS x nq <= 256 quads: at most one per thread
+    const bool vs = ((6 * A) % 4 == 0) && (a.state_ld % 4 == 0);
     PH_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e0 = tile * EPT;
@@ -419,8 +431,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             const int el = tid / A, i = tid - el * A;
             const long e = e0 + el;
             const bool live = tid < RT && e < a.E;
-            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
-            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            obase[tid] = live ? (e * A + i) * (long)T * a.obs_ld : -1;
+            sbase[tid] = live ? e * (long)T * a.state_ld + (long)i * 6 * A : -1;
             if (live) {
                 const unsigned long long ge = (unsigned long long)(a.env_offset + e);
                 const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
@@ -495,29 +507,28 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
             __syncthreads();
             PH(1);
             // ---------------- rollout-buffer writes (coalesced along the feature axis)
-            if (RO16_ABL & 1) {
-            } else if (vecw) {  // <= 16 x 16 obs quads and <= 16 x 15 state quads: at most one of each per thread
-                const int nq = din >> 2, ns = (6 * A) >> 2;
-                {
+            if (!(RO16_ABL & 1)) {
+                if (vo) {  // <= 16 x 16 obs quads and <= 16 x 15 state quads: at most one of each per thread
                     const int r = tid / nq, c4 = tid - r * nq;
                     if (r < RT && obase[r] >= 0)
-                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * din + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                        *reinterpret_cast<float4*>(a.obs + obase[r] + (long)t * a.obs_ld + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                } else {
+                    for (int idx = tid; idx < RT * din; idx += NTHREADS) {
+                        const int r = idx / din, c = idx - r * din;
+                        const long ob = obase[r];
+                        if (ob >= 0) a.obs[ob + (long)t * a.obs_ld + c] = Xs[r * LDT + c];
+                    }
                 }
-                {
+                if (vs) {
                     const int r = tid / ns, c4 = tid - r * ns;
                     if (r < RT && sbase[r] >= 0)
-                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * Ds + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
-                }
-            } else {
-                for (int idx = tid; idx < RT * din; idx += NTHREADS) {
-                    const int r = idx / din, c = idx - r * din;
-                    const long ob = obase[r];
-                    if (ob >= 0) a.obs[ob + (long)t * din + c] = Xs[r * LDT + c];
-                }
-                for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
-                    const int r = idx / (6 * A), c = idx - r * 6 * A;
-                    const long sb = sbase[r];
-                    if (sb >= 0) a.state[sb + (long)t * Ds + c] = Xs[r * LDT + c];
+                        *reinterpret_cast<float4*>(a.state + sbase[r] + (long)t * a.state_ld + 4 * c4) = *reinterpret_cast<const float4*>(Xs + r * LDT + 4 * c4);
+                } else {
+                    for (int idx = tid; idx < RT * 6 * A; idx += NTHREADS) {
+                        const int r = idx / (6 * A), c = idx - r * 6 * A;
+                        const long sb = sbase[r];
+                        if (sb >= 0) a.state[sb + (long)t * a.state_ld + c] = Xs[r * LDT + c];
+                    }
                 }
             }
             if (t > 0 && !(RO16_ABL & 4)) reward_write(t - 1);
@@ -622,7 +633,8 @@ extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int
 
 static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
                           int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, float eps,
-                          float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+                          float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream,
+                          int64_t obs_ld = 0, int64_t state_ld = 0) {
     CM_REQUIRE(E > 0 && T > 0, "cm_rollout_spread: bad dims E=%d T=%d", E, T);
     CM_REQUIRE(cm_rollout_spread_supported(A, agent_ids, hidden, n_hidden_layers),
                "cm_rollout_spread: unsupported shape A=%d hidden=%d layers=%d (use cm_policy_act + cm_synth_env_step)", A, hidden, n_hidden_layers);
@@ -631,6 +643,8 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0);
     a.H = hidden; a.L = n_hidden_layers; a.K = 5;
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+    a.obs_ld = obs_ld ? obs_ld : a.din; a.state_ld = state_ld ? state_ld : 6 * A * A;
+    CM_REQUIRE(a.obs_ld >= a.din && a.state_ld >= 6 * A * A, "cm_rollout_spread: leading dimensions %ld / %ld below the widths %d / %d", a.obs_ld, a.state_ld, a.din, 6 * A * A);
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
@@ -676,4 +690,14 @@ extern "C" int cm_rollout_spread_eps(float* env_state, int E, int A, int T, int 
     CM_REQUIRE(eps >= 0.0 && eps <= 1.0, "cm_rollout_spread_eps: eps=%g outside [0, 1]", eps);
     return rollout_spread(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, n_hidden_layers, (float)eps,
                           obs, state, action, logp, reward, stream);
+}
+
+/* both of the above with explicit leading dimensions of the obs / state buffers (include/cleanmarl_hip.h, "_ld" variants) */
+extern "C" int cm_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                    int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, double eps,
+                                    float* obs, int64_t obs_ld, float* state, int64_t state_ld, int32_t* action, float* logp,
+                                    float* reward, cm_stream_t stream) {
+    CM_REQUIRE(eps >= 0.0 && eps <= 1.0, "cm_rollout_spread_ld: eps=%g outside [0, 1]", eps);
+    return rollout_spread(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, n_hidden_layers, (float)eps,
+                          obs, state, action, logp, reward, stream, obs_ld, state_ld);
 }

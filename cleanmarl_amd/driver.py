@@ -70,7 +70,7 @@ class HostActor:
         return action.cpu().numpy(), logp.cpu().numpy(), h
 
 
-def host_rollout(venv, actor, E, A, seed, recurrent, device, explore=0.0):
+def host_rollout(venv, actor, E, A, seed, recurrent, device, explore=0.0, pad=False):
     """One episode per env over the pipe protocol (cleanmarl/mappo_multienvs.py:393-453; GRU: hidden state
     carried for alive envs only, cleanmarl/mappo_lstm_multienvs.py:406-433).  Returns (DeviceBatch, stats)."""
     cont = venv.reset_all()
@@ -106,10 +106,10 @@ def host_rollout(venv, actor, E, A, seed, recurrent, device, explore=0.0):
         alive = still
         if alive:
             obs, state, avail = np.stack(nobs), np.stack(nstate), np.stack(navail)
-    return _collate(eps, ep_len, E, A, device), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
+    return _collate(eps, ep_len, E, A, device, pad), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
 
 
-def _collate(eps, ep_len, E, A, device):
+def _collate(eps, ep_len, E, A, device, pad=False):
     """Zero-pad the per-episode lists to the longest episode + build the mask (RolloutBuffer.get_batch, :109-142)."""
     T = max(ep_len)
     Do, Ds, K = eps[0]["obs"][0].shape[-1], eps[0]["state"][0].shape[-1], eps[0]["avail"][0].shape[-1]
@@ -122,10 +122,10 @@ def _collate(eps, ep_len, E, A, device):
         b_lp[j, :n] = np.stack(e["logp"]); b_rew[j, :n] = np.asarray(e["reward"], np.float32); b_st[j, :n] = np.stack(e["state"])
         b_mask[j, :n] = True
     t = torch.from_numpy
-    return DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device)
+    return DeviceBatch.from_reference_layout(t(b_obs), t(b_act), t(b_lp), t(b_rew), t(b_st), t(b_av), t(b_mask), device, pad=pad)
 
 
-def host_rollout_single(env, actor, E, A, seed, recurrent, device, explore=0.0):
+def host_rollout_single(env, actor, E, A, seed, recurrent, device, explore=0.0, pad=False):
     """The single-environment front-ends (cleanmarl/mappo.py:302-343, ippo.py, mappo_lstm.py, ippo_lstm.py): ``batch_size``
     episodes collected ONE AFTER THE OTHER from one in-process env (no worker processes); the GRU hidden state starts at
     zero with every episode (mappo_lstm.py:306-318).  Returns the same (DeviceBatch, stats) as the vectorised collectors."""
@@ -144,10 +144,10 @@ def host_rollout_single(env, actor, E, A, seed, recurrent, device, explore=0.0):
             tot += r; n += 1
             obs = nobs
         eps.append(e); ep_reward.append(tot); ep_len.append(n); ep_info.append(info)
-    return _collate(eps, ep_len, E, A, device), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
+    return _collate(eps, ep_len, E, A, device, pad), dict(ep_reward=ep_reward, ep_len=ep_len, infos=ep_info)
 
 
-def host_rollout_shm(venv, actor, E, A, seed, recurrent, device, explore=0.0):
+def host_rollout_shm(venv, actor, E, A, seed, recurrent, device, explore=0.0, pad=False):
     """Same episode collection through the shared-memory batched-step vector env: one token per
     WORKER per step instead of one pickled round trip per ENV.  Returns the same (DeviceBatch, stats)."""
     hstate = {"h": None}
@@ -168,7 +168,7 @@ def host_rollout_shm(venv, actor, E, A, seed, recurrent, device, explore=0.0):
     out, mask, stats = venv.collect_episode(act_fn)
     t = torch.from_numpy
     b = DeviceBatch.from_reference_layout(t(out["obs"]), t(out["act"]), t(out["logp"]), t(out["rew"]), t(out["state"]),
-                                          t(out["avail"]), t(mask), device)
+                                          t(out["avail"]), t(mask), device, pad=pad)
     return b, stats
 
 
@@ -217,7 +217,7 @@ def run(script, argv=None):
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
-                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset)
+                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset, pad=not recurrent)
     elif device_env:
         if recurrent:
             from .gru import GRUSyntheticRollout
@@ -271,13 +271,13 @@ def run(script, argv=None):
             rew = b.reward.sum(1).cpu().tolist()
             stats = dict(ep_reward=rew, ep_len=[b.T] * E, infos=[None] * E)
         elif single_env:
-            b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, recurrent, device)
+            b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, recurrent, device, pad=not recurrent)
         else:
             if pinned is not None:
                 b, stats = pinned.collect(args.seed + training_step)
             else:
                 collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
-                b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device)
+                b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device, pad=not recurrent)
         n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
         if world > 1:
             torch.distributed.all_reduce(n_steps, group=pg)

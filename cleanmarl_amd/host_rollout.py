@@ -37,7 +37,7 @@ def _unpin(arr):
 class PinnedHostRollout:
     """One episode per env from a `ShmVectorEnv`, written straight into a device-resident DeviceBatch."""
 
-    def __init__(self, venv, learner, recurrent, device, row_offset=0, t_cap=64):
+    def __init__(self, venv, learner, recurrent, device, row_offset=0, t_cap=64, pad=None):
         self.v, self.L, self.recurrent, self.dev = venv, learner, recurrent, device
         self.lib = N.load()
         self.E, self.A, self.Do, self.Ds, self.K = venv.E, venv.A, venv.Do, venv.Ds, venv.K
@@ -49,7 +49,9 @@ class PinnedHostRollout:
         self.h_obs, self.h_state = torch.from_numpy(a["obs"]), torch.from_numpy(a["state"])
         self.h_avail, self.h_act = torch.from_numpy(a["avail"]), torch.from_numpy(a["actions"])
         self.cap = int(t_cap)
-        self.buf = DeviceBatch(self.E, self.A, self.cap, self.Do, self.Ds, self.K, device)
+        # leading dimensions rounded up to 4 floats for the MLP learners' 16-byte tile loads; the GRU / COMA kernels read contiguous rows
+        self.pad = (not recurrent) if pad is None else bool(pad)
+        self.buf = DeviceBatch(self.E, self.A, self.cap, self.Do, self.Ds, self.K, device, pad_obs=self.pad, pad_state=self.pad)
         self.h = None
         self.ws = None
         self.calls = 0
@@ -63,7 +65,7 @@ class PinnedHostRollout:
     def _grow(self):
         old, T0 = self.buf, self.cap
         self.cap *= 2
-        b = DeviceBatch(self.E, self.A, self.cap, self.Do, self.Ds, self.K, self.dev)
+        b = DeviceBatch(self.E, self.A, self.cap, self.Do, self.Ds, self.K, self.dev, pad_obs=self.pad, pad_state=self.pad)
         b.obs[:, :, :T0] = old.obs; b.state[:, :T0] = old.state; b.avail[:, :, :T0] = old.avail
         b.action[:, :, :T0] = old.action; b.logp[:, :, :T0] = old.logp
         self.buf = b
@@ -75,14 +77,14 @@ class PinnedHostRollout:
         off = lambda ten, nbytes: N.C.c_void_p(ten.data_ptr() + nbytes)
         self.calls += 1
         if self.recurrent:
-            N.check(lib.cm_gru_policy_act(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, spec.din, spec.hidden, K,
+            N.check(lib.cm_gru_policy_act(off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, off(b.avail, t * K), T * K, E * A, spec.din, spec.hidden, K,
                                           N.ptr(self.L.actor), N.ptr(self.h), seed, self.row_offset, self.calls, off(b.action, 4 * t),
                                           off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
         else:
             need = lib.cm_policy_act_workspace_bytes(E * A, spec.din, spec.hidden, spec.n_layers, K)  # 0 unless layered
             if need and (self.ws is None or self.ws.numel() < need):
                 self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            N.check(lib.cm_policy_act_ws(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, spec.din, spec.hidden,
+            N.check(lib.cm_policy_act_ws(off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, off(b.avail, t * K), T * K, E * A, spec.din, spec.hidden,
                                          spec.n_layers, K, N.ptr(self.L.actor), float(eps), seed, self.row_offset, self.calls,
                                          off(b.action, 4 * t), off(b.logp, 4 * t), T, N.ptr(self.ws) if need else None, need, s),
                     "cm_policy_act_ws")
@@ -122,7 +124,7 @@ class PinnedHostRollout:
             alive = alive[a["alive"][alive] == 1]
             t += 1
         T = int(ep_len.max())
-        out = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.dev)
+        out = DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.dev, pad_obs=self.pad, pad_state=self.pad)
         b = self.buf
         ep = torch.from_numpy(ep_len).to(self.dev)
         m = (torch.arange(T, device=self.dev)[None, :] < ep[:, None])          # [E, T] valid steps

@@ -63,12 +63,18 @@ class DeviceBatch:
     """Rollout storage in the device layout of include/cleanmarl_hip.h (the [E,A,T,F] permutation of the
     reference's RolloutBuffer batch, cleanmarl/mappo_multienvs.py:109-157)."""
 
-    def __init__(self, E, A, T, Do, Ds, K, device):
+    def __init__(self, E, A, T, Do, Ds, K, device, pad_obs=False, pad_state=False):
+        """pad_obs / pad_state: allocate the feature axis with a leading dimension rounded up to 4 floats (zero padding), so that rows are
+        16-byte aligned for the MLP kernels' tile loads when Do / Ds is not a multiple of 4 (21, 35, 115 at the BASELINE configs).
+        `obs` / `state` are then strided VIEWS [.., :Do] of the padded storage; `obs_ld` / `state_ld` are the leading dimensions that the
+        `*_ld` entry points take.  Consumers that assume contiguous rows (GRU, COMA) get unpadded batches."""
         self.E, self.A, self.T, self.Do, self.Ds, self.K = E, A, T, Do, Ds, K
         self.device = device
         f32 = dict(dtype=torch.float32, device=device)
-        self.obs = torch.zeros(E, A, T, Do, **f32)
-        self.state = torch.zeros(E, T, Ds, **f32)
+        self.obs_ld = (Do + 3) // 4 * 4 if pad_obs else Do
+        self.state_ld = (Ds + 3) // 4 * 4 if pad_state else Ds
+        self.obs = torch.zeros(E, A, T, self.obs_ld, **f32)[..., :Do]
+        self.state = torch.zeros(E, T, self.state_ld, **f32)[..., :Ds]
         self.avail = torch.zeros(E, A, T, K, dtype=torch.uint8, device=device)
         self.action = torch.zeros(E, A, T, dtype=torch.int32, device=device)
         self.logp = torch.zeros(E, A, T, **f32)
@@ -77,11 +83,20 @@ class DeviceBatch:
         self.ret = torch.zeros(E, A, T, **f32)
         self.adv = torch.zeros(E, A, T, **f32)
 
+    def shard(self, lo, hi):
+        """View of the envs [lo, hi): what a rank of an env-sharded run owns (no copy)."""
+        s = DeviceBatch.__new__(DeviceBatch)
+        s.E, s.A, s.T, s.Do, s.Ds, s.K, s.device = hi - lo, self.A, self.T, self.Do, self.Ds, self.K, self.device
+        s.obs_ld, s.state_ld = self.obs_ld, self.state_ld
+        for k in ("obs", "state", "avail", "action", "logp", "reward", "ep_len", "ret", "adv"):
+            setattr(s, k, getattr(self, k)[lo:hi])
+        return s
+
     @classmethod
-    def from_reference_layout(cls, b_obs, b_actions, b_log_probs, b_reward, b_states, b_avail, b_mask, device):
-        """Build from tensors laid out like the reference batch ([B,T,A,F] etc.)."""
+    def from_reference_layout(cls, b_obs, b_actions, b_log_probs, b_reward, b_states, b_avail, b_mask, device, pad=False):
+        """Build from tensors laid out like the reference batch ([B,T,A,F] etc.).  pad: round the leading dimensions of obs / state up to 4."""
         B, T, A, Do = b_obs.shape
-        self = cls(B, A, T, Do, b_states.shape[-1], b_avail.shape[-1], device)
+        self = cls(B, A, T, Do, b_states.shape[-1], b_avail.shape[-1], device, pad_obs=pad, pad_state=pad)
         self.obs.copy_(b_obs.permute(0, 2, 1, 3))
         self.state.copy_(b_states)
         self.avail.copy_(b_avail.permute(0, 2, 1, 3).to(torch.uint8))
@@ -98,7 +113,7 @@ def pad_time(b, T):
     if T == b.T:
         return b
     assert T > b.T
-    n = DeviceBatch(b.E, b.A, T, b.Do, b.Ds, b.K, b.device)
+    n = DeviceBatch(b.E, b.A, T, b.Do, b.Ds, b.K, b.device, pad_obs=b.obs_ld != b.Do, pad_state=b.state_ld != b.Ds)
     n.obs[:, :, :b.T] = b.obs; n.state[:, :b.T] = b.state; n.avail[:, :, :b.T] = b.avail; n.action[:, :, :b.T] = b.action
     n.logp[:, :, :b.T] = b.logp; n.reward[:, :b.T] = b.reward; n.ep_len.copy_(b.ep_len)
     return n
@@ -281,8 +296,9 @@ class PPOLearner:
         rows = E * T * Av
         self._ensure_ws(b)
         self.wait_critic()  # the critic epochs of the previous update ran on their own stream (under this batch's rollout)
-        N.check(lib.cm_mlp_forward_ws(N.ptr(x), rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
-                                      N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_ws")
+        x_ld = b.state_ld if self.algo == "mappo" else b.obs_ld
+        N.check(lib.cm_mlp_forward_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
+                                      N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_ld")
         N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
                                       hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
         if hp.normalize_advantage:
@@ -335,7 +351,7 @@ class PPOLearner:
         self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
-        N.check(self.lib.cm_critic_fwd_bwd(N.ptr(x), N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
+        N.check(self.lib.cm_critic_fwd_bwd_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
                                            0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
                                            N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), s),
                 "cm_critic_fwd_bwd")
@@ -344,7 +360,7 @@ class PPOLearner:
         """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor)."""
         self._ensure_ws(b)
         a = self.actor_spec
-        N.check(self.lib.cm_ppo_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
+        N.check(self.lib.cm_ppo_actor_fwd_bwd_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
                                               N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
                                               N.ptr(self.actor), self.hp.ppo_clip, self.hp.entropy_coef,
                                               N.ptr(self.g_actor if g is None else g), N.ptr(self.ws), self.ws.numel(), s),

@@ -18,7 +18,9 @@ def _off(t, nbytes):
 class SyntheticSpreadRollout:
     """E synthetic MPE-like envs (csrc/cm_env.hip), all truncated at exactly T steps."""
 
-    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0):
+    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0, pad=True):
+        """pad: obs / state buffers with leading dimensions rounded up to 4 floats (learner.DeviceBatch) -- the learner's kernels then
+        read 16-byte aligned rows whatever the env's feature widths; pad=False for consumers of contiguous rows (COMA)."""
         self.lib = N.load()
         self.E, self.A, self.T, self.K = E, A, T, 5
         self.agent_ids = bool(agent_ids)
@@ -28,7 +30,7 @@ class SyntheticSpreadRollout:
         self.device = torch.device(device)
         # two buffers used alternately: the learner's critic epochs (own stream, learner.py) may still read episode i's states and
         # returns while episode i + 1 is being written
-        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device, pad_obs=pad, pad_state=pad) for _ in range(2)]
         for bb in self.batches:
             bb.avail.fill_(1)
             bb.ep_len.fill_(T)
@@ -52,18 +54,21 @@ class SyntheticSpreadRollout:
             if not can_fuse:
                 raise N.NativeError("fused rollout requested for an unsupported shape")
             act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
-            if eps > 0.0:  # COMA's epsilon-mixed exploration (coma_multienvs.py:477-484)
-                N.check(lib.cm_rollout_spread_eps(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
-                                                  self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
-                                                  actor_spec.n_layers, float(eps), N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action),
-                                                  N.ptr(b.logp), N.ptr(b.reward), s), "cm_rollout_spread_eps")
-            else:
-                N.check(lib.cm_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed,
-                                              self.env_offset, self.episode, N.ptr(actor_flat), actor_spec.hidden,
-                                              actor_spec.n_layers, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.action), N.ptr(b.logp),
-                                              N.ptr(b.reward), s), "cm_rollout_spread")
+            # eps > 0: COMA's epsilon-mixed exploration (coma_multienvs.py:477-484)
+            N.check(lib.cm_rollout_spread_ld(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed, self.env_offset,
+                                             self.episode, N.ptr(actor_flat), actor_spec.hidden, actor_spec.n_layers, float(eps),
+                                             N.ptr(b.obs), b.obs_ld, N.ptr(b.state), b.state_ld, N.ptr(b.action), N.ptr(b.logp),
+                                             N.ptr(b.reward), s), "cm_rollout_spread_ld")
             self.episode += 1
             return b
+        if b.obs_ld != Do or b.state_ld != b.Ds:
+            # the per-step env kernels (cm_synth_env_reset / _step) write contiguous rows: shapes the fused kernel does not cover (and
+            # explicit fused=False runs) switch this rollout to unpadded buffers, once
+            self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+            for bb in self.batches:
+                bb.avail.fill_(1)
+                bb.ep_len.fill_(T)
+            self.batch = b = self.batches[self.episode & 1]
         N.check(lib.cm_synth_env_reset(N.ptr(self.env_state), E, A, int(self.agent_ids), self.seed, self.env_offset,
                                        self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
@@ -87,13 +92,13 @@ class SyntheticShapeRollout:
     states / availability masks, T x cm_policy_act (or cm_gru_policy_act) samples actions, one launch computes rewards."""
 
     def __init__(self, E, A, T, obs_raw=105, state_dim=243, n_actions=17, avail_p=0.7, seed=1, agent_ids=True, device="cuda:0",
-                 env_offset=0):
+                 env_offset=0, pad=True):
         self.lib = N.load()
         self.E, self.A, self.T, self.K = E, A, T, n_actions
         self.obs_raw, self.agent_ids, self.avail_p = obs_raw, bool(agent_ids), float(avail_p)
         self.Do, self.Ds = obs_raw + (A if agent_ids else 0), state_dim
         self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
-        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]  # see SyntheticSpreadRollout
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device, pad_obs=pad, pad_state=pad) for _ in range(2)]  # see SyntheticSpreadRollout
         for bb in self.batches:
             bb.ep_len.fill_(T)
         self.batch = self.batches[0]
@@ -111,14 +116,19 @@ class SyntheticShapeRollout:
                 self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         if eps > 0.0 or need:
             fused = False
-        N.check(lib.cm_shape_env_fill(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
-                                      self.episode, N.ptr(b.obs), N.ptr(b.state), N.ptr(b.avail), s), "cm_shape_env_fill")
+        N.check(lib.cm_shape_env_fill_ld(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
+                                         self.episode, N.ptr(b.obs), b.obs_ld, N.ptr(b.state), b.state_ld, N.ptr(b.avail), s),
+                "cm_shape_env_fill_ld")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
         gru = actor_spec.kind == "gru"
         if not gru and fused is not False:  # obs do not depend on the actions: sample every step in ONE launch
-            N.check(lib.cm_policy_act_episode(N.ptr(b.obs), N.ptr(b.avail), E * A, T, actor_spec.din, actor_spec.hidden,
-                                              actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A,
-                                              N.ptr(b.action), N.ptr(b.logp), s), "cm_policy_act_episode")
+            w0b = lib.cm_w0_image_bytes(actor_spec.din, actor_spec.hidden)  # scratch for the padded image of a streamed, unaligned W0
+            if w0b and (getattr(self, "w0_ws", None) is None or self.w0_ws.numel() < w0b):
+                self.w0_ws = torch.empty(w0b, dtype=torch.uint8, device=self.device)
+            N.check(lib.cm_policy_act_episode_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), E * A, T, actor_spec.din, actor_spec.hidden,
+                                                 actor_spec.n_layers, K, N.ptr(actor_flat), act_seed, self.env_offset * A,
+                                                 N.ptr(b.action), N.ptr(b.logp), N.ptr(self.w0_ws) if w0b else None, w0b, s),
+                    "cm_policy_act_episode_ld")
             N.check(lib.cm_shape_env_reward(E, A, T, K, self.seed, self.env_offset, self.episode, N.ptr(b.action), N.ptr(b.reward), s),
                     "cm_shape_env_reward")
             self.episode += 1
@@ -129,11 +139,11 @@ class SyntheticShapeRollout:
             self.h.zero_()
         for t in range(T):
             if gru:
-                N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                               actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
                                               _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
             else:
-                N.check(lib.cm_policy_act_ws(_off(b.obs, 4 * t * Do), T * Do, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                N.check(lib.cm_policy_act_ws(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                              actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps), act_seed,
                                              self.env_offset * A, t, _off(b.action, 4 * t), _off(b.logp, 4 * t), T,
                                              N.ptr(self.act_ws) if need else None, need, s), "cm_policy_act_ws")

@@ -229,6 +229,42 @@ int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
                           int64_t env_offset, int64_t episode, const float* params, int hidden,
                           float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream);
 
+/* ---- padded leading dimensions ("_ld" variants) -----------------------------------------------------------------------
+ * The reference's feature widths are whatever the env gives (21, 35, 115 at BASELINE configs 2 / 5 / 4): rows of obs [E][A][T][Do]
+ * are then not 16-byte aligned and every tile load of the MLP kernels falls back to 4-byte loads (config 4: the actor pass at 47 %
+ * of the fp32 MFMA peak instead of 58 %).  These variants take the LEADING DIMENSION of the feature axis separately from its
+ * width: obs [E][A][T][obs_ld], state [E][T][state_ld] with obs_ld >= Do, state_ld >= Ds; a leading dimension that is a multiple of 4
+ * (>= the width rounded up to 4) with ZERO padding columns puts the input rows on 16-byte loads.  The weights keep the reference's
+ * layout (W0 is [H][din]).  x_ld == din is the unpadded entry point.  Rollout kernels write the padding columns of a step's row as
+ * zeros or leave them untouched (allocate the buffers zeroed).  This permutes / pads only the storage of the batch the reference
+ * builds at cleanmarl/mappo_multienvs.py:113-132. */
+int cm_mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                      const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* ws / ws_bytes: optional scratch of cm_w0_image_bytes(din, hidden) bytes (16-byte aligned).  When the input is wider than 64 columns
+ * W0 is streamed per tile; if its rows (stride din) are not 16-byte aligned the entry points copy it once per call into a zero-padded
+ * image with an aligned leading dimension there (the training passes keep theirs in their workspace).  NULL / too small: W0 chunks
+ * stay on 4-byte loads -- slower, same results. */
+size_t cm_w0_image_bytes(int din, int hidden);
+int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
+                             int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
+                             int32_t* action, float* logp, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                            const float* logp_old, const float* adv, const int32_t* ep_len,
+                            int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                            const float* params, double ppo_clip, double entropy_coef,
+                            float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
+                         int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                         const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* eps = 0: cm_rollout_spread; eps in (0, 1]: cm_rollout_spread_eps */
+int cm_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                         int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, double eps,
+                         float* obs, int64_t obs_ld, float* state, int64_t state_ld, int32_t* action, float* logp, float* reward,
+                         cm_stream_t stream);
+int cm_shape_env_fill_ld(int E, int A, int T, int obs_raw, int agent_ids, int state_dim, int n_actions, double avail_p,
+                         uint64_t seed, int64_t env_offset, int64_t episode, float* obs, int64_t obs_ld, float* state,
+                         int64_t state_ld, uint8_t* avail, cm_stream_t stream);
+
 /* ---- COMA  (cleanmarl/coma_multienvs.py, cleanmarl/coma.py) -----------------------------------
  * Device layouts as above: obs [E][A][T][Do], state [E][T][Ds], action [E][A][T] int32, avail [E][A][T][K] u8,
  * reward [E][T], ep_len [E]; K-output tensors are [E][A][T][K]. */

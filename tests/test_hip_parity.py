@@ -553,17 +553,14 @@ def _full_size_setup(E=4096, A=8, T=128, K=5):
 
 
 def _shard_view(b, lo, hi):
-    from cleanmarl_amd.learner import DeviceBatch
-    s = DeviceBatch.__new__(DeviceBatch)
-    s.E, s.A, s.T, s.Do, s.Ds, s.K, s.device = hi - lo, b.A, b.T, b.Do, b.Ds, b.K, b.device
-    for k in ("obs", "state", "avail", "action", "logp", "reward", "ep_len", "ret", "adv"):
-        setattr(s, k, getattr(b, k)[lo:hi])
-    return s
+    return b.shard(lo, hi)
 
 
 def test_full_size_env_sharding_additivity():
-    """Gradient / statistic SUMS of two env shards add up to the full batch (the property multi-GPU relies on),
-    checked at the headline size where no CPU oracle finishes in seconds."""
+    """Gradient / statistic SUMS of env shards add up to the full batch (the property multi-GPU relies on), checked at the headline
+    size where no CPU oracle finishes in seconds -- and ONE of the shards (32 envs of the 4096) is small enough for the oracle:
+    its sums match the CPU restatement, which pins the full-size pass to the oracle through the additivity."""
+    from oracle import restatement as R
     from cleanmarl_amd import _native as N
     L, b = _full_size_setup()
     L.compute_targets(b)
@@ -571,15 +568,36 @@ def test_full_size_env_sharding_additivity():
     L.actor_pass(b, s); L.critic_pass(b, s)
     full = L.gbuf.clone()
     parts = torch.zeros_like(full)
-    for lo, hi in ((0, 1500), (1500, 4096)):  # uneven shards, tile-unaligned boundary
+    first = None
+    for lo, hi in ((0, 32), (32, 1500), (1500, 4096)):  # uneven shards, tile-unaligned boundaries
         sb = _shard_view(b, lo, hi)
         L.actor_pass(sb, s); L.critic_pass(sb, s)
         parts += L.gbuf
+        if first is None:
+            first = L.gbuf.clone()
     torch.cuda.synchronize()
     scale = full.abs().max().item()
     assert (full - parts).abs().max().item() <= 1e-4 * scale
-    Pa = L.actor.numel()
+    Pa, Pc = L.actor.numel(), L.critic.numel()
     assert full[Pa + 5].item() == b.ep_len.sum().item()  # N = b_mask.sum()
+    # ---- the 32-env shard against the oracle (same returns / advantages as inputs: the value pass + scan have their own tests)
+    sb = _shard_view(b, 0, 32)
+    T = b.T
+    mask = torch.arange(T)[None, :] < sb.ep_len.cpu()[:, None]
+    batch = dict(obs=sb.obs.permute(0, 2, 1, 3).cpu(), actions=sb.action.permute(0, 2, 1).long().cpu(), log_probs=sb.logp.permute(0, 2, 1).cpu(),
+                 reward=sb.reward.cpu(), states=sb.state.cpu(), avail=sb.avail.permute(0, 2, 1, 3).bool().cpu(), mask=mask)
+    hp = dict(gamma=0.99, td_lambda=0.95, epochs=1, ppo_clip=0.2, entropy_coef=0.001, clip_gradients=-1, optimizer="Adam",
+              learning_rate_actor=8e-4, learning_rate_critic=8e-4)
+    ap = [p.cpu() for p in torch.split(L.actor.cpu(), [int(np.prod(sh)) for sh in L.actor_spec.shapes()])]
+    ap = [p.reshape(sh) for p, sh in zip(ap, L.actor_spec.shapes())]
+    cp = [p.reshape(sh) for p, sh in zip(torch.split(L.critic.cpu(), [int(np.prod(sh)) for sh in L.critic_spec.shapes()]), L.critic_spec.shapes())]
+    scal, ag, cg = R.mlp_epoch(ap, cp, batch, sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu(), hp, "mappo")
+    n = float(first[Pa + 5])
+    assert n == float(mask.sum())
+    assert _err((first[:Pa] / n).cpu().numpy(), R.flat(ag).numpy()) <= TOL
+    assert _err((first[Pa + 8:Pa + 8 + Pc] / n).cpu().numpy(), R.flat(cg).numpy()) <= TOL
+    assert abs(float((-first[Pa + 0] - hp["entropy_coef"] * first[Pa + 1]) / n) - scal["actor_loss"]) <= TOL * (1 + abs(scal["actor_loss"]))
+    assert abs(float(first[Pa + 8 + Pc + 4] / n) - scal["critic_loss"]) <= TOL * (1 + abs(scal["critic_loss"]))
 
 
 def test_full_size_scan_linearity_and_padding_invariance():
@@ -806,3 +824,63 @@ def test_optimiser_step_matches_torch_at_size_boundaries(kind):
                 assert abs(float(norm) - want_norm) <= 1e-5 * (1 + want_norm), (kind, n, step)
                 assert _err(g[:n].cpu().numpy(), want_grad.numpy()) <= 1e-6, (kind, n, max_norm, step)  # what optimizer.step() consumed
                 assert _err(p.cpu().numpy(), ref.detach().numpy()) <= 1e-6, (kind, n, max_norm, step)
+
+
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [("mappo", 37, 3, 25, 21, 54, 5, 64, 1), ("ippo", 12, 10, 40, 115, 243, 17, 64, 1),
+                                                      ("mappo", 9, 5, 12, 35, 150, 5, 64, 1), ("mappo", 7, 2, 9, 131, 390, 6, 48, 2)])
+def test_padded_leading_dimensions_do_not_change_the_update(algo, E, A, T, Do, Ds, K, H, L):
+    """The `_ld` entry points (obs / state rows padded to a multiple of 4 floats so that tile loads are 16-byte wide; feature widths
+    21 / 35 / 115 of BASELINE configs 2 / 5 / 4, and 131 / 390 = three chunks + the split critic schedule): same returns, losses,
+    gradients and post-step parameters as the unpadded batch, and both within 1e-4 of the oracle."""
+    from oracle import restatement as R
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    batch = _random_case(31, E, A, T, Do, Ds, K)
+    aspec, cspec = NetSpec(Do, H, L, K), NetSpec(Ds if algo == "mappo" else Do, H, L, 1)
+    ap, cp = init_params_like_torch(aspec), init_params_like_torch(cspec)
+    hpd = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=True, normalize_return=False, epochs=2, ppo_clip=0.2, entropy_coef=0.01,
+               clip_gradients=0.5, optimizer="Adam", learning_rate_actor=8e-4, learning_rate_critic=8e-4)
+    recs = []
+    for pad in (False, True):
+        b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"], batch["states"],
+                                              batch["avail"], batch["mask"], dev, pad=pad)
+        assert (b.obs_ld % 4 == 0 and b.state_ld % 4 == 0) if pad else (b.obs_ld == Do and b.state_ld == Ds)
+        L_ = PPOLearner(algo, aspec, cspec, A, HParams(**hpd), dev, [p.clone() for p in ap], [p.clone() for p in cp])
+        r = L_.train_iteration(b, keep_grads=True)
+        torch.cuda.synchronize()
+        recs.append((b.ret.clone(), b.adv.clone(), [dict(d) for d in r]))
+    (ret0, adv0, r0), (ret1, adv1, r1) = recs
+    assert torch.equal(ret0, ret1) and torch.equal(adv0, adv1)  # the value pass reads the same numbers in the same order
+    ret, adv, orec = R.mlp_update(ap, cp, batch, hpd, algo)
+    assert _err(ret1.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL
+    for e in range(2):
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
+            assert abs(r0[e][k] - r1[e][k]) <= 1e-6 * (1 + abs(r0[e][k])), (k, r0[e][k], r1[e][k])
+            assert abs(r1[e][k] - orec[e][k]) <= TOL * (1 + abs(orec[e][k])), (k, r1[e][k], orec[e][k])
+        for k in ("actor_grads", "critic_grads", "actor_after", "critic_after"):
+            assert _err(r0[e][k].cpu().numpy(), r1[e][k].cpu().numpy()) <= 1e-6, k
+            assert _err(r1[e][k].cpu().numpy(), R.flat(orec[e][k]).numpy()) <= TOL, k
+
+
+def test_padded_rollout_buffers_hold_the_same_rollout():
+    """cm_rollout_spread_ld / cm_shape_env_fill_ld / cm_policy_act_episode_ld: buffers with padded leading dimensions receive exactly the
+    rollout of the unpadded ones (bit for bit), and their padding columns stay zero."""
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    from cleanmarl_amd.rollout import SyntheticShapeRollout, SyntheticSpreadRollout
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    for mk, spec_k in ((lambda pad: SyntheticSpreadRollout(50, 3, 9, seed=7, device=dev, env_offset=11, pad=pad), 5),
+                       (lambda pad: SyntheticSpreadRollout(600, 5, 6, seed=7, device=dev, env_offset=11, pad=pad), 5),
+                       (lambda pad: SyntheticShapeRollout(9, 3, 7, obs_raw=29, state_dim=11, n_actions=17, seed=5, device=dev, env_offset=3, pad=pad), 17)):
+        ra, rb = mk(False), mk(True)
+        spec = NetSpec(ra.Do, 64, 1, spec_k)
+        p = flatten_params(init_params_like_torch(spec), dev)
+        for _ in range(2):
+            ba, bb = ra.collect(p, spec), rb.collect(p, spec)
+        torch.cuda.synchronize()
+        assert bb.obs_ld % 4 == 0 and bb.state_ld % 4 == 0 and (bb.obs_ld != ra.Do or bb.state_ld != ra.Ds)
+        for k in ("obs", "state", "avail", "action", "logp", "reward"):
+            assert torch.equal(getattr(ba, k), getattr(bb, k)), k
+        st = bb.obs.as_strided((bb.E, bb.A, bb.T, bb.obs_ld), (bb.A * bb.T * bb.obs_ld, bb.T * bb.obs_ld, bb.obs_ld, 1))
+        assert not st[..., bb.Do:].any()

@@ -30,7 +30,7 @@ ap.add_argument("--cpu-envs", type=int, default=16)
 args = ap.parse_args()
 E, A, T = args.envs, args.agents, args.T
 dev = torch.device("cuda:0")
-roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev)
+roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, pad=False)  # COMA's kernels read contiguous rows
 Do, Ds, K = roll.Do, roll.Ds, roll.K
 Dc = coma_critic_input_dim(Do, Ds, A, K)
 aspec, cspec = NetSpec(Do, 64, 1, K), NetSpec(Dc, 64, 1, K)

@@ -19,6 +19,8 @@ CFG = [  # name, algo, gru, E, A, T, Do, Ds, K
     ("cfg4 IPPO 2048x10x256 (all envs on 1 GPU)", "ippo", False, 2048, 10, 256, 115, 243, 17),
     ("cfg5 MAPPO-GRU 1024x5x128 tbptt=10", "mappo", True, 1024, 5, 128, 35, 150, 5),
 ]
+if os.environ.get("CM_BENCH_ALIGNED"):  # what 16-byte aligned rows would buy: the same configs with feature widths rounded up to 4
+    CFG = [(n + " [widths rounded up to 4]", al, g, E, A, T, (Do + 3) // 4 * 4, (Ds + 3) // 4 * 4, K) for (n, al, g, E, A, T, Do, Ds, K) in CFG]
 dev = torch.device("cuda:0")
 for name, algo, gru, E, A, T, Do, Ds, K in CFG:
     g = torch.Generator().manual_seed(0)

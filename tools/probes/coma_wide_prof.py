@@ -6,7 +6,7 @@ from cleanmarl_amd.learner import NetSpec, init_params_like_torch
 from cleanmarl_amd.rollout import SyntheticSpreadRollout
 E, A, T = 4096, 8, 128
 dev = torch.device("cuda:0")
-roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev)
+roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, pad=False)  # COMA's kernels read contiguous rows
 Do, Ds, K = roll.Do, roll.Ds, roll.K
 aspec, cspec = NetSpec(Do, 64, 1, K), NetSpec(coma_critic_input_dim(Do, Ds, A, K), 128, 1, K)
 L = COMALearner(aspec, cspec, A, COMAHParams(), dev, init_params_like_torch(aspec), init_params_like_torch(cspec))
