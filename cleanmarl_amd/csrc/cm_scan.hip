@@ -77,6 +77,8 @@ extern "C" int cm_td_lambda_scan(const float* reward, const float* values, const
     const int nseq = E * Av;
     const int grid = (nseq + SCAN_WAVES - 1) / SCAN_WAVES;
     const size_t lds = (size_t)SCAN_WAVES * 2 * T * sizeof(float);
+    if (lds > 64 * 1024)  // dynamic LDS above the 64 KB default needs the attribute (T > 2048 at four waves per workgroup)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_td_lambda_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_td_lambda_scan, dim3(grid), dim3(SCAN_WAVES * 64), lds, (hipStream_t)stream,
                        reward, values, ep_len, E, A, Av, T, a, gv, ret, adv);
     CM_CHECK_LAUNCH("cm_td_lambda_scan");

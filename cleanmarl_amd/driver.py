@@ -251,15 +251,23 @@ def run(script, argv=None):
     training_step = num_episodes = step = 0
     if args.checkpoint and os.path.exists(args.checkpoint):  # resume (every rank loads the same replicated state)
         ck = torch.load(args.checkpoint, map_location="cpu")
+        if ck.get("script", script) != script:
+            raise N.NativeError(f"checkpoint {args.checkpoint} was written by {ck['script']}, not {script}")
         learner.load_state_dict(ck["learner"])
         training_step, num_episodes, step = ck["training_step"], ck["num_episodes"], ck["step"]
         if roll is not None:
             roll.episode = ck.get("episode", 0)
+        host_actor.calls = ck.get("host_actor_calls", 0)  # the sampler's Philox counter of the host-env paths
+        if pinned is not None:
+            pinned.calls = ck.get("pinned_calls", 0)
 
     def save_checkpoint():
-        if args.checkpoint and rank == 0:
-            torch.save(dict(learner=learner.state_dict(), training_step=training_step, num_episodes=num_episodes, step=step,
-                            episode=roll.episode if roll is not None else 0), args.checkpoint)
+        if args.checkpoint and rank == 0:  # written next to the target and renamed: a crash mid-write never leaves a truncated file
+            tmp = args.checkpoint + ".tmp"
+            torch.save(dict(version=2, script=script, learner=learner.state_dict(), training_step=training_step, num_episodes=num_episodes,
+                            step=step, episode=roll.episode if roll is not None else 0,
+                            host_actor_calls=host_actor.calls, pinned_calls=pinned.calls if pinned is not None else 0), tmp)
+            os.replace(tmp, args.checkpoint)
     iteration = 0
     while step < args.total_timesteps:
         if not device_env:
@@ -286,9 +294,24 @@ def run(script, argv=None):
                 torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX, group=pg)
                 b = pad_time(b, int(t_max.item()))
         step += int(n_steps.item())  # counts ENV steps, like the reference (:435)
-        ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
-        if args.env_type == "smaclite":
-            ep_stats.extend([i["battle_won"] for i in stats["infos"]])
+        if world > 1:
+            # rollout/* scalars and their cadence must be those of ONE process owning all batch_size envs: gather every rank's episodes
+            # (variable counts per rank: pad to the largest shard) instead of logging rank 0's shard
+            won = [float(i["battle_won"]) for i in stats["infos"]] if args.env_type == "smaclite" else [0.0] * E
+            loc = torch.full((3, (E_glob + world - 1) // world), float("nan"), dtype=torch.float64, device=device)
+            loc[0, :E] = torch.tensor(stats["ep_reward"], dtype=torch.float64); loc[1, :E] = torch.tensor(stats["ep_len"], dtype=torch.float64)
+            loc[2, :E] = torch.tensor(won, dtype=torch.float64)
+            parts = [torch.empty_like(loc) for _ in range(world)]
+            torch.distributed.all_gather(parts, loc, group=pg)
+            allp = torch.cat(parts, dim=1).cpu()
+            keep = ~torch.isnan(allp[1])
+            ep_rewards.extend(allp[0][keep].tolist()); ep_lengths.extend(allp[1][keep].tolist())
+            if args.env_type == "smaclite":
+                ep_stats.extend(allp[2][keep].tolist())
+        else:
+            ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
+            if args.env_type == "smaclite":
+                ep_stats.extend([i["battle_won"] for i in stats["infos"]])
         num_episodes += E_glob
         log_now = (training_step % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
         if log_now:

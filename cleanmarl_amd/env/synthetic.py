@@ -100,6 +100,19 @@ def _normal01(a, b):
     return (np.sqrt(F(-2.0) * np.log(u1)) * np.cos(F(6.283185307179586) * u2)).astype(F)
 
 
+def _normal4(x, y, z, w):
+    """FOUR normals per Philox call -- twin of normal4() in csrc/cm_env.hip: both Box-Muller outputs of the word pairs (x, y), (z, w).
+    Returns [..., 4]."""
+    def pair(a, b):
+        u1 = ((np.asarray(a, np.uint32) >> np.uint32(8)).astype(F) + F(0.5)) * F(1.0 / 16777216.0)
+        r = np.sqrt(F(-2.0) * np.log(u1)).astype(F)
+        ang = (F(6.283185307179586) * u01(b)).astype(F)
+        return (r * np.cos(ang)).astype(F), (r * np.sin(ang)).astype(F)
+    n0, n1 = pair(x, y)
+    n2, n3 = pair(z, w)
+    return np.stack([n0, n1, n2, n3], axis=-1)
+
+
 class SyntheticShapeEnv(CommonInterface):
     """CPU twin of the on-device "shape" env (cm_shape_env_fill / cm_shape_env_reward): wide random observations, a
     separate global state, availability masks with action 0 always legal, fixed horizon -- BASELINE config 4's
@@ -120,12 +133,12 @@ class SyntheticShapeEnv(CommonInterface):
     def _observe(self):
         A, t = self.n_agents, self.t
         c2 = (t * A + np.arange(A, dtype=np.uint32))[:, None]
-        x, y, _, _ = self._words(c2, np.uint32(0x100) + np.arange(self.obs_raw, dtype=np.uint32)[None, :])
-        raw = _normal01(x, y)
-        x, y, _, _ = self._words(np.uint32(t), np.uint32(0x40000000) + np.arange(self.state_dim, dtype=np.uint32))
-        self.state = _normal01(x, y)
-        x, _, _, _ = self._words(c2, np.uint32(0x80000000) + np.arange(self.K, dtype=np.uint32)[None, :])
-        av = (u01(x) < self.avail_p)
+        # features / actions 4g .. 4g+3 share the Philox counter (.., base + g): four values per call (normal4 / the four words)
+        go, gs, gk = (self.obs_raw + 3) // 4, (self.state_dim + 3) // 4, (self.K + 3) // 4
+        raw = _normal4(*self._words(c2, np.uint32(0x100) + np.arange(go, dtype=np.uint32)[None, :])).reshape(A, 4 * go)[:, :self.obs_raw]
+        self.state = _normal4(*self._words(np.uint32(t), np.uint32(0x40000000) + np.arange(gs, dtype=np.uint32))).reshape(4 * gs)[:self.state_dim]
+        words = np.stack(self._words(c2, np.uint32(0x80000000) + np.arange(gk, dtype=np.uint32)[None, :]), axis=-1).reshape(A, 4 * gk)[:, :self.K]
+        av = (u01(words) < self.avail_p)
         av[:, 0] = True
         self.avail = av.astype(np.int64)
         return np.concatenate([raw, np.eye(A, dtype=F)], 1) if self.agent_ids else raw

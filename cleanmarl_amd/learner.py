@@ -513,7 +513,8 @@ class PPOLearner:
     def state_dict(self):
         """Flat parameters + Adam moments + step counters (CPU tensors; torch.save-able)."""
         self.wait_critic()
-        return dict(algo=self.algo, actor_spec=vars(self.actor_spec), critic_spec=vars(self.critic_spec),
+        hp = {k: getattr(self.hp, k) for k in ("optimizer", "learning_rate_actor", "learning_rate_critic", "epochs", "tbptt")}
+        return dict(algo=self.algo, actor_spec=vars(self.actor_spec), critic_spec=vars(self.critic_spec), hp=hp,
                     actor=self.actor.cpu(), critic=self.critic.cpu(),
                     opt_a=dict(m=self.opt_a.m.cpu(), v=self.opt_a.v.cpu(), step=self.opt_a.step),
                     opt_c=dict(m=self.opt_c.m.cpu(), v=self.opt_c.v.cpu(), step=self.opt_c.step))
@@ -521,6 +522,14 @@ class PPOLearner:
     def load_state_dict(self, sd):
         if sd["algo"] != self.algo or sd["actor_spec"] != vars(self.actor_spec) or sd["critic_spec"] != vars(self.critic_spec):
             raise N.NativeError("checkpoint was written for a different algorithm / network shape")
+        saved = sd.get("hp")
+        if saved is not None and saved.get("optimizer") != self.hp.optimizer:  # the moments of one optimiser mean nothing to another
+            raise N.NativeError(f"checkpoint holds {saved.get('optimizer')} state, this run uses --optimizer={self.hp.optimizer}")
+        if saved is not None:
+            diff = {k: (v, getattr(self.hp, k)) for k, v in saved.items() if k != "optimizer" and getattr(self.hp, k) != v}
+            if diff:
+                import warnings
+                warnings.warn(f"resuming with different hyper-parameters than the checkpoint was written with: {diff}")
         self.wait_critic()
         self.actor.copy_(sd["actor"]); self.critic.copy_(sd["critic"])
         for opt, o in ((self.opt_a, sd["opt_a"]), (self.opt_c, sd["opt_c"])):
