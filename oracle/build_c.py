@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_build", "libtdlambda.so")
 
 
-SRCS = ["td_lambda.c", "ppo_loss.c"]
+SRCS = ["td_lambda.c", "ppo_loss.c", "optim_moments.c"]
 
 
 def build():
@@ -55,3 +55,71 @@ def ppo_losses_c(batch, actor_params, critic_params, adv, ret, ppo_clip, entropy
                        len(actor_params) // 2 - 2, cp.ctypes.data, critic_params[0].shape[0], len(critic_params) // 2 - 2,
                        1 if algo == "ippo" else 0, float(ppo_clip), float(entropy_coef), out.ctypes.data)
     return dict(actor_loss=out[0], critic_loss=out[1], entropy=out[2], kl=out[3], clipfrac=out[4], n_valid=out[5])
+
+
+def _lib():
+    return ctypes.CDLL(build())
+
+
+def clip_optim_step_c(params, grads, m, v, step, lr, kind, max_norm, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """oracle/optim_moments.c::clip_optim_step_ref on flat float32 numpy arrays (updated IN PLACE); returns the pre-clip norm.
+    kind: "Adam" | "AdamW" | "SGD" | "RMSprop" with torch's defaults (AdamW: weight_decay 0.01, RMSprop: alpha 0.99)."""
+    import numpy as np
+    kinds = {"Adam": 0, "AdamW": 1, "SGD": 2, "RMSprop": 3}
+    if kind == "AdamW" and weight_decay == 0.0:
+        weight_decay = 0.01
+    if kind == "RMSprop":
+        beta2 = 0.99
+    lib = _lib()
+    P, D, I = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+    lib.clip_optim_step_ref.restype = D
+    lib.clip_optim_step_ref.argtypes = [P, P, P, P, ctypes.c_long, I, D, D, D, D, D, I, D]
+    for a in (params, grads, m, v):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return lib.clip_optim_step_ref(params.ctypes.data, grads.ctypes.data, m.ctypes.data, v.ctypes.data, params.size, int(step), float(lr),
+                                   beta1, beta2, eps, weight_decay, kinds[kind], float(max_norm))
+
+
+def masked_normalize_c(x, mask, eps=0.0, valid_only=False):
+    """oracle/optim_moments.c::masked_normalize_ref: x [B,T,A] float32 (copy returned), mask [B,T] -> (normalised x, (count, mean, std))."""
+    import numpy as np
+    x = np.ascontiguousarray(x, np.float32).copy(); mk = np.ascontiguousarray(mask, np.uint8)
+    B, T, A = x.shape
+    out = np.zeros(3, np.float64)
+    lib = _lib()
+    lib.masked_normalize_ref.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                         ctypes.c_int, ctypes.c_void_p]
+    lib.masked_normalize_ref(x.ctypes.data, mk.ctypes.data, B, T, A, float(eps), int(valid_only), out.ctypes.data)
+    return x, tuple(out)
+
+
+def gru_cell_c(x, h, W_ih, W_hh, b_ih, b_hh):
+    """oracle/optim_moments.c::gru_cell_ref row by row: x [R,I], h [R,H] -> h' [R,H]."""
+    import numpy as np
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    x, h, W_ih, W_hh, b_ih, b_hh = map(f, (x, h, W_ih, W_hh, b_ih, b_hh))
+    R, I = x.shape; H = h.shape[1]
+    out = np.empty((R, H), np.float32)
+    lib = _lib()
+    P = ctypes.c_void_p
+    lib.gru_cell_ref.argtypes = [P] * 6 + [ctypes.c_int, ctypes.c_int, P]
+    for r in range(R):
+        lib.gru_cell_ref(x[r].ctypes.data, h[r].ctypes.data, W_ih.ctypes.data, W_hh.ctypes.data, b_ih.ctypes.data, b_hh.ctypes.data, I, H,
+                         out[r].ctypes.data)
+    return out
+
+
+def categorical_sample_c(logits, u):
+    """oracle/optim_moments.c::categorical_sample_ref row by row: masked logits [R,K], uniforms [R] -> (actions, logp)."""
+    import numpy as np
+    z = np.ascontiguousarray(logits, np.float32); u = np.ascontiguousarray(u, np.float32)
+    R, K = z.shape
+    act = np.empty(R, np.int64); lp = np.empty(R, np.float32)
+    lib = _lib()
+    lib.categorical_sample_ref.restype = ctypes.c_int
+    lib.categorical_sample_ref.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    one = ctypes.c_float()
+    for r in range(R):
+        act[r] = lib.categorical_sample_ref(z[r].ctypes.data, K, float(u[r]), ctypes.byref(one))
+        lp[r] = one.value
+    return act, lp

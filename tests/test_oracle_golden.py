@@ -132,3 +132,90 @@ def test_plain_c_loss_loop_matches_reference_golden(golden_dir, name, algo):
     for k, zk in (("actor_loss", "actor_losses"), ("critic_loss", "critic_losses"), ("entropy", "entropies_bonuses"),
                   ("kl", "kl_divergences"), ("clipfrac", "clipped_ratios")):
         assert abs(got[k] - float(z[zk][0])) <= 5e-6 * (1.0 + abs(float(z[zk][0]))), (k, got[k], float(z[zk][0]))
+
+
+OPT_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_rmsprop", "mappo"),
+             ("ippo_sgd", "ippo"), ("ippo_ragged_norm", "ippo"), ("ippo_dense", "ippo")]
+
+
+@pytest.mark.parametrize("name,algo", OPT_CASES)
+def test_plain_c_clip_and_optimiser_step_matches_reference_golden(golden_dir, name, algo):
+    """oracle/optim_moments.c::clip_optim_step_ref (clip_grad_norm_ + one torch.optim step, all four optimisers the goldens cover:
+    Adam, AdamW, SGD, RMSprop) fed with the reference's per-epoch gradients reproduces the reference's post-step parameters and its
+    logged pre-clip gradient norms, epoch after epoch (optimiser state carried)."""
+    from oracle.build_c import clip_optim_step_c
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    for net, init, lr in (("actor", ap, hp["learning_rate_actor"]), ("critic", cp, hp["learning_rate_critic"])):
+        p = R.flat(init).numpy().astype(np.float32).copy()
+        m, v = np.zeros_like(p), np.zeros_like(p)
+        for e in range(int(hp["epochs"])):
+            g = np.ascontiguousarray(z[f"{net}_grads"][e], np.float32).copy()
+            # the goldens hold p.grad AFTER clip_grad_norm_ (what optimizer.step() consumed) and the logged norm BEFORE it
+            norm = clip_optim_step_c(p, g, m, v, e + 1, lr, str(hp["optimizer"]), float(hp["clip_gradients"]))
+            logged, mx = float(z[f"{net}_gradients"][e]), float(hp["clip_gradients"])
+            _close(norm, mx * logged / (logged + 1e-6) if 0 < mx < logged else logged, 5e-6)
+            _close(p, z[f"{net}_after"][e])
+
+
+def test_plain_c_clip_branch_matches_torch():
+    """The goldens never clip (their norms stay below max_norm): the clipping branch of clip_optim_step_ref against torch itself."""
+    from oracle.build_c import clip_optim_step_c
+    torch.manual_seed(0)
+    for kind, cls in (("Adam", torch.optim.Adam), ("AdamW", torch.optim.AdamW), ("SGD", torch.optim.SGD), ("RMSprop", torch.optim.RMSprop)):
+        ref = torch.nn.Parameter(torch.randn(1000))
+        opt = cls([ref], lr=3e-3)
+        p = ref.detach().numpy().copy(); m, v = np.zeros_like(p), np.zeros_like(p)
+        for step in range(1, 4):
+            g = torch.randn(1000) * 2.0
+            ref.grad = g.clone()
+            n_ref = torch.nn.utils.clip_grad_norm_([ref], 0.7)
+            opt.step()
+            gc = g.numpy().copy()
+            n = clip_optim_step_c(p, gc, m, v, step, 3e-3, kind, 0.7)
+            _close(n, float(n_ref)); _close(gc, ref.grad.numpy()); _close(p, ref.detach().numpy())
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_ragged_norm", "mappo"), ("ippo_ragged_norm", "ippo")])
+def test_plain_c_masked_normalisation_matches_reference_golden(golden_dir, name, algo):
+    """oracle/optim_moments.c::masked_normalize_ref: advantage normalisation (agent-mean moments over valid steps, unbiased std, no
+    epsilon, :505-512) reproduces the reference's normalised advantages from the raw TD(lambda) ones, and the reward normalisation of
+    RolloutBuffer.get_batch (:143-146, eps = 1e-6, valid entries only) the reference's b_reward."""
+    from oracle.build_c import masked_normalize_c
+    batch, ap, cp, hp, z = R.load_golden(os.path.join(golden_dir, name + ".npz"))
+    mask = batch["mask"].numpy()
+    with torch.no_grad():
+        values = R.critic_values(cp, batch, algo)
+        ret, adv_raw = R.td_lambda(batch["reward"], values, batch["mask"], hp["gamma"], hp["td_lambda"])
+    assert hp["normalize_advantage"]
+    adv_n, (cnt, mean, sd) = masked_normalize_c(adv_raw.numpy(), mask)
+    assert cnt == mask.sum()
+    _close(adv_n, z["advantages"], 5e-6)
+    if hp["normalize_return"]:
+        _close(masked_normalize_c(ret.numpy(), mask)[0], z["return_lambda"], 5e-6)
+    if "b_reward_raw" in z.files:
+        rn, _ = masked_normalize_c(z["b_reward_raw"][..., None], mask, eps=1e-6, valid_only=True)
+        _close(rn[..., 0], z["b_reward"], 5e-6)
+
+
+def test_plain_c_gru_cell_and_sampler_match_the_pinned_oracle():
+    """gru_cell_ref against torch.nn.GRUCell (what cleanmarl/mappo_lstm_multienvs.py:162-184 calls) and categorical_sample_ref against
+    oracle/sampling.py (the Python twin of the device sampler: same uniforms -> same actions, same log-probs)."""
+    from oracle import sampling
+    from oracle.build_c import categorical_sample_c, gru_cell_c
+    torch.manual_seed(3)
+    cell = torch.nn.GRUCell(21, 48)
+    x, h = torch.randn(17, 21), torch.randn(17, 48)
+    with torch.no_grad():
+        want = cell(x, h).numpy()
+    got = gru_cell_c(x.numpy(), h.numpy(), cell.weight_ih.detach().numpy(), cell.weight_hh.detach().numpy(), cell.bias_ih.detach().numpy(),
+                     cell.bias_hh.detach().numpy())
+    _close(got, want, 5e-6)
+    rng = np.random.default_rng(5)
+    logits = rng.normal(size=(400, 9)).astype(np.float32) * 2
+    avail = rng.random((400, 9)) < 0.6
+    avail[:, 2] = True
+    logits = np.where(avail, logits, np.float32(-1e9))
+    a_py, lp_py, u = sampling.act(logits, avail, seed=11, row_offset=100, t=7)
+    a_c, lp_c = categorical_sample_c(logits, u)
+    assert (a_c == a_py).all() and avail[np.arange(400), a_c].all()
+    _close(lp_c, lp_py, 2e-6)
