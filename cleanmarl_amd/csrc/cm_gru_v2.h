@@ -185,19 +185,31 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
             }
         };
         head_load(0);  // the rows were written by this workgroup: the __syncthreads() above made them visible
+        // per-item inputs of a pass (4 lanes per (row, step) item), also requested one pass ahead and BEFORE the previous pass's dh_head
+        // stores: queued behind those the loads stalled the wave ~1800 cycles per pass at issue
+        struct Item { unsigned char avb[4]; int act; float lpo, advv; };
+        auto item_load = [&](int sA, Item& it) {
+            const int s_i = sA + (hrow >> 5), t_i = a.t0 + s_i;
+            const bool ok = rvalid && s_i < CL;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                it.avb[j] = 1;
+                if (ok && 4 * j + hq < K) it.avb[j] = a.avail[(grow * T + t_i) * K + 4 * j + hq];
+            }
+            const long o = grow * T + t_i;
+            it.act = ok ? a.action[o] : 0;
+            it.lpo = ok ? a.logp_old[o] : 0.f; it.advv = ok ? a.adv[o] : 0.f;
+        };
+        Item cur;
+        item_load(0, cur);
         for (int s0 = 0; s0 < CL; s0 += 2) {
             const int s_it = s0 + (hrow >> 5), t_it = a.t0 + s_it;
             const bool ivalid = rvalid && s_it < CL;
-            // per-item inputs (latency hides under the MFMA below)
             unsigned char avb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                avb[j] = 1;
-                if (ivalid && 4 * j + hq < K) avb[j] = a.avail[(grow * T + t_it) * K + 4 * j + hq];
-            }
-            const long o = grow * T + t_it;
-            const int act = ivalid ? a.action[o] : 0;
-            const float lpo = ivalid ? a.logp_old[o] : 0.f, advv = ivalid ? a.adv[o] : 0.f;
+            for (int j = 0; j < 4; ++j) avb[j] = cur.avb[j];
+            const int act = cur.act;
+            const float lpo = cur.lpo, advv = cur.advv;
             lds_barrier();  // HB / ls / ls2 of the previous pass are dead
             PH(6);
 #pragma unroll
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
                 *q = (*q > 0.0f) ? dh[i] : 0.0f;
             }
             lds_barrier();
+            if (s0 + 2 < CL) item_load(s0 + 2, cur);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = tid + NTHREADS * q, it = idx >> 4, c4 = (idx & 15) * 4;
