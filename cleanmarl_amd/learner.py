@@ -450,35 +450,43 @@ class PPOLearner:
             side = self._critic_stream
             rec.record_stream(side)
 
-            def actor_epochs():
-                for ep in range(nE0):
-                    g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
-                    self._timed("actor", self.actor_pass, b, s, g_actor)
-                    actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self.world > 1 else None)
-                rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
+            def actor_epoch(ep):
+                g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
+                self._timed("actor", self.actor_pass, b, s, g_actor)
+                actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self.world > 1 else None)
 
-            def critic_epochs():
-                side.wait_stream(main)
+            def critic_epoch(ep):
                 with torch.cuda.stream(side):
                     sc = N.stream_ptr()
-                    if timed:
-                        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        c0.record()
-                    for ep in range(nE0):
-                        g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
-                        self._timed("critic", self.critic_pass, b, sc, g_critic)
-                        critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self.world > 1 else None, sc)
-                    rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
-                    if timed:
-                        c1.record()
-                        self.critic_span = (c0, c1)
+                    if timed and ep == 0:
+                        self._c0 = torch.cuda.Event(enable_timing=True)
+                        self._c0.record()
+                    g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
+                    self._timed("critic", self.critic_pass, b, sc, g_critic)
+                    critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self.world > 1 else None, sc)
+                    if ep == nE0 - 1:
+                        rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+                        if timed:
+                            c1 = torch.cuda.Event(enable_timing=True)
+                            c1.record()
+                            self.critic_span = (self._c0, c1)
 
-            if overlap == 2:  # released now, lowest priority: they take the compute units the actor's kernels and the next rollout leave idle
-                critic_epochs()
-                actor_epochs()
-            else:             # released when the actor's epochs are done: they run under the next rollout only
-                actor_epochs()
-                critic_epochs()
+            if overlap == 2:
+                # released now, lowest priority: the critic's kernels take the compute units the actor's kernels and the next rollout leave
+                # idle.  HOST order matters as much as stream order: the launches are interleaved epoch by epoch, actor first -- with all of
+                # the critic's ~20 launches enqueued ahead of the first actor kernel the main stream sat idle for ~150 us per iteration
+                # (kernel trace of the 512-env share) while the critic ran alone
+                side.wait_stream(main)
+                for ep in range(nE0):
+                    actor_epoch(ep)
+                    critic_epoch(ep)
+            else:  # released when the actor's epochs are done: they run under the next rollout only
+                for ep in range(nE0):
+                    actor_epoch(ep)
+                side.wait_stream(main)
+                for ep in range(nE0):
+                    critic_epoch(ep)
+            rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
             side.wait_stream(main)  # the statistics need both halves; they leave on the critic stream, `main` never waits for them
             with torch.cuda.stream(side):
                 host, ev, attach = _to_host_async(self._ring, rec)
