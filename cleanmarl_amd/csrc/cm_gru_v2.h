@@ -361,31 +361,47 @@ __device__ __forceinline__ void colred32t(f32x16& acc, const float* ZT_n0, const
         acc = mfma32(a.w, b.w, acc);
     }
 }
-inline size_t gru2_bwd_lds_bytes() { return (size_t)(5 * T32 * LDT + 7 * HP * LTT + 2 * NTHREADS) * sizeof(float); }
+// acc[32 rows x 32 cols] += dG[32 rows][64 (n)] * (register image of W[64 n][32 cols]), dG read from its TRANSPOSED tile [n][row]:
+// the A operand of MFMA (j, q) is dG[row r][n = 8j + 4h + q] = GT[(8j + 4h + q) * LTT + r] -- 4-byte reads, lanes r contiguous
+__device__ __forceinline__ void rowpar_rb_t(f32x16& acc, const float* GT, const float (&w)[32]) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = GT + (4 * h) * LTT + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a0 = ap[(8 * j) * LTT], a1 = ap[(8 * j + 1) * LTT], a2 = ap[(8 * j + 2) * LTT], a3 = ap[(8 * j + 3) * LTT];
+        acc = mfma32(a0, w[4 * j], acc);
+        acc = mfma32(a1, w[4 * j + 1], acc);
+        acc = mfma32(a2, w[4 * j + 2], acc);
+        acc = mfma32(a3, w[4 * j + 3], acc);
+    }
+}
+constexpr int G2B_TILES = 8;  // per set: G0T G1T G2T G3T X1T HPT OBT D1T
+inline size_t gru2_bwd_lds_bytes() { return (size_t)(5 * T32 * LDT + G2B_TILES * HP * LTT + 2 * NTHREADS) * sizeof(float); }
 
+// Backward sweep.  The recurrence of a step is: gate derivatives (element-wise, needs dh) -> data path (dx1 / dh_prev = dG W, 96 MFMAs
+// per wave) -> dh.  The weight gradients of the step (112 MFMAs per wave) are NOT on that chain: they are issued one step LATER, in the
+// barrier interval in which the NEXT step's gate derivatives are computed -- into registers, so that the tiles the MFMAs read stay
+// intact -- and the matrix pipe works through them while the VALU produces the derivatives; the tiles of the new step are written
+// after the next barrier.  Three barriers per step (twelve in the first generation).  Weight-gradient operands come from transposed
+// [column][row] tiles (16-byte reads along the contracted rows), the data path reads row-major tiles and register weights.
 __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GruOff off = gru_offsets(a.din, a.H, a.K);
-    float* p = smem;
-    float* DH = p; p += T32 * LDT;    // row-major [32][LDT]: dh carried backwards; G0..G3 = the four pre-activation gradients
-    float* G0 = p; p += T32 * LDT;
-    float* G1 = p; p += T32 * LDT;
-    float* G2 = p; p += T32 * LDT;
-    float* G3 = p; p += T32 * LDT;
-    float* G0T = p; p += HP * LTT;    // the same four, x1 (then dx1), h_{t-1} and the obs tile TRANSPOSED [64][LTT]
-    float* G1T = p; p += HP * LTT;
-    float* G2T = p; p += HP * LTT;
-    float* G3T = p; p += HP * LTT;
-    float* A1T = p; p += HP * LTT;
-    float* HPT = p; p += HP * LTT;
-    float* OBT = p; p += HP * LTT;
-    float* red = p;                   // 2 * NTHREADS
+    float* DH = smem;                                   // row-major [32][LDT]: dh carried backwards
+    float* G0 = DH + T32 * LDT;                         // row-major pre-activation gradients of the step (data path)
+    float* G1 = G0 + T32 * LDT;
+    float* G2 = G1 + T32 * LDT;
+    float* G3 = G2 + T32 * LDT;
+    float* S = G3 + T32 * LDT;                          // 8 transposed tiles [64][LTT]: G0T G1T G2T G3T X1T HPT OBT D1T
+    float *G0T = S, *G1T = S + HP * LTT, *G2T = S + 2 * HP * LTT, *G3T = S + 3 * HP * LTT;
+    float *X1T = S + 4 * HP * LTT, *HPT = S + 5 * HP * LTT, *OBT = S + 6 * HP * LTT, *D1T = S + 7 * HP * LTT;
+    float* red = S + G2B_TILES * HP * LTT;              // 2 * NTHREADS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, role = wave >> 1, h = lane >> 5, lc = lane & 31;
     const int H = a.H, din = a.din, T = a.T, CL = a.t1 - a.t0;
     const long R = (long)a.E * a.A;
     const int col = 32 * wn + lc;
-    const int ec = tid & 63, er0 = 8 * (tid >> 6);  // elementwise phase: this thread owns column ec of rows er0 .. er0 + 7
+    const int ec = tid & 63, er0 = 8 * (tid >> 6);  // element-wise phase: this thread owns column ec of rows er0 .. er0 + 7
     // role 0: dx1 = sum_q dG_i[q] W_ih[q]; role 1: dh_prev = sum_q dG_h[q] W_hh[q] -- this wave's 32 columns of the three blocks
     float wG[3][32];
 #pragma unroll
@@ -402,6 +418,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
     PH_DECL
     const long ntiles = (R + T32 - 1) / T32;
     struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], dhh[8], ob[8]; } P;
+    // weight gradients of the step whose tiles are in LDS
+    auto wgrad = [&]() {
+        colred32t(accWih[0], G0T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWih[1], G1T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWih[2], G2T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWhh[0], G0T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accWhh[1], G1T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accWhh[2], G3T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accW1, D1T + 32 * role * LTT, OBT + 32 * wn * LTT);
+        const float4 u = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0), w4 = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0 + 4);
+        db1 += ((u.x + u.y) + (u.z + u.w)) + ((w4.x + w4.y) + (w4.z + w4.w));
+    };
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * T32;
         // everything a step reads from HBM is requested one step AHEAD, under the MFMA phases of the step before
@@ -427,48 +455,45 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
         for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
         load_pre(CL - 1);
         for (int s = CL - 1; s >= 0; --s) {
-            lds_barrier();  // the previous step's fc1 gradient has read A1T / OBT, its dh_prev is in DH
+            lds_barrier();  // dh_prev of the step before is in DH, its dx1 in D1T: the tiles in LDS are those of step s + 1, complete
             PH(0);
-            // ---- gate derivatives (elementwise); dh = carried dh + the head's share of this step (k_gru2_fwd)
-            {
-                float v0[8], v1[8], v2[8], v3[8];
+            // ---- gate derivatives of step s INTO REGISTERS (dh = carried dh + the head's share, k_gru2_fwd) ...
+            float v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int o = (er0 + e) * LDT + ec;
+                const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e];
+                const float dh = DH[o] + P.dhh[e];
+                const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
+                const float dn_pre = dn * (1.0f - nn * nn);
+                v0[e] = dn_pre * ghn * rr * (1.0f - rr); v1[e] = dzg * zz * (1.0f - zz); v2[e] = dn_pre; v3[e] = dn_pre * rr;
+                DH[o] = dh * zz;
+            }
+            // ---- ... while the matrix pipe works through the weight gradients of step s + 1 (independent of the lines above)
+            if (s + 1 < CL) wgrad();
+            lds_barrier();  // every read of the tiles of step s + 1 is done
+            PH(1);
+            {   // tiles of step s: row-major for the data path, transposed for the weight gradients
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int o = (er0 + e) * LDT + ec;
-                    const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e];
-                    const float dh = DH[o] + P.dhh[e];
-                    const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
-                    const float dn_pre = dn * (1.0f - nn * nn);
-                    const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
-                    const float dz_pre = dzg * zz * (1.0f - zz);
-                    v0[e] = dr_pre; v1[e] = dz_pre; v2[e] = dn_pre; v3[e] = dn_pre * rr;
                     G0[o] = v0[e]; G1[o] = v1[e]; G2[o] = v2[e]; G3[o] = v3[e];
-                    DH[o] = dh * zz;
                 }
                 const int ot = ec * LTT + er0;
 #define CM_ST8(dst, v) do { *reinterpret_cast<float4*>(dst + ot) = make_float4(v[0], v[1], v[2], v[3]); \
                             *reinterpret_cast<float4*>(dst + ot + 4) = make_float4(v[4], v[5], v[6], v[7]); } while (0)
                 CM_ST8(G0T, v0); CM_ST8(G1T, v1); CM_ST8(G2T, v2); CM_ST8(G3T, v3);
-                CM_ST8(A1T, P.x1); CM_ST8(HPT, P.hprev); CM_ST8(OBT, P.ob);
+                CM_ST8(X1T, P.x1); CM_ST8(HPT, P.hprev); CM_ST8(OBT, P.ob);
 #undef CM_ST8
-                // bias gradients = column sums: this thread already holds 8 rows of its column
                 dbg[0] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
                 dbg[1] += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
                 dbg[2] += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
                 dbg[3] += ((v3[0] + v3[1]) + (v3[2] + v3[3])) + ((v3[4] + v3[5]) + (v3[6] + v3[7]));
             }
             lds_barrier();
-            PH(1);
-            if (s > 0) load_pre(s - 1);
-            // ---- weight gradients of the gates: wave (role, wn) owns the (n-half = role, k-half = wn) tile of every block
-            colred32t(accWih[0], G0T + 32 * role * LTT, A1T + 32 * wn * LTT);
-            colred32t(accWih[1], G1T + 32 * role * LTT, A1T + 32 * wn * LTT);
-            colred32t(accWih[2], G2T + 32 * role * LTT, A1T + 32 * wn * LTT);
-            colred32t(accWhh[0], G0T + 32 * role * LTT, HPT + 32 * wn * LTT);
-            colred32t(accWhh[1], G1T + 32 * role * LTT, HPT + 32 * wn * LTT);
-            colred32t(accWhh[2], G3T + 32 * role * LTT, HPT + 32 * wn * LTT);
             PH(2);
-            // ---- data path, weights from registers: no staging, no barrier between the gates
+            if (s > 0) load_pre(s - 1);
+            // ---- data path of step s, weights from registers
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -476,30 +501,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
             rowpar_rb(acc, G1, wG[1], HP / 8);
             rowpar_rb(acc, role == 0 ? G2 : G3, wG[2], HP / 8);
             PH(3);
-            lds_barrier();  // every wave is done with A1T (x1) and G*
-            PH(4);
-            if (role == 0) {  // dx1 through relu', written transposed: accumulator rows (i & 3) + 8 (i >> 2) + 4 h are 4 consecutive ones
+            if (role == 0) {  // dx1 through relu' -> D1T (nobody reads it before the next barrier)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4* t = reinterpret_cast<float4*>(A1T + col * LTT + 8 * q + 4 * h);
-                    const float4 x = *t;
-                    *t = make_float4(x.x > 0.f ? acc[4 * q] : 0.f, x.y > 0.f ? acc[4 * q + 1] : 0.f,
-                                     x.z > 0.f ? acc[4 * q + 2] : 0.f, x.w > 0.f ? acc[4 * q + 3] : 0.f);
+                    const float4 x = *reinterpret_cast<const float4*>(X1T + col * LTT + 8 * q + 4 * h);
+                    *reinterpret_cast<float4*>(D1T + col * LTT + 8 * q + 4 * h) =
+                        make_float4(x.x > 0.f ? acc[4 * q] : 0.f, x.y > 0.f ? acc[4 * q + 1] : 0.f,
+                                    x.z > 0.f ? acc[4 * q + 2] : 0.f, x.w > 0.f ? acc[4 * q + 3] : 0.f);
                 }
-            } else {          // dh_{t-1}
+            } else {          // dh_{t-1}: the element-wise phase is two barriers back
 #pragma unroll
                 for (int i = 0; i < 16; ++i) DH[((i & 3) + 8 * (i >> 2) + 4 * h) * LDT + col] += acc[i];
             }
-            lds_barrier();
-            PH(5);
-            // ---- fc1 weight gradient + its bias
-            colred32t(accW1, A1T + 32 * role * LTT, OBT + 32 * wn * LTT);
-            {
-                const float4 u = *reinterpret_cast<const float4*>(A1T + ec * LTT + er0), w4 = *reinterpret_cast<const float4*>(A1T + ec * LTT + er0 + 4);
-                db1 += ((u.x + u.y) + (u.z + u.w)) + ((w4.x + w4.y) + (w4.z + w4.w));
-            }
-            PH(6);
+            PH(4);
         }
+        lds_barrier();
+        wgrad();  // step 0
     }
     PH2_FLUSH(512);
     // ================================ partial gradient of this workgroup (fc2 + statistics were written by k_gru2_fwd)

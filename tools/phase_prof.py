@@ -82,8 +82,7 @@ if which == "gru":
     CL = 10
     for name, base, per, names in (("k_gru2_fwd", 0, CL, ["barrier_top", "gru2_step (fc1, 6 products, gates)", "-", "-", "-", "workspace stores",
                                                          "head: barrier", "head: load h'", "head: logits", "head: ppo math", "head: dW2 + dh_head + store"]),
-                                   ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives", "weight gradients (6 colred)", "data path (3 blocks, reg B)",
-                                                          "barrier", "dx1 / dh write", "fc1 gradient"])):
+                                   ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives (s, registers) | weight gradients (s + 1)", "tile writes", "data path (3 blocks, reg B)", "dx1 / dh write"])):
         rows = prof[base:base + 512]
         used = rows[rows.sum(1) > 0].double()
         ph = used.mean(0).cpu(); tot = float(ph.sum())
