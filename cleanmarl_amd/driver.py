@@ -182,12 +182,19 @@ def run(script, argv=None):
     if not str(args.device).startswith("cuda"):
         raise N.NativeError(f"--device={args.device}: this build computes on MI355X only (cuda / cuda:N); there is no CPU path")
     random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)  # :291-294
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CM_DIST_BACKEND=gloo is a TEST hook (tests/test_dist_gpu.py): RCCL refuses two ranks on one device, gloo does not, so the N > 1 code
+    # path of the drivers can be exercised on a 1-GPU box with every rank on cuda:0
+    backend = os.environ.get("CM_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
     E_glob = args.batch_size
     if E_glob < world:

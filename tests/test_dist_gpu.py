@@ -251,3 +251,87 @@ def test_bench_contract_single_gpu():
     assert 1.0 < sh["speedup_bound"] < 8.5
     pr = out["phase_roofline"]
     assert set(pr) == {"rollout", "value_pass_scan", "critic_fwd_bwd", "whole_step"} and all(0 < v["frac"] < 1 for v in pr.values())
+
+
+def _worker_overlap(rank, world, port, gold, algo, out):
+    """Same as _worker but WITHOUT keep_grads: update() then takes the two-stream schedule (critic epochs on the low-priority stream, own
+    communicator, not joined) that small batches use in production."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import restatement as R
+    from cleanmarl_amd import dist
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    batch, ap, cp, hp, z = R.load_golden(gold)
+    dev = torch.device("cuda:0")
+    reward = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else batch["reward"]
+    lo, n = dist.shard(batch["obs"].shape[0], rank, world)
+    sl = slice(lo, lo + n)
+    b = DeviceBatch.from_reference_layout(batch["obs"][sl], batch["actions"][sl], batch["log_probs"][sl], reward[sl],
+                                          batch["states"][sl], batch["avail"][sl], batch["mask"][sl], dev, pad=True)
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"],
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = PPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
+                   process_group=torch.distributed.group.WORLD, world_size=world)
+    assert L.overlap_critic(b) == 2 and L.pg_c is not L.pg
+    recs = L.train_iteration(b)
+    recs = [dict(r) for r in recs]  # materialises the lazily copied statistics (waits for both streams)
+    L.wait_critic()
+    torch.cuda.synchronize()
+    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu()), f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_ragged_norm", "mappo"), ("ippo_ragged_norm", "ippo")])
+def test_two_ranks_two_stream_schedule_reproduces_the_reference(golden_dir, tmp_path, name, algo):
+    """The production schedule of small batches at N = 2 (critic epochs on their own low-priority stream and communicator, released with the
+    actor's, joined by the next reader; padded leading dimensions): final parameters and per-epoch scalars of the unmodified single-process
+    reference, bit-identical across ranks."""
+    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+    gold = os.path.join(golden_dir, name + ".npz")
+    mp.spawn(_worker_overlap, args=(world, port, gold, algo, out), nprocs=world, join=True)
+    z = np.load(gold)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    for g in got:
+        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+        for e, r in enumerate(g["recs"]):
+            assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+    assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
+
+
+def test_two_rank_cli_run_with_host_envs_matches_the_single_process_run(tmp_path):
+    """mappo_multienvs.py launched as two ranks (torch.distributed.run, gloo test hook, both on cuda:0) with HOST envs: every rank owns the
+    global env indices of its shard and its own Philox rows (all ranks used to collect the same episodes), the logged rollout
+    statistics are those of ALL envs, and the first iteration's scalars equal the single-process run of the same command."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import json, sys; sys.path.insert(0, %r); from cleanmarl_amd.driver import run; "
+            "out = run('mappo_multienvs', ['--env_type=synthetic_cpu', '--batch_size=6', '--synthetic_agents=3', '--synthetic_steps=9', "
+            "'--total_timesteps=108', '--eval_steps=100000', '--log_every=1', '--vector_env=pinned']); "
+            "import os; "
+            "print('HIST ' + json.dumps(out['history'])) if os.environ.get('RANK', '0') == '0' else None") % root
+    env = dict(os.environ, CM_DIST_BACKEND="gloo")
+    script = str(tmp_path / "run_cli.py")
+    open(script, "w").write(prog + "\n")
+    one = subprocess.run([sys.executable, script], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), script], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    hist = lambda p: json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("HIST ")][0][5:])
+    h1, h2 = hist(one), hist(two)
+    first = lambda h, tag: [v for t, v, s in h if t == tag][0]
+    for tag in ("rollout/ep_reward", "rollout/ep_length", "rollout/num_episodes"):
+        assert abs(first(h1, tag) - first(h2, tag)) <= 1e-5 * (1 + abs(first(h1, tag))), tag   # same episodes, all 6 envs in the mean
+    for tag in ("train/actor_loss", "train/critic_loss", "train/entropy", "train/actor_gradients", "train/critic_gradients"):
+        assert abs(first(h1, tag) - first(h2, tag)) <= 1e-4 * (1 + abs(first(h1, tag))), tag
+    assert [s for t, v, s in h1 if t == "train/num_updates"] == [s for t, v, s in h2 if t == "train/num_updates"]
