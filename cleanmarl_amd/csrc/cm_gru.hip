@@ -1408,15 +1408,15 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     const long nt32 = ((long)R + T32 - 1) / T32;
     const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
     const int KP32 = n_actions <= 8 ? 8 : KMAX;
-    if (fwd32 && !force_v1 && n_actions <= KP2) {  // second-generation sweeps: weights in registers, head outside the recurrence
-        const size_t lf = gru2_fwd_lds_bytes(), lb = gru2_bwd_lds_bytes();
-        if (wv) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf);
-            hipLaunchKernelGGL(k_gru2_fwd<true>, dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf);
-            hipLaunchKernelGGL(k_gru2_fwd<false>, dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a);
-        }
+    if (fwd32 && !force_v1) {  // second-generation sweeps: weights in registers, head outside the recurrence
+        const int KP = n_actions <= 16 ? 16 : 32;
+        const size_t lf = gru2_fwd_lds_bytes(KP), lb = gru2_bwd_lds_bytes();
+#define CM_GRU2_F(WV_, KP_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf); \
+        hipLaunchKernelGGL((k_gru2_fwd<WV_, KP_>), dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a); } while (0)
+        if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
+        else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
+#undef CM_GRU2_F
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);
         CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");

@@ -14,7 +14,7 @@
 //     steps at a time on the MFMA (64 (row, step) items per pass) and hands the backward sweep a ready dh_head[s] tile in the
 //     workspace.  The backward step loses its head phase (2 barriers, a 128-thread VALU GEMV) and its weight staging (6 barriers).
 //   * 4 barriers per step in both sweeps (were 7 / 12).
-// Limits: K <= 16 actions, din <= 64, H <= 64 (the dispatcher keeps the first-generation kernels for anything else).
+// Limits: K <= 32 actions (head padded to 16 or 32), din <= 64, H <= 64 (the dispatcher keeps the first-generation kernels for anything else).
 // Workspace: 7 slots per (step, row): x1 | r | z | n | W_hn h + b_hn | h' | dh_head.
 #pragma once
 
@@ -24,7 +24,6 @@
 #define PH2_FLUSH(base)
 #endif
 constexpr int WS2 = 7 * HP;
-constexpr int KP2 = 16;  // padded head width of the v2 kernels
 
 // B-operand register image, "nt" form (Y = A W^T): w[4j + i] = W[(n0 + r) * ld + 8j + 4h + i], zero outside [nrows) x [ncols)
 template <bool VEC>
@@ -75,11 +74,13 @@ __device__ __forceinline__ void rowpar_rb(f32x16& acc, const float* As, const fl
     }
 }
 
-constexpr int g2f_lds_floats() { return 8 * T32 * LDT + TM * LDT + KP2 * WLD + 2 * TM * KP2 + KMAX + 2 * NTHREADS; }
-inline size_t gru2_fwd_lds_bytes() { return (size_t)g2f_lds_floats() * sizeof(float); }
+constexpr int g2f_lds_floats(int KP) { return 8 * T32 * LDT + TM * LDT + KP * WLD + 2 * TM * KP + KMAX + 2 * NTHREADS; }
+inline size_t gru2_fwd_lds_bytes(int KP) { return (size_t)g2f_lds_floats(KP) * sizeof(float); }
 
-template <bool WV>
+// KP: padded head width, 16 (K <= 16) or 32
+template <bool WV, int KP>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
+    constexpr int KJ = KP / 4, NCT = KP / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GruOff off = gru_offsets(a.din, a.H, a.K);
     float* p = smem;
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
     float* SN = p; p += T32 * LDT;
     float* SG = p; p += T32 * LDT;   // W_hn h + b_hn
     float* HB = p; p += TM * LDT;    // head pass: relu(h') of two steps (64 items), then dh_head
-    float* wouts = p; p += KP2 * WLD;
-    float* ls = p; p += TM * KP2;    // logits of the 64 items
-    float* ls2 = p; p += TM * KP2;   // dlogits of the 64 items
+    float* wouts = p; p += KP * WLD;
+    float* ls = p; p += TM * KP;     // logits of the 64 items
+    float* ls2 = p; p += TM * KP;    // dlogits of the 64 items
     float* b2 = p; p += KMAX;
     float* red = p;                  // 2 * NTHREADS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
     // ---- one-time: this wave's weight columns -> registers, head weights + biases -> LDS
     G2W w;
     g2_load_weights<WV>(w, a.params, off, din, H);
-    for (int i = tid; i < KP2 * WLD; i += NTHREADS) {
+    for (int i = tid; i < KP * WLD; i += NTHREADS) {
         const int k = i / WLD, c = i % WLD;
         wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
     }
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
 
     PH_DECL
     float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
-    f32x4 accWo = {0.f, 0.f, 0.f, 0.f};  // dW2[k = 4 (lane >> 4) + q][hidden column 16 wave + (lane & 15)]
+    f32x4 accWo[NCT];  // dW2[k = 16 ct + 4 (lane >> 4) + q][hidden column 16 wave + (lane & 15)]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accWo[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbo = 0.f;
     const long ntiles = (R + T32 - 1) / T32;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -187,12 +190,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
         head_load(0);  // the rows were written by this workgroup: the __syncthreads() above made them visible
         // per-item inputs of a pass (4 lanes per (row, step) item), also requested one pass ahead and BEFORE the previous pass's dh_head
         // stores: queued behind those the loads stalled the wave ~1800 cycles per pass at issue
-        struct Item { unsigned char avb[4]; int act; float lpo, advv; };
+        struct Item { unsigned char avb[KJ]; int act; float lpo, advv; };
         auto item_load = [&](int sA, Item& it) {
             const int s_i = sA + (hrow >> 5), t_i = a.t0 + s_i;
             const bool ok = rvalid && s_i < CL;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < KJ; ++j) {
                 it.avb[j] = 1;
                 if (ok && 4 * j + hq < K) it.avb[j] = a.avail[(grow * T + t_i) * K + 4 * j + hq];
             }
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
         for (int s0 = 0; s0 < CL; s0 += 2) {
             const int s_it = s0 + (hrow >> 5), t_it = a.t0 + s_it;
             const bool ivalid = rvalid && s_it < CL;
-            unsigned char avb[4];
+            unsigned char avb[KJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) avb[j] = cur.avb[j];
+            for (int j = 0; j < KJ; ++j) avb[j] = cur.avb[j];
             const int act = cur.act;
             const float lpo = cur.lpo, advv = cur.advv;
             lds_barrier();  // HB / ls / ls2 of the previous pass are dead
@@ -222,32 +225,35 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
             if (s0 + 2 < CL) head_load(s0 + 2);
             lds_barrier();
             PH(7);
-            {   // logits on the 16x16x4 MFMA: wave w = items 16w..16w+15
-                const f32x4 lg = head_logits_mfma(HB + 16 * wave * LDT, wouts);
+            {   // logits on the 16x16x4 MFMA: wave w = items 16w..16w+15, one call per 16 head outputs
                 const int n = lane & 15, g4 = lane >> 4;
-                const float bias = b2[n];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * KP2 + n] = lg[q] + bias;
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const f32x4 lg = head_logits_mfma(HB + 16 * wave * LDT, wouts + 16 * ct * WLD);
+                    const float bias = b2[16 * ct + n];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * KP + 16 * ct + n] = lg[q] + bias;
+                }
             }
             lds_barrier();
             PH(8);
             {   // PPO clipped-surrogate head (arithmetic of k_gru32_chunk_fwd): statistics + dlogits -> ls2
-                float zreg[4];
+                float zreg[KJ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) zreg[j] = (4 * j + hq < K && avb[j]) ? ls[hrow * KP2 + 4 * j + hq] : -1e9f;
+                for (int j = 0; j < KJ; ++j) zreg[j] = (4 * j + hq < K && avb[j]) ? ls[hrow * KP + 4 * j + hq] : -1e9f;
                 const bool valid = ivalid && t_it < eplen;
                 float m = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
                 m = quad_max(m);
-                float ssum = 0.0f, pj[4];
+                float ssum = 0.0f, pj[KJ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
+                for (int j = 0; j < KJ; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
                 ssum = quad_sum(ssum);
                 const float lse = m + logf(ssum), rs = 1.0f / ssum;
                 float ent = 0.f, lpa = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (4 * j + hq < K) {
+                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) {
                     const float lp = zreg[j] - lse;
                     pj[j] *= rs; ent -= pj[j] * lp;
                     if (4 * j + hq == act) lpa = lp;
@@ -265,32 +271,34 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
                 }
                 const float gr = gsel * ratio;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KJ; ++j) {
                     const int k = 4 * j + hq;
                     float d = 0.f;
                     if (k < K && valid && zreg[j] > -5e8f) {
                         const float lp = zreg[j] - lse;
                         d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
                     }
-                    ls2[hrow * KP2 + k] = d;
+                    ls2[hrow * KP + k] = d;
                 }
             }
             lds_barrier();
             PH(9);
             // fc2 gradient: dW2 += dlogits^T relu(h') over the 64 items (wave = 16 hidden columns), db2 += column sums
-            colred_head16<KP2>(accWo, ls2, 0, HB + 16 * wave);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) colred_head16<KP>(accWo[ct], ls2, 16 * ct, HB + 16 * wave);
             {
-                const int k = tid & 15, part = tid >> 4;
+                constexpr int PARTS = NTHREADS / KP, RPP = TM / PARTS;
+                const int k = tid % KP, part = tid / KP;
                 float sb = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sb += ls2[(part * 4 + r) * KP2 + k];
+                for (int r = 0; r < RPP; ++r) sb += ls2[(part * RPP + r) * KP + k];
                 dbo += sb;
             }
             // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .., columns 32 wn ..
             f32x16 dh;
 #pragma unroll
             for (int i = 0; i < 16; ++i) dh[i] = 0.0f;
-            head_bwd_mfma<KP2>(dh, ls2 + 32 * g * KP2, wouts + 32 * wn);
+            head_bwd_mfma<KP>(dh, ls2 + 32 * g * KP, wouts + 32 * wn);
             lds_barrier();  // every read of HB (fc2 gradient) is done: it becomes the dh_head tile
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -315,18 +323,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
     {
         const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 4 * g4 + r, c = 16 * wave + n;
-            if (k < K && c < H) out[off.W2 + k * H + c] = accWo[r];
-        }
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * ct + 4 * g4 + r, c = 16 * wave + n;
+                if (k < K && c < H) out[off.W2 + k * H + c] = accWo[ct][r];
+            }
     }
     __syncthreads();
-    red[tid] = dbo;  // [16 parts][16 k]
+    red[tid] = dbo;  // [NTHREADS / KP parts][KP]
     __syncthreads();
     if (tid < K) {
         float sb = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) sb += red[q * 16 + tid];
+        for (int q = 0; q < NTHREADS / KP; ++q) sb += red[q * KP + tid];
         out[off.b2 + tid] = sb;
     }
     float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
