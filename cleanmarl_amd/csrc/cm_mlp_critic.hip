@@ -1,5 +1,6 @@
 // cm_mlp_critic.hip -- cm_critic_fwd_bwd (a8/a9, critic side); schedules in cm_mlp_split.h
 #include "cm_mlp_wide.h"
+#include "cm_critic_fused.h"
 
 extern "C" size_t cm_critic_workspace_bytes(int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers) {
     const long rows = per_agent ? (long)E * A * T : (long)E * T;
@@ -22,6 +23,11 @@ extern "C" int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* r
     a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = 1;
     a.params = params; a.ret = ret; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = per_agent ? 1 : 0;
     if (wide) return wide_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
+    // wide inputs (129 .. 448 columns, one hidden layer): ONE pass over the input with W0 and dW0 in registers (cm_critic_fused.h);
+    // CM_CRITIC_SCHEDULE=split keeps the two-kernel schedule of cm_mlp_split.h (A/B runs, tests)
+    const char* sched = getenv("CM_CRITIC_SCHEDULE");
+    if (critic_fused_shape(a) && !(sched && strcmp(sched, "split") == 0))
+        return run_critic_fused(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
     return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
 }
 extern "C" int cm_critic_fwd_bwd(const float* x, const float* ret, const int32_t* ep_len,

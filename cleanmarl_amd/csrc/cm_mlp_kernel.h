@@ -1063,7 +1063,7 @@ inline int grid_for(long rows, int nch = 0) {
 // 16-byte tile loads need 16-byte aligned rows of the input (leading dimension a multiple of 4 floats, >= din rounded up: the quad that
 // straddles din reads zero padding) AND of W0 wherever W0 is tile-loaded, i.e. streamed: its own rows when din % 4 == 0, else the
 // padded image of prep_w0_image; a single-chunk input (din <= 64) keeps W0 in LDS and never tile-loads it.
-inline bool x_rows_vec(const MlpArgs& a) {
+__host__ __device__ inline bool x_rows_vec(const MlpArgs& a) {
     return (a.x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && a.x_stride >= (a.din + 3) / 4 * 4;
 }
 inline bool can_vec(const MlpArgs& a) {

@@ -89,6 +89,13 @@ def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
     ("mappo", 37, 3, 25, 21, 54, 5, 64, 1),     # config-1/2 shapes, ragged tile edge
     ("mappo", 16, 8, 32, 56, 384, 5, 64, 1),    # config-3 shapes (6 input chunks for the critic)
+    # the register-resident wide-input critic (csrc/cm_critic_fused.h) at every chunk count it serves, ragged rows, narrow H
+    ("mappo", 11, 3, 13, 21, 150, 5, 64, 1),    # 3 chunks (config-5 state width), 4-float aligned after padding only
+    ("mappo", 7, 2, 29, 24, 200, 4, 48, 1),     # 4 chunks, H = 48
+    ("mappo", 5, 3, 41, 24, 300, 4, 64, 1),     # 5 chunks
+    ("ippo", 6, 3, 20, 140, 10, 5, 64, 1),      # per-agent critic on a 140-wide observation (3 chunks), 3-chunk actor
+    ("mappo", 4, 11, 23, 24, 260, 4, 64, 1),    # 11 agents: targets beyond the 8 prefetched ones
+    ("mappo", 300, 2, 30, 24, 448, 4, 64, 1),   # 7 chunks, 282 row tiles over 256 workgroups (second pass of the tile loop)
     ("ippo", 12, 10, 40, 115, 243, 17, 64, 1),  # config-4 shapes (2 chunks, 17 actions, avail masks)
     ("mappo", 9, 2, 17, 70, 140, 6, 32, 2),     # H=32 padded to 64, 2 hidden layers, 2/3 chunks
     ("ippo", 5, 3, 8, 7, 11, 3, 48, 0),         # no hidden->hidden layer, odd H

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cleanmarl_amd import _native as N  # noqa: E402
 
-N.LIB_PATH = os.path.join(ROOT, "cleanmarl_amd", "libcleanmarl_hip_prof.so")
+N.LIB_PATH = os.environ.get("CM_PROF_LIB", os.path.join(ROOT, "cleanmarl_amd", "libcleanmarl_hip_prof.so"))
 lib = N.load()
 lib.cm_prof_set_buffer.argtypes = [C.c_void_p]
 which = sys.argv[1] if len(sys.argv) > 1 else "actor"
@@ -101,6 +101,14 @@ if which == "rollout":
     print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase ({used.shape[0]} WGs):")
     for i, n in enumerate(names):
         print(f"  {n:24s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+    print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
+    sys.exit(0)
+if which == "critic" and os.environ.get("CM_CRITIC_SCHEDULE") != "split" and 128 < Ds <= 448:  # csrc/cm_critic_fused.h
+    names = ["fwd_L0 (X -> LDS, NC chunks)", "h0 -> LDS", "fwd_L1 + value", "loss", "dZ1 -> LDS", "dW1", "dH0 + dZ0 -> LDS", "dW0", "barrier_end"]
+    tiles_per_wg = E * T / 64 / 256
+    print(f"critic (fused): {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks per tile:")
+    for i, n in enumerate(names):
+        print(f"  {n:30s} {float(ph[i]) / tiles_per_wg:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
     print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
     sys.exit(0)
 names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
