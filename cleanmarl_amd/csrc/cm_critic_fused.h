@@ -388,6 +388,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
     }
 }
 
+constexpr long CM_FUSED_MIN_ROWS = 131072;  // 8 row tiles per CU; below, the split schedule of cm_mlp_split.h is as fast or faster
 inline bool critic_fused_shape(const MlpArgs& a) {
     const int nc = (a.din + KC - 1) / KC;
     return nc >= 3 && nc <= 7 && a.H <= HP && a.L == 1 && a.dout == 1 && x_rows_vec(a) && !mfma_bf16x3();  // 8 chunks: 177 KB of LDS

@@ -24,9 +24,12 @@ extern "C" int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* r
     a.params = params; a.ret = ret; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = per_agent ? 1 : 0;
     if (wide) return wide_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
     // wide inputs (129 .. 448 columns, one hidden layer): ONE pass over the input with W0 and dW0 in registers (cm_critic_fused.h);
-    // CM_CRITIC_SCHEDULE=split keeps the two-kernel schedule of cm_mlp_split.h (A/B runs, tests)
+    // -- from CM_FUSED_MIN_ROWS rows on: the kernel wants whole CUs (one 256-thread workgroup with 512 registers per lane and ~140 KB
+    // of LDS), so a small batch neither amortises its per-workgroup prologue / partial-gradient row nor shares CUs with the rollout
+    // it is overlapped with (learner.overlap_critic).  CM_CRITIC_SCHEDULE=fused / split force either schedule (A/B runs, tests).
     const char* sched = getenv("CM_CRITIC_SCHEDULE");
-    if (critic_fused_shape(a) && !(sched && strcmp(sched, "split") == 0))
+    const bool force_fused = sched && strcmp(sched, "fused") == 0, force_split = sched && strcmp(sched, "split") == 0;
+    if (critic_fused_shape(a) && !force_split && (force_fused || a.rows >= CM_FUSED_MIN_ROWS))
         return run_critic_fused(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
     return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
 }

@@ -663,15 +663,15 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
 #endif
     const int EPT = TM / A;
     const int ntiles = (E + EPT - 1) / EPT;
-    // Few 64-row tiles (a GPU's share of a sharded batch, config 2) leave most CUs idle and every step a 64-row serial chain: below
-    // 1.5 tiles per CU the 16-row form runs instead (same arithmetic; CM_ROLLOUT_TILE=16 / 64 forces one for A/B runs and tests)
+    // Few 64-row tiles (a GPU's share of a sharded batch, config 2) leave most CUs idle and every step a 64-row serial chain: while
+    // all 16-row tiles are resident at once (768 workgroups; a second pass would double the time) the 16-row form runs instead (same arithmetic; CM_ROLLOUT_TILE=16 / 64 forces one for A/B runs and tests)
     const char* forced_s = getenv("CM_ROLLOUT_TILE");  // read per launch (tests flip it inside one process)
     const int forced = forced_s ? atoi(forced_s) : 0;
     const bool can16 = A <= TS;
-    const bool use16 = can16 && (forced == 16 || (forced != 64 && ntiles < 384));
+    const int EPT16 = can16 ? TS / A : 1;
+    const int nt16 = (E + EPT16 - 1) / EPT16;
+    const bool use16 = can16 && (forced == 16 || (forced != 64 && nt16 <= 768));  // one resident wave of 16-row workgroups (3 per CU)
     if (use16) {
-        const int EPT16 = TS / A;
-        const int nt16 = (E + EPT16 - 1) / EPT16;
         const size_t lds16 = ((size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 16 + (size_t)TS * LDT * 2 + TS * 2 * 3 + 4 * TS + 2 * TS) * sizeof(float);
         const int grid16 = nt16 < 768 ? nt16 : 768;  // ~49 KB of LDS: three workgroups per CU
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);

@@ -370,17 +370,20 @@ class PPOLearner:
         """Schedule of update(): 0 = both networks interleaved on the current stream; 2 = the critic's epochs on a second,
         LOWEST-priority stream released at the start of the update and not joined there -- its kernels take the compute units
         the actor's kernels and, above all, the NEXT rollout leave idle (the rollout is a latency chain on a fraction of the chip);
-        1 = the same stream released only when the actor's epochs are done (kept for A/B runs: it loses to 2 everywhere).
+        1 = the same stream released only when the actor's epochs are done (wins for the smallest batches, where every kernel
+        leaves most of the chip idle and the critic's launches only delay the actor's).
         Measured (profiles/r02_critic_overlap_schedules.txt, ms per iteration, schedule 0 / 1 / 2): config 3 at 512 envs (one GPU's
         share of 8) 1.81 / 1.60 / 1.56, 1024 envs 2.92 / 2.98 / 2.77, 4096 envs 9.51 / 9.53 / 9.31; config 4 at 256 envs 4.10 / 4.19 /
-        3.91; config 2 1.44 / 1.30 / 1.32.  Default: 2 up to 2^21 rows, 0 above -- at full size the gain is 2 % and the actor kernel,
+        3.91; config 2 1.44 / 1.30 / 1.32; config 3 at 256 envs (a share of 16) 1.26 / 1.09 / 1.27.  Default: 1 up to 2^18 rows, 2 up to
+        2^21 rows, 0 above -- at full size the gain is 2 % and the actor kernel,
         the one the roofline is quoted on, would be timed with a second kernel beside it (1.87 -> 2.2 ms per launch).
         CM_CRITIC_OVERLAP=0 / 1 / 2 forces a schedule."""
         import os
         v = os.environ.get("CM_CRITIC_OVERLAP")
         if v in ("0", "1", "2"):
             return int(v)
-        return 2 if b.E * b.A * b.T <= (1 << 21) else 0
+        rows = b.E * b.A * b.T
+        return 1 if rows <= (1 << 18) else 2 if rows <= (1 << 21) else 0
 
     def update(self, b, keep_grads=False):
         """`epochs` full-batch PPO steps (cleanmarl/mappo_multienvs.py:521-594).  The two networks are independent (separate losses,

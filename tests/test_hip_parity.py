@@ -110,6 +110,21 @@ def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
     _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
 
 
+@pytest.fixture(autouse=True)
+def _fused_critic_at_test_sizes(monkeypatch):
+    """The one-pass wide-input critic (csrc/cm_critic_fused.h) is selected from 131072 rows on; the cases of this module are far
+    smaller, so they force it wherever its shape rules allow (129..448 aligned input columns, one hidden layer) -- the two-kernel
+    schedule it replaces keeps its own cases below."""
+    monkeypatch.setenv("CM_CRITIC_SCHEDULE", "fused")
+
+
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [("mappo", 16, 8, 32, 56, 384, 5, 64, 1), ("mappo", 7, 2, 29, 24, 200, 4, 48, 1),
+                                                      ("ippo", 6, 3, 20, 140, 10, 5, 64, 1)])
+def test_wide_critic_split_schedule_matches_oracle(algo, E, A, T, Do, Ds, K, H, L, monkeypatch):
+    monkeypatch.setenv("CM_CRITIC_SCHEDULE", "split")  # what batches below 131072 rows run
+    _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
+
+
 def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize):
     from oracle import restatement as R
     from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch

@@ -96,7 +96,7 @@ if which == "rollout":
     used = prof[(prof.sum(1) > 0)]
     ph = used.double().mean(0).cpu(); tot = float(ph.sum())
     names = ["barrier_top", "obs+reward_partials", "buffer_writes", "fwd_mlp", "head_logits(mfma)", "sample+physics"]
-    if os.environ.get("CM_ROLLOUT_TILE") == "16" or (os.environ.get("CM_ROLLOUT_TILE") != "64" and (E + 64 // A - 1) // (64 // A) < 384):
+    if os.environ.get("CM_ROLLOUT_TILE") == "16" or (os.environ.get("CM_ROLLOUT_TILE") != "64" and (E + 16 // A - 1) // (16 // A) <= 768):
         names = ["barrier_top", "reward_partials+obs", "buffer_writes+philox", "layer0", "layer1", "head(mfma)", "sample+physics"]
     print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase ({used.shape[0]} WGs):")
     for i, n in enumerate(names):
