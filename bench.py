@@ -318,7 +318,7 @@ def main():
             rec = {}
             for g in (2, 4, 8):
                 ww = Workload(name, Eg // g, 0, dev)
-                rr = ww.run(10, 3)
+                rr = ww.run(20, 6)
                 rec[f"1/{g} ({Eg // g} envs)"] = dict(ms_per_step=rr["ms_per_step"], phase_ms=rr["phase_ms"],
                                                       speedup_bound=full_ms[name] / rr["ms_per_step"])
                 ww.close()
