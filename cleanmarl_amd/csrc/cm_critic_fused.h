@@ -12,7 +12,7 @@
 //     relu' masks and the head's dot product); LDS carries only what other waves need (H0, dZ1, dZ0 tiles).
 // One workgroup per CU (registers: 2 x 16 x NC + ~120), the next tile's first two X chunks in flight in registers during the backward
 // phases.  Same un-normalised sums and statistic slots as k_mlp<.., M_CRITIC>; summation order differs (tolerance-tested, 1e-4).
-// Shapes: Din = 129 .. 448 (NC = 3 .. 7 chunks of 64), H <= 64, ONE hidden->hidden layer, scalar output; others keep the split schedule.
+// Shapes: Din = 65 .. 448 (NC = 2 .. 7 chunks of 64), H <= 64, ONE hidden->hidden layer, scalar output; others keep the split schedule.
 #pragma once
 #include "cm_mlp_train.h"
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
         // products finds every wave's stores long finished (one exposed store + barrier per tile instead of one per chunk)
         f32x4 z0[4] = {zero4, zero4, zero4, zero4};
         xstore(XS, pa);
-        xload(pa, tile, 2);
+        if (NC > 2) xload(pa, tile, 2); else xload(pa, min(ntile, ntiles - 1), 0);
         __syncthreads();
         const unsigned xa_f = cf_lds_addr(XS + n * LDT + 4 * g);  // forward A operand: rows 16 rb + n, columns 16 j + 4 g ..
         f32x4 xr[2][2];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
 constexpr long CM_FUSED_MIN_ROWS = 131072;  // 8 row tiles per CU; below, the split schedule of cm_mlp_split.h is as fast or faster
 inline bool critic_fused_shape(const MlpArgs& a) {
     const int nc = (a.din + KC - 1) / KC;
-    return nc >= 3 && nc <= 7 && a.H <= HP && a.L == 1 && a.dout == 1 && x_rows_vec(a) && !mfma_bf16x3();  // 8 chunks: 177 KB of LDS
+    return nc >= 2 && nc <= 7 && a.H <= HP && a.L == 1 && a.dout == 1 && x_rows_vec(a) && !mfma_bf16x3();  // 8 chunks: 177 KB of LDS
 }
 inline size_t critic_fused_lds_bytes(int nc) { return (size_t)(nc * TM * LDT + 2 * TM * LDT + 5 * TM + 2 * NTHREADS) * sizeof(float); }
 
@@ -412,7 +412,7 @@ inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t w
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_fused<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k_critic_fused<NC_>, dim3(grid), dim3(NTHREADS), lds, s, a); } while (0)
     switch (nc) {
-        case 3: CM_CF(3); break; case 4: CM_CF(4); break; case 5: CM_CF(5); break;
+        case 2: CM_CF(2); break; case 3: CM_CF(3); break; case 4: CM_CF(4); break; case 5: CM_CF(5); break;
         case 6: CM_CF(6); break; default: CM_CF(7); break;
     }
 #undef CM_CF

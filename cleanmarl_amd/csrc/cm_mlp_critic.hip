@@ -23,7 +23,7 @@ extern "C" int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* r
     a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = 1;
     a.params = params; a.ret = ret; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = per_agent ? 1 : 0;
     if (wide) return wide_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
-    // wide inputs (129 .. 448 columns, one hidden layer): ONE pass over the input with W0 and dW0 in registers (cm_critic_fused.h);
+    // wide inputs (65 .. 448 columns, one hidden layer): ONE pass over the input with W0 and dW0 in registers (cm_critic_fused.h);
     // -- from CM_FUSED_MIN_ROWS rows on: the kernel wants whole CUs (one 256-thread workgroup with 512 registers per lane and ~140 KB
     // of LDS), so a small batch neither amortises its per-workgroup prologue / partial-gradient row nor shares CUs with the rollout
     // it is overlapped with (learner.overlap_critic).  CM_CRITIC_SCHEDULE=fused / split force either schedule (A/B runs, tests).
