@@ -132,10 +132,31 @@ def stream_ptr(stream=None):
     return C.c_void_p(s.cuda_stream)
 
 
+_LOW_PRIORITY = {}
+
+
 def low_priority_stream(device):
-    """torch view (ExternalStream) of a lowest-priority HIP stream created by the library; lives for the process."""
+    """torch view (ExternalStream) of a lowest-priority HIP stream created by the library: ONE per device and process, shared by every
+    learner.  HIP multiplexes its streams onto a handful of hardware queues; a process that kept creating streams (bench.py builds a
+    learner per workload) ended up with a "second" stream on the default stream's queue -- the critic's epochs then ran serialised
+    with the actor's (1024-env share of config 3: 3.5 ms instead of 2.7)."""
     import torch
-    h = load().cm_stream_create_low_priority()
-    if not h:
-        raise NativeError("cm_stream_create_low_priority failed: " + (load().cm_last_error() or b"?").decode())
-    return torch.cuda.ExternalStream(h, device=device)
+    key = torch.device(device).index or 0
+    if key not in _LOW_PRIORITY:
+        h = load().cm_stream_create_low_priority()
+        if not h:
+            raise NativeError("cm_stream_create_low_priority failed: " + (load().cm_last_error() or b"?").decode())
+        _LOW_PRIORITY[key] = torch.cuda.ExternalStream(h, device=device)
+    return _LOW_PRIORITY[key]
+
+
+_SIDE = {}
+
+
+def side_stream(device):
+    """A normal-priority second stream, one per device and process (same reason as low_priority_stream)."""
+    import torch
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]

@@ -54,7 +54,7 @@ class GRUPPOLearner(PPOLearner):
         # ranks, so the collectives still pair up.
         main = torch.cuda.current_stream()
         if self._critic_stream is None:
-            self._critic_stream = torch.cuda.Stream(device=self.device)
+            self._critic_stream = N.side_stream(self.device)  # one per process: see _native.low_priority_stream
         side = self._critic_stream
         self.wait_critic()
         side.wait_stream(main)
