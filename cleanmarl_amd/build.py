@@ -56,9 +56,53 @@ def build_native(force=False, verbose=False, out=None, extra_flags=()):
     return out
 
 
+ASM_DIR = os.path.join(HERE, "build", "asm")
+HAND_PIPELINED = ("cm_mlp_critic.hip", "cm_gru.hip")  # translation units that use cm_common.h's cf_lds128 / cf_wait
+
+
+def emit_asm(force=False):
+    """Device assembly (hipcc -S --cuda-device-only) of the translation units with hand-issued LDS reads, for
+    tools/lint_lds_hazards.py.  Returns the .s paths; up-to-date files are kept."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(ASM_DIR, exist_ok=True)
+    deps = glob.glob(os.path.join(CSRC, "*.h"))
+
+    def one(name):
+        src, out = os.path.join(CSRC, name), os.path.join(ASM_DIR, name + ".s")
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps + [src]):
+            return out
+        cmd = [HIPCC] + [f for f in FLAGS if f not in ("-shared", "-fPIC")] + ["-S", "--cuda-device-only", src, "-o", out + ".tmp"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed on {src}:\n" + r.stdout + r.stderr)
+        os.replace(out + ".tmp", out)
+        return out
+    with ThreadPoolExecutor(max_workers=len(HAND_PIPELINED)) as ex:
+        return list(ex.map(one, HAND_PIPELINED))
+
+
+def lint_hand_pipelines(force=False):
+    """emit_asm + the in-flight-register check; raises on a hazard.  Returns (hand-issued reads, kernels) checked."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lint_lds_hazards", os.path.join(HERE, "..", "tools", "lint_lds_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    reads = kernels = 0
+    for f in emit_asm(force):
+        probs, nk, nhand = mod.lint_file(f)
+        if probs:
+            raise RuntimeError(f"{os.path.basename(f)}: registers of in-flight LDS reads are touched before their s_waitcnt:\n  " + "\n  ".join(probs[:10]))
+        reads, kernels = reads + nhand, kernels + nk
+    if reads == 0:
+        raise RuntimeError("lint_hand_pipelines: no hand-issued LDS read found -- the asm markers changed?")
+    return reads, kernels
+
+
 if __name__ == "__main__":
     import sys
-    if "--prof" in sys.argv:  # phase-profiling build used by tools/phase_prof.py
+    if "--asm" in sys.argv:
+        print("hand-issued LDS reads / kernels checked:", lint_hand_pipelines(force=True))
+    elif "--prof" in sys.argv:  # phase-profiling build used by tools/phase_prof.py
         print(build_native(force=True, out=os.path.join(HERE, "libcleanmarl_hip_prof.so"), extra_flags=["-DCM_PHASE_PROF"]))
     else:
         print(build_native(force=True, verbose="-v" in sys.argv))

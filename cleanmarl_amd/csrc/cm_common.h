@@ -129,3 +129,19 @@ __device__ __forceinline__ double cm_wave_sum_d(double v) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS reads whose ISSUE ORDER is fixed in the source: for kernels that run one wave per SIMD (cm_critic_fused.h, the GRU sweeps), where nothing hides LDS latency unless a read is
+// issued a step or two ahead of the MFMAs that consume it -- and the compiler, at the register limit, schedules every ds_read next to
+// its use (read, s_waitcnt lgkmcnt(0), 4 MFMAs: measured 39 cycles per 32-cycle MFMA).  The reads are therefore inline asm (kept in
+// program order) and waited for by hand: cf_wait<N>(v) = "at most N younger LDS operations still in flight", tied to the value so
+// the consuming MFMAs cannot move above it.  lgkmcnt retires LDS operations in order, so LDS operations the compiler adds in between
+// only make these waits (and the compiler's own) more conservative.
+template <int OFF> __device__ __forceinline__ f32x4 cf_lds128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void cf_wait(f32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
+template <int N> __device__ __forceinline__ void cf_wait(f32x4& v, f32x4& w) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(w) : "n"(N)); }
+__device__ __forceinline__ unsigned cf_lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }  // low 32 bits of a flat LDS address = LDS offset
+

@@ -26,21 +26,6 @@ __device__ __forceinline__ float cf_row16_sum(float v) {
     return v;
 }
 
-// LDS reads whose ISSUE ORDER is fixed in the source: the kernel runs one wave per SIMD, so nothing hides LDS latency unless a read is
-// issued a step or two ahead of the MFMAs that consume it -- and the compiler, at the register limit, schedules every ds_read next to
-// its use (read, s_waitcnt lgkmcnt(0), 4 MFMAs: measured 39 cycles per 32-cycle MFMA).  The reads are therefore inline asm (kept in
-// program order) and waited for by hand: cf_wait<N>(v) = "at most N younger LDS operations still in flight", tied to the value so
-// the consuming MFMAs cannot move above it.  lgkmcnt retires LDS operations in order, so LDS operations the compiler adds in between
-// only make these waits (and the compiler's own) more conservative.
-template <int OFF> __device__ __forceinline__ f32x4 cf_lds128(unsigned addr) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N> __device__ __forceinline__ void cf_wait(f32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
-template <int N> __device__ __forceinline__ void cf_wait(f32x4& v, f32x4& w) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(w) : "n"(N)); }
-__device__ __forceinline__ unsigned cf_lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }  // low 32 bits of a flat LDS address = LDS offset
-
 // [64 rows x 64 k] (LDS, A operand) x [64 k x 16 own columns] (registers, B operand) in 8 steps of 8 MFMAs: step s = 16 k (s >> 1) x 32
 // rows (s & 1), two 16-byte reads per step into the ring xr[2][2], issued one step ahead.  base = cf_lds_addr(tile + n * LDT + 4 * g).
 #define CF_LD2(xr, base, s_) do { (xr)[(s_) & 1][0] = cf_lds128<(32 * ((s_) & 1) * LDT + 16 * ((s_) >> 1)) * 4>(base); \

@@ -50,37 +50,59 @@ __device__ __forceinline__ void g2_load_weights(G2W& w, const float* params, con
     w.bin = ok ? params[off.bih + 2 * H + c] : 0.0f;
     w.bhn = ok ? params[off.bhh + 2 * H + c] : 0.0f;
 }
-// three products that share their A operand: acc_p[rb] += A[16 rb + ..][16 kb] * W_p^T, p = 0..2, rb = 0..1 (six independent chains)
+// three products that share their A operand: acc_p[rb] += A[16 rb + ..][16 kb] * W_p^T, p = 0..2, rb = 0..1 (six independent chains).
+// The sweeps run ONE wave per SIMD, so the A-operand reads of k block j + 1 are issued (inline asm, cm_common.h) BEFORE the 24 MFMAs of
+// block j: left to the compiler they followed them, and every block started with an exposed LDS round trip (~100 of its 770 cycles).
+#define CM_G2_LD(j_) do { xa[(j_) & 1] = cf_lds128<16 * (j_) * 4>(ab); ya[(j_) & 1] = cf_lds128<(16 * LDT + 16 * (j_)) * 4>(ab); } while (0)
 __device__ __forceinline__ void g2_prod3(f32x4 (&a0)[2], f32x4 (&a1)[2], f32x4 (&a2)[2], const float* As,
                                          const float (&w0)[16], const float (&w1)[16], const float (&w2)[16]) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const float4* ap0 = reinterpret_cast<const float4*>(As + n * LDT + 4 * g);
-    const float4* ap1 = reinterpret_cast<const float4*>(As + (16 + n) * LDT + 4 * g);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 x = ap0[4 * j], y = ap1[4 * j];
-#define CM_G2_K(c, i) do { \
-        a0[0] = mfma16(x.c, w0[4 * j + i], a0[0]); a1[0] = mfma16(x.c, w1[4 * j + i], a1[0]); a2[0] = mfma16(x.c, w2[4 * j + i], a2[0]); \
-        a0[1] = mfma16(y.c, w0[4 * j + i], a0[1]); a1[1] = mfma16(y.c, w1[4 * j + i], a1[1]); a2[1] = mfma16(y.c, w2[4 * j + i], a2[1]); } while (0)
-        CM_G2_K(x, 0); CM_G2_K(y, 1); CM_G2_K(z, 2); CM_G2_K(w, 3);
+    const unsigned ab = cf_lds_addr(As + n * LDT + 4 * g);
+    f32x4 xa[2], ya[2];
+#define CM_G2_K(j_, i) do { \
+        a0[0] = mfma16(x[i], w0[4 * (j_) + i], a0[0]); a1[0] = mfma16(x[i], w1[4 * (j_) + i], a1[0]); a2[0] = mfma16(x[i], w2[4 * (j_) + i], a2[0]); \
+        a0[1] = mfma16(y[i], w0[4 * (j_) + i], a0[1]); a1[1] = mfma16(y[i], w1[4 * (j_) + i], a1[1]); a2[1] = mfma16(y[i], w2[4 * (j_) + i], a2[1]); } while (0)
+#define CM_G2_BLOCK(j_, NEXT_) do { NEXT_; const f32x4 x = xa[(j_) & 1], y = ya[(j_) & 1]; \
+        CM_G2_K(j_, 0); CM_G2_K(j_, 1); CM_G2_K(j_, 2); CM_G2_K(j_, 3); } while (0)
+    CM_G2_LD(0);
+    CM_G2_BLOCK(0, CM_G2_LD(1); cf_wait<2>(xa[0], ya[0]));
+    CM_G2_BLOCK(1, CM_G2_LD(2); cf_wait<2>(xa[1], ya[1]));
+    CM_G2_BLOCK(2, CM_G2_LD(3); cf_wait<2>(xa[0], ya[0]));
+    CM_G2_BLOCK(3, cf_wait<0>(xa[1], ya[1]));
+#undef CM_G2_BLOCK
 #undef CM_G2_K
-    }
 }
 __device__ __forceinline__ void g2_prod1(f32x4 (&a0)[2], const float* As, const float (&w0)[16], int kb16) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const float4* ap0 = reinterpret_cast<const float4*>(As + n * LDT + 4 * g);
-    const float4* ap1 = reinterpret_cast<const float4*>(As + (16 + n) * LDT + 4 * g);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < kb16) {
-            const float4 x = ap0[4 * j], y = ap1[4 * j];
-            a0[0] = mfma16(x.x, w0[4 * j], a0[0]); a0[1] = mfma16(y.x, w0[4 * j], a0[1]);
-            a0[0] = mfma16(x.y, w0[4 * j + 1], a0[0]); a0[1] = mfma16(y.y, w0[4 * j + 1], a0[1]);
-            a0[0] = mfma16(x.z, w0[4 * j + 2], a0[0]); a0[1] = mfma16(y.z, w0[4 * j + 2], a0[1]);
-            a0[0] = mfma16(x.w, w0[4 * j + 3], a0[0]); a0[1] = mfma16(y.w, w0[4 * j + 3], a0[1]);
-        }
+    const unsigned ab = cf_lds_addr(As + n * LDT + 4 * g);
+    f32x4 xa[2], ya[2];
+#define CM_G2_BLOCK1(j_, NEXT_) do { NEXT_; const f32x4 x = xa[(j_) & 1], y = ya[(j_) & 1]; \
+        a0[0] = mfma16(x[0], w0[4 * (j_)], a0[0]);     a0[1] = mfma16(y[0], w0[4 * (j_)], a0[1]); \
+        a0[0] = mfma16(x[1], w0[4 * (j_) + 1], a0[0]); a0[1] = mfma16(y[1], w0[4 * (j_) + 1], a0[1]); \
+        a0[0] = mfma16(x[2], w0[4 * (j_) + 2], a0[0]); a0[1] = mfma16(y[2], w0[4 * (j_) + 2], a0[1]); \
+        a0[0] = mfma16(x[3], w0[4 * (j_) + 3], a0[0]); a0[1] = mfma16(y[3], w0[4 * (j_) + 3], a0[1]); } while (0)
+    // kb16 is uniform: blocks past it are skipped (their weights are zero anyway).  Every case is ONE straight-line pipeline with its
+    // first read inside: a read issued ahead of a branch would be copied by the compiler (phi) while still in flight -- the linter
+    // tools/lint_lds_hazards.py checks the generated code for exactly that
+    switch (kb16) {
+        case 1:
+            CM_G2_LD(0); CM_G2_BLOCK1(0, cf_wait<0>(xa[0], ya[0]));
+            break;
+        case 2:
+            CM_G2_LD(0); CM_G2_BLOCK1(0, CM_G2_LD(1); cf_wait<2>(xa[0], ya[0])); CM_G2_BLOCK1(1, cf_wait<0>(xa[1], ya[1]));
+            break;
+        case 3:
+            CM_G2_LD(0); CM_G2_BLOCK1(0, CM_G2_LD(1); cf_wait<2>(xa[0], ya[0])); CM_G2_BLOCK1(1, CM_G2_LD(2); cf_wait<2>(xa[1], ya[1]));
+            CM_G2_BLOCK1(2, cf_wait<0>(xa[0], ya[0]));
+            break;
+        default:
+            CM_G2_LD(0); CM_G2_BLOCK1(0, CM_G2_LD(1); cf_wait<2>(xa[0], ya[0])); CM_G2_BLOCK1(1, CM_G2_LD(2); cf_wait<2>(xa[1], ya[1]));
+            CM_G2_BLOCK1(2, CM_G2_LD(3); cf_wait<2>(xa[0], ya[0])); CM_G2_BLOCK1(3, cf_wait<0>(xa[1], ya[1]));
+            break;
     }
+#undef CM_G2_BLOCK1
 }
+#undef CM_G2_LD
 // One step.  In: X0 = obs tile [32][LDT] (zero padded to 64 columns), hp = h_{t-1}.  Out: X1 = x1, hn = h'; with SAVE also the
 // tiles r, z, n, W_hn h + b_hn (SR, SZ, SN, SG) that the backward sweep needs.  Barriers: the caller's barrier BEFORE the call must
 // cover X0 / hp (and the previous readers of X1 / S* / hn); the function ends with the barrier that completes hn and the tiles.

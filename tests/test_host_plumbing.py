@@ -150,3 +150,28 @@ def test_rank_shards_of_host_vector_envs_are_distinct_and_tile_the_global_batch(
         got = s.arr["obs"].copy()
         s.close()
         assert np.allclose(got, want[off:off + 2])
+
+
+def test_hand_issued_lds_reads_are_never_touched_in_flight():
+    """csrc/cm_critic_fused.h and csrc/cm_gru_step2.h issue LDS reads through inline asm and wait for them by hand; the compiler
+    does not know they are asynchronous.  The generated assembly must not read or overwrite their destination registers, branch or
+    reach a label before the covering s_waitcnt (tools/lint_lds_hazards.py; a phi copy at a branch once did)."""
+    from cleanmarl_amd.build import lint_hand_pipelines
+    reads, kernels = lint_hand_pipelines()
+    assert reads >= 1000 and kernels >= 50
+
+
+def test_lds_hazard_linter_flags_a_copy_before_the_wait(tmp_path):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lint_lds_hazards.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    good = "k:\n\t;;#ASMSTART\n\tds_read_b128 v[4:7], v1 offset:0\n\t;;#ASMEND\n\tv_add_f32_e32 v9, v8, v8\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v2, v4\n\ts_endpgm\n"
+    bad = good.replace("v_add_f32_e32 v9, v8, v8", "v_mov_b64_e32 v[10:11], v[4:5]")
+    branch = good.replace("v_add_f32_e32 v9, v8, v8", "s_cbranch_vccz .LBB0_1")
+    for text, want in ((good, 0), (bad, 1), (branch, 1)):
+        f = tmp_path / "k.s"
+        f.write_text(text)
+        probs, nk, nhand = lint.lint_file(str(f))
+        assert nk == 1 and nhand == 1 and len(probs) == want, (text, probs)
