@@ -253,6 +253,11 @@ int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* ava
                             int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                             const float* params, double ppo_clip, double entropy_coef,
                             float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* cm_critic_fwd_bwd_ld picks one of three schedules with the same sums (summation order differs; parity tests at 1e-4): the fused tile
+ * kernel (din <= 128), the two-kernel split schedule (wider inputs) and -- for 65 .. 448 input columns on 16-byte aligned rows, one
+ * hidden layer, from 131072 rows on -- the one-pass kernel of csrc/cm_critic_fused.h, which reads x from HBM once.  The padding columns
+ * [din, x_ld) must hold FINITE values (the library's own rollouts write zeros): they meet zero weights, never a mask.
+ * Environment (read per call; for A/B runs and tests): CM_CRITIC_SCHEDULE=fused|split forces the one-pass / two-kernel schedule. */
 int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
                          int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                          const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
