@@ -25,12 +25,16 @@ def is_stale():
 
 def _compile(args):
     src, obj, extra, verbose = args
-    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + extra + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    # -save-temps=obj: the device assembly (<stem>-hip-amdgcn-amd-amdhsa-gfx950.s) lands next to the object for lint_hand_pipelines()
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-save-temps=obj"] + extra + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+    stem = os.path.join(os.path.dirname(obj), os.path.splitext(os.path.basename(src))[0])
+    for junk in glob.glob(stem + "-*.hipi") + glob.glob(stem + "-*.bc") + glob.glob(stem + "-host-*.s") + glob.glob(stem + "-*.out*"):
+        os.remove(junk)
     return obj
 
 
@@ -56,39 +60,25 @@ def build_native(force=False, verbose=False, out=None, extra_flags=()):
     return out
 
 
-ASM_DIR = os.path.join(HERE, "build", "asm")
-HAND_PIPELINED = ("cm_mlp_critic.hip", "cm_gru.hip")  # translation units that use cm_common.h's cf_lds128 / cf_wait
+def device_asm(lib=None):
+    """The device assembly files written next to the objects of the last build of `lib` (build_native compiles with -save-temps=obj)."""
+    objdir = os.path.join(HERE, "build", os.path.basename(lib or LIB) + ".obj")
+    return sorted(glob.glob(os.path.join(objdir, "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
 
 
-def emit_asm(force=False):
-    """Device assembly (hipcc -S --cuda-device-only) of the translation units with hand-issued LDS reads, for
-    tools/lint_lds_hazards.py.  Returns the .s paths; up-to-date files are kept."""
-    from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(ASM_DIR, exist_ok=True)
-    deps = glob.glob(os.path.join(CSRC, "*.h"))
-
-    def one(name):
-        src, out = os.path.join(CSRC, name), os.path.join(ASM_DIR, name + ".s")
-        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps + [src]):
-            return out
-        cmd = [HIPCC] + [f for f in FLAGS if f not in ("-shared", "-fPIC")] + ["-S", "--cuda-device-only", src, "-o", out + ".tmp"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc -S failed on {src}:\n" + r.stdout + r.stderr)
-        os.replace(out + ".tmp", out)
-        return out
-    with ThreadPoolExecutor(max_workers=len(HAND_PIPELINED)) as ex:
-        return list(ex.map(one, HAND_PIPELINED))
-
-
-def lint_hand_pipelines(force=False):
-    """emit_asm + the in-flight-register check; raises on a hazard.  Returns (hand-issued reads, kernels) checked."""
+def lint_hand_pipelines():
+    """tools/lint_lds_hazards.py over the assembly of every translation unit of the in-tree library (builds it first if its assembly is
+    missing or stale); raises on a hazard.  Returns (hand-issued LDS reads, kernels) checked."""
     import importlib.util
+    files = device_asm()
+    if is_stale() or len(files) != len(sources()) or any(os.path.getmtime(f) < os.path.getmtime(src) for f, src in zip(files, sources())):
+        build_native(force=True)
+        files = device_asm()
     spec = importlib.util.spec_from_file_location("lint_lds_hazards", os.path.join(HERE, "..", "tools", "lint_lds_hazards.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     reads = kernels = 0
-    for f in emit_asm(force):
+    for f in files:
         probs, nk, nhand = mod.lint_file(f)
         if probs:
             raise RuntimeError(f"{os.path.basename(f)}: registers of in-flight LDS reads are touched before their s_waitcnt:\n  " + "\n  ".join(probs[:10]))
@@ -100,8 +90,8 @@ def lint_hand_pipelines(force=False):
 
 if __name__ == "__main__":
     import sys
-    if "--asm" in sys.argv:
-        print("hand-issued LDS reads / kernels checked:", lint_hand_pipelines(force=True))
+    if "--lint" in sys.argv:
+        print("hand-issued LDS reads / kernels checked:", lint_hand_pipelines())
     elif "--prof" in sys.argv:  # phase-profiling build used by tools/phase_prof.py
         print(build_native(force=True, out=os.path.join(HERE, "libcleanmarl_hip_prof.so"), extra_flags=["-DCM_PHASE_PROF"]))
     else:

@@ -144,4 +144,15 @@ template <int OFF> __device__ __forceinline__ f32x4 cf_lds128(unsigned addr) {
 template <int N> __device__ __forceinline__ void cf_wait(f32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
 template <int N> __device__ __forceinline__ void cf_wait(f32x4& v, f32x4& w) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v), "+v"(w) : "n"(N)); }
 __device__ __forceinline__ unsigned cf_lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }  // low 32 bits of a flat LDS address = LDS offset
-
+// scalar twin and the waits of the 32x32x2 product forms (cm_mlp_kernel.h): 4 + 4 scalars, or one 16-byte and 4 scalars
+template <int OFF> __device__ __forceinline__ float cf_lds32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void cf_wait(float (&a)[4], float (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void cf_wait(f32x4& a, float (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}

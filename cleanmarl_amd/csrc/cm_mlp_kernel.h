@@ -131,10 +131,119 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // All three MFMA loops are software-pipelined by hand: the LDS operands of batch i+1 are requested before the
 // MFMAs of batch i issue, so the ~100-cycle ds_read latency hides under the 4 x 64-cycle MFMA batch instead of
-// stalling the matrix pipe once per loop iteration.
+// stalling the matrix pipe once per loop iteration.  Written in C++ that order did not survive the compiler (round 2, ISA of the actor
+// kernel): the forward loop waited for one of the two FRESH reads of every batch (`s_waitcnt lgkmcnt(1)` right behind them: the
+// `a = an` rotation had become a copy of the in-flight register's successor) and the weight-gradient loop issued read, lgkmcnt(0),
+// 2 MFMAs.  The reads are therefore issued through cm_common.h's asm helpers (program order kept, waits placed by hand, destination
+// registers never touched in flight -- checked on the generated code by tools/lint_lds_hazards.py); every pipeline is straight-line code.
 //
 // acc[32x32] += A[32 rows][8*kb] * B[32 rows(n)][8*kb]^T ; A,B row-major in LDS with stride LDT.
 // k is consumed in the permuted order {8j+i, 8j+4+i}: lane half h reads floats [8j+4h, 8j+4h+4) as one b128.
+template <int J, int KB>
+__device__ __forceinline__ void nt_steps(f32x16& acc, unsigned aa, unsigned ba, f32x4& a0, f32x4& b0, f32x4& a1, f32x4& b1) {
+    if constexpr (J < KB) {
+        f32x4& ca = (J & 1) ? a1 : a0; f32x4& cb = (J & 1) ? b1 : b0;
+        if constexpr (J + 1 < KB) {
+            f32x4& na = (J & 1) ? a0 : a1; f32x4& nb = (J & 1) ? b0 : b1;
+            na = cf_lds128<32 * (J + 1)>(aa); nb = cf_lds128<32 * (J + 1)>(ba);
+            cf_wait<2>(ca, cb);
+        } else {
+            cf_wait<0>(ca, cb);
+        }
+        acc = mfma32(ca[0], cb[0], acc);
+        acc = mfma32(ca[1], cb[1], acc);
+        acc = mfma32(ca[2], cb[2], acc);
+        acc = mfma32(ca[3], cb[3], acc);
+        nt_steps<J + 1, KB>(acc, aa, ba, a0, b0, a1, b1);
+    }
+}
+template <int KB>
+__device__ __forceinline__ void rowpar_nt_pipe(f32x16& acc, unsigned aa, unsigned ba) {
+    f32x4 a0 = cf_lds128<0>(aa), b0 = cf_lds128<0>(ba), a1, b1;
+    nt_steps<0, KB>(acc, aa, ba, a0, b0, a1, b1);
+}
+__device__ __forceinline__ void rowpar_nt_hand(f32x16& acc, const float* As, const float* Bs, int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned aa = cf_lds_addr(As + r * LDT + 4 * h), ba = cf_lds_addr(Bs + r * LDT + 4 * h);
+    switch (kb) {  // wave-uniform; each case is one straight-line pipeline with its first read inside
+        case 8: rowpar_nt_pipe<8>(acc, aa, ba); break;
+        case 7: rowpar_nt_pipe<7>(acc, aa, ba); break;
+        case 6: rowpar_nt_pipe<6>(acc, aa, ba); break;
+        case 5: rowpar_nt_pipe<5>(acc, aa, ba); break;
+        case 4: rowpar_nt_pipe<4>(acc, aa, ba); break;
+        case 3: rowpar_nt_pipe<3>(acc, aa, ba); break;
+        case 2: rowpar_nt_pipe<2>(acc, aa, ba); break;
+        case 1: rowpar_nt_pipe<1>(acc, aa, ba); break;
+        default: break;
+    }
+}
+
+// acc[32x32] += dZ[32 rows][64 (n)] * W[64 (n)][32 cols]  (W row-major [n][k] in LDS, read transposed)
+template <int J>
+__device__ __forceinline__ void tn_steps(f32x16& acc, unsigned aa, unsigned ba, f32x4& a0, float (&b0)[4], f32x4& a1, float (&b1)[4]) {
+    if constexpr (J < HP / 8) {
+        f32x4& ca = (J & 1) ? a1 : a0; float (&cb)[4] = (J & 1) ? b1 : b0;
+        if constexpr (J + 1 < HP / 8) {
+            f32x4& na = (J & 1) ? a0 : a1; float (&nb)[4] = (J & 1) ? b0 : b1;
+            na = cf_lds128<32 * (J + 1)>(aa);
+            nb[0] = cf_lds32<(8 * (J + 1) + 0) * LDT * 4>(ba); nb[1] = cf_lds32<(8 * (J + 1) + 1) * LDT * 4>(ba);
+            nb[2] = cf_lds32<(8 * (J + 1) + 2) * LDT * 4>(ba); nb[3] = cf_lds32<(8 * (J + 1) + 3) * LDT * 4>(ba);
+            cf_wait<5>(ca, cb);
+        } else {
+            cf_wait<0>(ca, cb);
+        }
+        acc = mfma32(ca[0], cb[0], acc);
+        acc = mfma32(ca[1], cb[1], acc);
+        acc = mfma32(ca[2], cb[2], acc);
+        acc = mfma32(ca[3], cb[3], acc);
+        tn_steps<J + 1>(acc, aa, ba, a0, b0, a1, b1);
+    }
+}
+__device__ __forceinline__ void rowpar_tn_hand(f32x16& acc, const float* As, const float* Ws_c0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned aa = cf_lds_addr(As + r * LDT + 4 * h), ba = cf_lds_addr(Ws_c0 + (4 * h) * LDT + r);
+    f32x4 a0 = cf_lds128<0>(aa), a1;
+    float b0[4] = {cf_lds32<0>(ba), cf_lds32<LDT * 4>(ba), cf_lds32<2 * LDT * 4>(ba), cf_lds32<3 * LDT * 4>(ba)}, b1[4];
+    tn_steps<0>(acc, aa, ba, a0, b0, a1, b1);
+}
+
+// acc[32 (n) x 32 (k)] += sum_rows dZ[row][n0 + i] * X[row][k0 + j]   over the TM rows of the tile
+template <int S>
+__device__ __forceinline__ void colred_steps(f32x16& acc, unsigned aa, unsigned ba, float (&a0)[4], float (&b0)[4], float (&a1)[4], float (&b1)[4]) {
+    if constexpr (S < TM / 8) {
+        float (&ca)[4] = (S & 1) ? a1 : a0; float (&cb)[4] = (S & 1) ? b1 : b0;
+        if constexpr (S + 1 < TM / 8) {
+            float (&na)[4] = (S & 1) ? a0 : a1; float (&nb)[4] = (S & 1) ? b0 : b1;
+            na[0] = cf_lds32<2 * (4 * (S + 1) + 0) * LDT * 4>(aa); nb[0] = cf_lds32<2 * (4 * (S + 1) + 0) * LDT * 4>(ba);
+            na[1] = cf_lds32<2 * (4 * (S + 1) + 1) * LDT * 4>(aa); nb[1] = cf_lds32<2 * (4 * (S + 1) + 1) * LDT * 4>(ba);
+            na[2] = cf_lds32<2 * (4 * (S + 1) + 2) * LDT * 4>(aa); nb[2] = cf_lds32<2 * (4 * (S + 1) + 2) * LDT * 4>(ba);
+            na[3] = cf_lds32<2 * (4 * (S + 1) + 3) * LDT * 4>(aa); nb[3] = cf_lds32<2 * (4 * (S + 1) + 3) * LDT * 4>(ba);
+            cf_wait<8>(ca, cb);
+        } else {
+            cf_wait<0>(ca, cb);
+        }
+        acc = mfma32(ca[0], cb[0], acc);
+        acc = mfma32(ca[1], cb[1], acc);
+        acc = mfma32(ca[2], cb[2], acc);
+        acc = mfma32(ca[3], cb[3], acc);
+        colred_steps<S + 1>(acc, aa, ba, a0, b0, a1, b1);
+    }
+}
+__device__ __forceinline__ void colred_hand(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned aa = cf_lds_addr(Zs_n0 + h * LDT + r), ba = cf_lds_addr(Xs_k0 + h * LDT + r);
+    float a0[4], b0[4], a1[4], b1[4];
+    a0[0] = cf_lds32<0>(aa); b0[0] = cf_lds32<0>(ba);
+    a0[1] = cf_lds32<2 * LDT * 4>(aa); b0[1] = cf_lds32<2 * LDT * 4>(ba);
+    a0[2] = cf_lds32<4 * LDT * 4>(aa); b0[2] = cf_lds32<4 * LDT * 4>(ba);
+    a0[3] = cf_lds32<6 * LDT * 4>(aa); b0[3] = cf_lds32<6 * LDT * 4>(ba);
+    colred_steps<0>(acc, aa, ba, a0, b0, a1, b1);
+}
+
+// compiler-scheduled twins (the C++ loops of round 1).  Both forms produce the same bits; which one a launch uses is the HAND template
+// parameter of k_mlp: the hand-ordered forms win when the kernel has the GPU to itself (actor pass of config 3: 1.88 -> 1.85 ms,
+// value pass of config 4: 1.49 -> 1.31 ms) and lose when a second kernel shares the CUs (512-env share with the critic on the
+// second stream: 1.54 -> 1.69 ms per iteration; config 4's two-chunk actor: +4 %), so launch_variant picks them by shape and size.
 __device__ __forceinline__ void rowpar_nt(f32x16& acc, const float* As, const float* Bs, int kb) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float4* ap = reinterpret_cast<const float4*>(As + r * LDT + 4 * h);
@@ -196,6 +305,16 @@ __device__ __forceinline__ void colred(f32x16& acc, const float* Zs_n0, const fl
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
     }
+}
+
+template <bool HAND> __device__ __forceinline__ void rowpar_nt_sel(f32x16& acc, const float* As, const float* Bs, int kb) {
+    if constexpr (HAND) rowpar_nt_hand(acc, As, Bs, kb); else rowpar_nt(acc, As, Bs, kb);
+}
+template <bool HAND> __device__ __forceinline__ void rowpar_tn_sel(f32x16& acc, const float* As, const float* Ws_c0) {
+    if constexpr (HAND) rowpar_tn_hand(acc, As, Ws_c0); else rowpar_tn(acc, As, Ws_c0);
+}
+template <bool HAND> __device__ __forceinline__ void colred_sel(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
+    if constexpr (HAND) colred_hand(acc, Zs_n0, Xs_k0); else colred(acc, Zs_n0, Xs_k0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -435,7 +554,7 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
 template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
 
 // VEC: 0 = 4-byte tile loads; 1 = 16-byte loads of the input rows and of streamed W0 chunks (can_vec)
-template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false>
+template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false, bool HAND = false>
 __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool TRAIN = (MODE >= M_ACTOR);
@@ -576,7 +695,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             PH(0);
             const int w = min(KC, din - c * KC);
             if (BF) rowpar_nt_bf(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);
-            else rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
+            else rowpar_nt_sel<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
         }
         {
             float* H0 = smem + lds.Hs(0);
@@ -602,7 +721,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
                 if (BF) rowpar_nt_bf(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 16);
-                else rowpar_nt(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                else rowpar_nt_sel<HAND>(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
                 float* Hl = smem + lds.Hs(l);
                 const float bias = smem[lds.bl(l - 1) + 32 * wn + lc];
 #pragma unroll
@@ -875,11 +994,11 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         dbh[l] += s;
                     }
                     if (BF) colred_bf(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
-                    else colred(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
+                    else colred_sel<HAND>(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
                     if (BF) rowpar_tn_bf(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
-                    else rowpar_tn(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
+                    else rowpar_tn_sel<HAND>(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
                     __syncthreads();
                     PH(7);
 #pragma unroll
@@ -931,7 +1050,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         __syncthreads();
                     }
                     if (BF) colred_bf(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
-                    else colred(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
+                    else colred_sel<HAND>(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
                 }
             }
             PH(9);
@@ -1086,7 +1205,7 @@ inline void prep_w0_image(MlpArgs& a, float* scratch, size_t scratch_floats, hip
     a.w0p = scratch; a.w0_ld = ld;
 }
 
-template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false>
+template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false, bool HAND = false>
 inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
 #ifdef CM_PHASE_PROF
     // profiling build only (tools/phase_prof.py): CM_PROF_ONE_WG=1 pads LDS so that ONE workgroup fits a CU and halves the grid --
@@ -1095,9 +1214,9 @@ inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t
         if (e[0] == '1') { if (lds_bytes < 100 * 1024) lds_bytes = 100 * 1024; if (grid > 256) grid = 256; }
     }
 #endif
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<NCH, MODE, VEC, LCAP, KJ, BF, HAND>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ, BF>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ, BF, HAND>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
 }
 
 // CM_MFMA=bf16x3 opts the PPO training passes into the compensated-bf16 GEMM loops (default: exact fp32 MFMA)
@@ -1109,6 +1228,15 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
     const bool vec = can_vec(a), l1 = a.L <= 1, k8 = a.dout <= 8;
     if constexpr ((MODE == M_ACTOR || MODE == M_CRITIC) && NCH <= 2) {
         if (vec && l1 && k8 && mfma_bf16x3()) { launch_one<NCH, MODE, 1, 1, 2, true>(a, grid, lds_bytes, s); return; }
+    }
+    // hand-ordered LDS reads (see rowpar_nt): the single-chunk actor pass of a batch too large to share the GPU with the critic's
+    // epochs (learner.overlap_critic's 2^21-row limit), and every forward pass (the value pass follows the rollout and the join with
+    // the critic stream: nothing runs beside it).  CM_MLP_FORMS=hand|loop forces one form wherever both are compiled (A/B runs, tests).
+    if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH == 0)) {
+        const char* f = getenv("CM_MLP_FORMS");
+        const bool big = MODE == M_FWD || a.rows > (1L << 21);
+        const bool hand = f ? (f[0] == 'h') : big;
+        if (vec && l1 && k8 && hand) { launch_one<NCH, MODE, 1, 1, 2, false, true>(a, grid, lds_bytes, s); return; }
     }
     if (vec) {
         if (l1) { if (k8) launch_one<NCH, MODE, 1, 1, 2>(a, grid, lds_bytes, s); else launch_one<NCH, MODE, 1, 1, 8>(a, grid, lds_bytes, s); }

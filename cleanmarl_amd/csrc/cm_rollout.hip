@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-            rowpar_nt(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (din + 7) >> 3);
+            rowpar_nt_hand(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (din + 7) >> 3);  // hand-ordered LDS reads (cm_mlp_kernel.h): 1.115 -> 1.08 ms at config 3
             {
                 const float bias = b0s[32 * wn + lc];
 #pragma unroll
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
             if (L > 0) {  // hidden layer; H1 aliases Xs (every wave is past its layer-0 reads)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-                rowpar_nt(acc, H0 + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                rowpar_nt_hand(acc, H0 + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
                 const float bias = b1s[32 * wn + lc];
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {

@@ -885,6 +885,39 @@ def test_padded_leading_dimensions_do_not_change_the_update(algo, E, A, T, Do, D
             assert _err(r1[e][k].cpu().numpy(), R.flat(orec[e][k]).numpy()) <= TOL, k
 
 
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [("mappo", 37, 3, 25, 21, 54, 5, 64, 1), ("mappo", 13, 8, 20, 56, 384, 5, 48, 1)])
+def test_hand_ordered_and_compiler_scheduled_product_forms_agree_bit_for_bit(algo, E, A, T, Do, Ds, K, H, L, monkeypatch):
+    """k_mlp's 32x32x2 products exist in two forms (csrc/cm_mlp_kernel.h: LDS reads issued by hand through inline asm, or left to the
+    compiler); launches pick one by shape and size.  Same operands, same order: a whole update must produce identical bits with either,
+    and both sit within 1e-4 of the oracle.  (The hand-ordered actor pass only runs above 2^21 rows by default: forced here.)"""
+    from oracle import restatement as R
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    batch = _random_case(77, E, A, T, Do, Ds, K)
+    aspec, cspec = NetSpec(Do, H, L, K), NetSpec(Ds, H, L, 1)
+    ap, cp = init_params_like_torch(aspec), init_params_like_torch(cspec)
+    hpd = dict(gamma=0.99, td_lambda=0.95, normalize_advantage=True, normalize_return=False, epochs=2, ppo_clip=0.2, entropy_coef=0.01,
+               clip_gradients=0.5, optimizer="Adam", learning_rate_actor=8e-4, learning_rate_critic=8e-4)
+    out = {}
+    for forms in ("hand", "loop"):
+        monkeypatch.setenv("CM_MLP_FORMS", forms)
+        b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"], batch["states"],
+                                              batch["avail"], batch["mask"], dev, pad=True)  # 16-byte rows: the forms' common shape
+        L_ = PPOLearner(algo, aspec, cspec, A, HParams(**hpd), dev, [p.clone() for p in ap], [p.clone() for p in cp])
+        r = L_.train_iteration(b, keep_grads=True)
+        torch.cuda.synchronize()
+        out[forms] = (b.ret.clone(), [dict(d) for d in r], L_.actor.clone(), L_.critic.clone())
+    assert torch.equal(out["hand"][0], out["loop"][0])
+    assert torch.equal(out["hand"][2], out["loop"][2]) and torch.equal(out["hand"][3], out["loop"][3])
+    for e in range(2):
+        assert torch.equal(out["hand"][1][e]["actor_grads"], out["loop"][1][e]["actor_grads"])
+    ret, adv, orec = R.mlp_update(ap, cp, batch, hpd, algo)
+    assert _err(out["hand"][0].permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL
+    for e in range(2):
+        assert _err(out["hand"][1][e]["actor_after"].cpu().numpy(), R.flat(orec[e]["actor_after"]).numpy()) <= TOL
+
+
 def test_padded_rollout_buffers_hold_the_same_rollout():
     """cm_rollout_spread_ld / cm_shape_env_fill_ld / cm_policy_act_episode_ld: buffers with padded leading dimensions receive exactly the
     rollout of the unpadded ones (bit for bit), and their padding columns stay zero."""

@@ -5,7 +5,7 @@ Some kernels (csrc/cm_critic_fused.h, csrc/cm_gru_step2.h) issue their LDS reads
 (cm_common.h: cf_lds128 / cf_wait) so that the reads run ahead of the MFMAs that consume them.  The compiler does not know that such a
 read is asynchronous: if it ever copies or otherwise reads the destination registers between the read and its s_waitcnt (a phi copy at a
 branch did exactly that once), the kernel computes garbage without any diagnostic.  This linter walks the compiler's assembly
-(`hipcc -S --cuda-device-only`, written by `python -m cleanmarl_amd.build --asm` to cleanmarl_amd/build/asm/) kernel by kernel with the
+(`-save-temps=obj` of the library build: cleanmarl_amd/build/libcleanmarl_hip.so.obj/*-gfx950.s; `python -m cleanmarl_amd.build --lint`) kernel by kernel with the
 in-order LGKM queue: reads between `;;#ASMSTART` and `;;#ASMEND` are the hand-issued ones; an instruction that reads or overwrites
 one of their destination registers ahead of the covering `s_waitcnt lgkmcnt(N)`, or a branch / label while one is pending (the helpers
 are for straight-line pipelines), is reported.
@@ -108,8 +108,8 @@ def lint_file(path):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sys.argv[1:] or sorted(os.path.join(here, "cleanmarl_amd", "build", "asm", f)
-                                   for f in os.listdir(os.path.join(here, "cleanmarl_amd", "build", "asm")) if f.endswith(".s"))
+    d = os.path.join(here, "cleanmarl_amd", "build", "libcleanmarl_hip.so.obj")
+    files = sys.argv[1:] or sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith("gfx950.s"))
     total, bad = 0, 0
     for f in files:
         probs, nk, nhand = lint_file(f)
