@@ -260,7 +260,11 @@ class PPOLearner:
         self.critic_span = None  # bench.py: (start, end) timing events of the last update's critic epochs (set when self.events is a list)
         # the critic's all-reduces get their own communicator: collectives issued from two streams on ONE communicator are ordered
         # by the library's internal stream, which would put the critic's message in front of the actor's next one
-        self.pg_c = torch.distributed.new_group() if (world_size > 1 and process_group is not None) else process_group
+        # CM_FORCE_COLLECTIVES=1 (test hook): issue the all-reduces even at world size 1 -- tests/test_dist_gpu.py runs the schedules over
+        # RCCL (backend "nccl") on the one GPU it has; a 1-rank sum is the identity, so the results must equal the plain run
+        import os
+        self._coll = world_size > 1 or (process_group is not None and os.environ.get("CM_FORCE_COLLECTIVES") == "1")
+        self.pg_c = torch.distributed.new_group() if (self._coll and process_group is not None) else process_group
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
@@ -432,13 +436,13 @@ class PPOLearner:
             for ep in range(nE0):
                 g = self.gbuf_rows[ep]
                 self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS])
-                wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if self.world > 1 else None
+                wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if self._coll else None
                 if pending is not None:
                     critic_step(*pending, s)
                 self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:])
-                wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if self.world > 1 else None
+                wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if self._coll else None
                 actor_step(ep, wa)
-                if self.world > 1:
+                if self._coll:
                     pending = (ep, wc)
                 else:
                     critic_step(ep, None, s)
@@ -456,7 +460,7 @@ class PPOLearner:
             def actor_epoch(ep):
                 g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
                 self._timed("actor", self.actor_pass, b, s, g_actor)
-                actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self.world > 1 else None)
+                actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self._coll else None)
 
             def critic_epoch(ep):
                 with torch.cuda.stream(side):
@@ -466,7 +470,7 @@ class PPOLearner:
                         self._c0.record()
                     g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
                     self._timed("critic", self.critic_pass, b, sc, g_critic)
-                    critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self.world > 1 else None, sc)
+                    critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self._coll else None, sc)
                     if ep == nE0 - 1:
                         rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
                         if timed:

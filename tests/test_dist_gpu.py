@@ -315,6 +315,60 @@ def _check_overlap_ranks(gold, out, world):
     assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
 
 
+def _worker_rccl(rank, world, port, gold, algo, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from oracle import restatement as R
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    batch, ap, cp, hp, z = R.load_golden(gold)
+    dev = torch.device("cuda:0")
+    reward = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else batch["reward"]
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"],
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    res = {}
+    for sched in ("0", "1", "2"):
+        os.environ["CM_CRITIC_OVERLAP"] = sched
+        b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], reward, batch["states"], batch["avail"],
+                                              batch["mask"], dev, pad=True)
+        L = PPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=[p.clone() for p in ap],
+                       critic_params=[p.clone() for p in cp], process_group=torch.distributed.group.WORLD, world_size=world)
+        assert L._coll and L.pg_c is not L.pg
+        recs = [dict(r) for r in L.train_iteration(b)]
+        L.wait_critic()
+        torch.cuda.synchronize()
+        res[sched] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu())
+    torch.save(res, f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_ragged_norm", "mappo")])
+def test_rccl_carries_the_all_reduces_of_every_update_schedule(golden_dir, tmp_path, name, algo, monkeypatch):
+    """The data-path collectives over RCCL itself (backend "nccl"), on the one GPU a test box has: world size 1 with CM_FORCE_COLLECTIVES=1
+    makes update() issue every asynchronous all-reduce it would issue at N > 1 -- actor and critic messages on their own communicators, from
+    the launch stream and the low-priority stream, waited for by stream order -- for the one-stream and both two-stream schedules.  A
+    one-rank sum is the identity, so each schedule must land on the unmodified reference's post-update parameters; what this pins is that
+    RCCL initialises, accepts the two communicators and the handles' stream-side waits, and neither deadlocks nor reorders the steps."""
+    monkeypatch.setenv("CM_FORCE_COLLECTIVES", "1")
+    out, gold = str(tmp_path / "rccl"), os.path.join(golden_dir, name + ".npz")
+    mp.spawn(_worker_rccl, args=(1, _free_port(), gold, algo, out), nprocs=1, join=True)
+    z = np.load(gold)
+    got = torch.load(f"{out}.0", weights_only=False)
+    for sched, g in got.items():
+        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL, sched
+        for e, r in enumerate(g["recs"]):
+            assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL, sched
+    assert torch.equal(got["1"]["actor"], got["2"]["actor"]) and torch.equal(got["1"]["critic"], got["2"]["critic"])
+
+
 def test_two_rank_cli_run_with_host_envs_matches_the_single_process_run(tmp_path):
     """mappo_multienvs.py launched as two ranks (torch.distributed.run, gloo test hook, both on cuda:0) with HOST envs: every rank owns the
     global env indices of its shard and its own Philox rows (all ranks used to collect the same episodes), the logged rollout
