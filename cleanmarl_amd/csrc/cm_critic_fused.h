@@ -10,9 +10,15 @@
 //     once, dZ0 never leaves the chip;
 //   * hidden activations / value head / loss are produced from the accumulator layout in place (h0, h1 stay in registers for the
 //     relu' masks and the head's dot product); LDS carries only what other waves need (H0, dZ1, dZ0 tiles).
-// One workgroup per CU (registers: 2 x 16 x NC + ~120), the next tile's first two X chunks in flight in registers during the backward
-// phases.  Same un-normalised sums and statistic slots as k_mlp<.., M_CRITIC>; summation order differs (tolerance-tested, 1e-4).
-// Shapes: Din = 65 .. 448 (NC = 2 .. 7 chunks of 64), H <= 64, ONE hidden->hidden layer, scalar output; others keep the split schedule.
+//   * every LDS read that feeds an MFMA is issued by hand, a step or two ahead of its use (cm_common.h: cf_lds128 / cf_wait; the kernel
+//     runs ONE wave per SIMD, so nothing else hides LDS latency, and the compiler keeps a read next to its use).  The generated code is
+//     checked for touched in-flight registers by tools/lint_lds_hazards.py; all pipelines are straight-line code for that reason.
+// One workgroup per CU (registers: 2 x 16 x NC + ~230, W0 parked in the accumulation-register file), the next tile's first two X
+// chunks in flight in registers during the backward phases.  Same un-normalised sums and statistic slots as k_mlp<.., M_CRITIC>;
+// summation order differs (tolerance-tested, 1e-4).  Measured at config 3 (524288 rows x 384): 0.576 ms = 71 % of the fp32 MFMA peak,
+// 0.85 GB of HBM traffic for 0.82 GB algorithmic (split schedule: 0.772 ms, 1.95 GB).  DESIGN.md section 3.1b.
+// Shapes: Din = 65 .. 448 (NC = 2 .. 7 chunks of 64) on 16-byte aligned rows, H <= 64, ONE hidden->hidden layer, scalar output, at
+// least CM_FUSED_MIN_ROWS rows (whole CUs per workgroup: small batches and batches overlapped with other kernels keep the split schedule).
 #pragma once
 #include "cm_mlp_train.h"
 
