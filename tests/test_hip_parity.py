@@ -918,6 +918,45 @@ def test_hand_ordered_and_compiler_scheduled_product_forms_agree_bit_for_bit(alg
         assert _err(out["hand"][1][e]["actor_after"].cpu().numpy(), R.flat(orec[e]["actor_after"]).numpy()) <= TOL
 
 
+def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeypatch):
+    """cm_critic_fwd_bwd_ld straight through the C-ABI, 24 seeded random shapes inside the one-pass kernel's domain (2 .. 7 input chunks,
+    H <= 64, central and per-agent targets, ragged episode lengths, row counts with partial tiles and more tiles than workgroups, padded and
+    exact leading dimensions): gradient + statistics buffer of CM_CRITIC_SCHEDULE=fused against =split (both against the oracle elsewhere;
+    here the two schedules against each other, 1e-4 of the buffer's scale)."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        nc = int(rng.integers(2, 8))
+        din = int(rng.integers(64 * (nc - 1) + 1, 64 * nc + 1))
+        ld = (din + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))
+        H = int(rng.choice([16, 33, 48, 64]))
+        A, T = int(rng.integers(1, 12)), int(rng.integers(3, 40))
+        per_agent = int(rng.integers(0, 2))
+        E = int(rng.choice([1, 3, 17, 70, 700 if case % 6 == 0 else 40]))
+        torch.manual_seed(case)
+        spec = NetSpec(din, H, 1, 1)
+        p = flatten_params(init_params_like_torch(spec), dev)
+        rows_shape = (E, A, T) if per_agent else (E, T)
+        x = torch.zeros(*rows_shape, ld, device=dev)
+        x[..., :din] = torch.randn(*rows_shape, din, device=dev)
+        ret = torch.randn(E, A, T, device=dev)
+        ep_len = torch.from_numpy(rng.integers(1, T + 1, size=E).astype(np.int32)).to(dev)
+        ws = torch.empty(lib.cm_critic_workspace_bytes(E, A, T, per_agent, din, H, 1), dtype=torch.uint8, device=dev)
+        out = {}
+        for sched in ("fused", "split"):
+            monkeypatch.setenv("CM_CRITIC_SCHEDULE", sched)
+            g = torch.full((spec.nparams + N.NUM_STATS,), float("nan"), device=dev)
+            N.check(lib.cm_critic_fwd_bwd_ld(N.ptr(x), ld, N.ptr(ret), N.ptr(ep_len), E, A, T, per_agent, din, H, 1, N.ptr(p), N.ptr(g),
+                                             N.ptr(ws), ws.numel(), N.stream_ptr()), "cm_critic_fwd_bwd_ld")
+            torch.cuda.synchronize()
+            out[sched] = g.cpu().numpy()
+        assert np.isfinite(out["fused"]).all(), (case, din, H, A, T, E, per_agent)
+        scale = 1.0 + np.abs(out["split"]).max()
+        assert np.abs(out["fused"] - out["split"]).max() <= TOL * scale, (case, din, ld, H, A, T, E, per_agent)
+
+
 def test_padded_rollout_buffers_hold_the_same_rollout():
     """cm_rollout_spread_ld / cm_shape_env_fill_ld / cm_policy_act_episode_ld: buffers with padded leading dimensions receive exactly the
     rollout of the unpadded ones (bit for bit), and their padding columns stay zero."""
