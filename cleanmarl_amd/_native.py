@@ -22,6 +22,17 @@ _f = C.c_float
 _u64 = C.c_uint64
 _sz = C.c_size_t
 
+
+
+class OptStep(C.Structure):
+    """cm_opt_step_t of include/cleanmarl_hip.h: one optimiser step, fused behind a training pass by the *_train_step entry points."""
+    _fields_ = [("params", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("out_norm", _p), ("scratch", _p),
+                ("lr", _d), ("beta1", _d), ("beta2", _d), ("eps", _d), ("weight_decay", _d), ("max_norm", _d), ("grad_scale", _d),
+                ("step", C.c_int32), ("opt_kind", C.c_int32)]
+
+
+_po = C.POINTER(OptStep)
+
 # name -> (restype, argtypes); mirrors include/cleanmarl_hip.h one to one
 SIGNATURES = {
     "cm_last_error": (C.c_char_p, []),
@@ -70,6 +81,11 @@ SIGNATURES = {
     "cm_critic_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "cm_critic_fwd_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_grad_norm_clip_adam": (_i, [_p, _p, _p, _p, _l, _i, _d, _d, _d, _d, _d, _i, _d, _d, _p, _p]),
+    "cm_opt_step_scratch_bytes": (_sz, []),
+    "cm_optimizer_step": (_i, [_p, _l, _po, _p]),
+    "cm_ppo_actor_train_step_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _d, _p, _p, _sz, _po, _p]),
+    "cm_critic_train_step_ld": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _po, _p]),
+    "cm_gru_actor_chunk_train_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _d, _d, _p, _p, _sz, _po, _p]),
     "cm_gru_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "cm_gru_actor_chunk_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _d, _d,
                                         _p, _p, _sz, _p]),

@@ -57,6 +57,8 @@ def build_native(force=False, verbose=False, out=None, extra_flags=()):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(out + ".tmp", out)
+    if out == LIB:  # the hand-issued LDS pipelines depend on what THIS compiler did around them: a hazard fails the build
+        _lint(device_asm(out))
     return out
 
 
@@ -69,11 +71,18 @@ def device_asm(lib=None):
 def lint_hand_pipelines():
     """tools/lint_lds_hazards.py over the assembly of every translation unit of the in-tree library (builds it first if its assembly is
     missing or stale); raises on a hazard.  Returns (hand-issued LDS reads, kernels) checked."""
-    import importlib.util
     files = device_asm()
-    if is_stale() or len(files) != len(sources()) or any(os.path.getmtime(f) < os.path.getmtime(src) for f, src in zip(files, sources())):
-        build_native(force=True)
+    by_stem = {os.path.basename(f).split("-hip-amdgcn")[0]: f for f in files}
+    stale = is_stale() or any(os.path.splitext(os.path.basename(src))[0] not in by_stem or
+                              os.path.getmtime(by_stem[os.path.splitext(os.path.basename(src))[0]]) < os.path.getmtime(src) for src in sources())
+    if stale:
+        build_native(force=True)  # lints as its last step
         files = device_asm()
+    return _lint(files)
+
+
+def _lint(files):
+    import importlib.util
     spec = importlib.util.spec_from_file_location("lint_lds_hazards", os.path.join(HERE, "..", "tools", "lint_lds_hazards.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -51,6 +51,9 @@ class COMALearner:
         self.actor_spec, self.critic_spec = actor_spec, critic_spec
         assert critic_spec.dout == actor_spec.dout, "COMA's critic has one output per action"
         self.pg, self.world = process_group, world_size
+        # CM_FORCE_COLLECTIVES=1 (test hook, as in learner.PPOLearner): issue the all-reduces at world size 1 too
+        import os
+        self._coll = world_size > 1 or (process_group is not None and os.environ.get("CM_FORCE_COLLECTIVES") == "1")
         self.actor = flatten_params(actor_params if actor_params is not None else init_params_like_torch(actor_spec), device)
         self.critic = flatten_params(critic_params if critic_params is not None else init_params_like_torch(critic_spec), device)
         self.target = self.critic.clone()  # copy.deepcopy(critic), :406
@@ -93,10 +96,13 @@ class COMALearner:
         dist.merge_moments_(self.moments, self.pg, self.world)
 
     def _adam(self, params, g, opt, which, s):
-        opt.step += 1
-        N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
-                                                opt.lr, 0.9, opt.beta2, 1e-8, opt.wd, opt.kind, float(self.hp.clip_gradients), 1.0,
-                                                N.ptr(self.norms[which:]), s), "cm_grad_norm_clip_adam")
+        """norm_d + clip_grad_norm_ + optimizer.step() as one launch on the (all-reduced) gradient buffer."""
+        o = opt.next_step(params, self.norms[which:], self.hp.clip_gradients)
+        N.check(self.lib.cm_optimizer_step(N.ptr(g), params.numel(), o, s), "cm_optimizer_step")
+
+    def _allreduce(self, t):
+        if self._coll:
+            torch.distributed.all_reduce(t, group=self.pg)
 
     def _q(self, params, avail, out, b, s):
         """Q[E,A,T,K] of Critic(state, obs, actions) without materialising coma_inputs (factored layer 0, csrc/cm_coma.hip)."""
@@ -136,7 +142,7 @@ class COMALearner:
         N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, b.Ds,
                                            b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws),
                                            self.ws.numel(), s), "cm_coma_critic_fwd_bwd")
-        dist.allreduce_sum_(self.g_critic, self.pg, self.world)
+        self._allreduce(self.g_critic)
         self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
         self.training_step += 1
         if self.training_step % int(hp.target_network_update_freq) == 0:
@@ -148,12 +154,12 @@ class COMALearner:
         N.check(lib.cm_coma_advantage(N.ptr(self.logits), N.ptr(self.q), N.ptr(b.action), N.ptr(b.ep_len), E, A, T, K, N.ptr(b.adv),
                                       N.ptr(self.tstats), N.ptr(self.ws), self.ws.numel(), s), "cm_coma_advantage")
         if hp.normalize_advantage:
-            dist.allreduce_sum_(self.tstats, self.pg, self.world)
+            self._allreduce(self.tstats)
             N.check(lib.cm_coma_normalize_adv(N.ptr(b.adv), N.ptr(self.tstats), E, A, T, s), "cm_coma_normalize_adv")
         N.check(lib.cm_coma_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.adv), N.ptr(b.ep_len), E, A, T, a.din,
                                           a.hidden, a.n_layers, K, N.ptr(self.actor), hp.entropy_coef, N.ptr(self.g_actor),
                                           N.ptr(self.ws), self.ws.numel(), s), "cm_coma_actor_fwd_bwd")
-        dist.allreduce_sum_(self.g_actor, self.pg, self.world)
+        self._allreduce(self.g_actor)
         self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
         st = torch.cat([self.g_actor[Pa:], self.g_critic[Pc:], self.norms]).cpu().double()  # single sync
         st_a, st_c = st[:N.NUM_STATS], st[N.NUM_STATS:2 * N.NUM_STATS]

@@ -17,6 +17,11 @@ void cm_set_error(const char* fmt, ...);
     if (e_ != hipSuccess) CM_FAIL(-2, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 #define CM_REQUIRE(cond, ...) do { if (!(cond)) CM_FAIL(-1, __VA_ARGS__); } while (0)
 
+// fold per-workgroup partial gradient rows and apply the optimiser step in one launch (cm_optim.hip); part2 / isplit: a second partial
+// set holding columns [0, isplit) (the split critic's streamed dW0), NULL if none
+int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
+                          float* grad_and_stats, const cm_opt_step_t* opt, hipStream_t s, const char* who);
+
 // ---------------------------------------------------------------- Philox4x32-10 (counter RNG)
 // Keyed by the run seed, counted by (global row, time step, stream id): the draw for a given
 // (env, agent, t) is the same no matter how envs are sharded over GPUs.

@@ -387,7 +387,7 @@ inline bool critic_fused_shape(const MlpArgs& a) {
 inline size_t critic_fused_lds_bytes(int nc) { return (size_t)(nc * TM * LDT + 2 * TM * LDT + 5 * TM + 2 * NTHREADS) * sizeof(float); }
 
 // launches k_critic_fused + the partial-row reduction; same workspace layout as the fused k_mlp passes (MAX_GRID partial rows)
-inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who, const cm_opt_step_t* opt = nullptr) {
     const int64_t P = cm_mlp_param_count(a.din, a.H, a.L, a.dout);
     const size_t need = train_ws_bytes(a.din, a.H, a.L, a.dout);
     CM_REQUIRE(ws && ws_bytes >= need, "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
@@ -408,7 +408,7 @@ inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t w
     }
 #undef CM_CF
     CM_CHECK_LAUNCH(who);
-    return finish_train(a, grid, P, grad_and_stats, s, who);
+    return finish_train(a, grid, P, grad_and_stats, s, who, 0, opt);
 }
 
 }  // namespace

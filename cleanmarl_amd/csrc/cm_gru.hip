@@ -1367,12 +1367,12 @@ extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int 
     return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
 }
 
-extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
-                                          const float* logp_old, const float* adv, const int32_t* ep_len,
-                                          int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
-                                          const float* params, const float* h_in, float* h_out,
-                                          double ppo_clip, double entropy_coef,
-                                          float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t* action,
+                          const float* logp_old, const float* adv, const int32_t* ep_len,
+                          int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                          const float* params, const float* h_in, float* h_out,
+                          double ppo_clip, double entropy_coef,
+                          float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream, const cm_opt_step_t* opt) {
     if (int rc = gru_check("cm_gru_actor_chunk_fwd_bwd", din, hidden, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T, "cm_gru_actor_chunk_fwd_bwd: bad dims E=%d A=%d T=%d t0=%d t1=%d", E, A, T, t0, t1);
     const size_t need = cm_gru_workspace_bytes(E, A, din, hidden, n_actions, t1 - t0);
@@ -1423,7 +1423,7 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
         const int64_t P2 = cm_gru_param_count(din, hidden, n_actions);
         MlpArgs m2 = {};
         m2.partial = a.partial; m2.PS = a.PS;
-        return finish_train(m2, grid32, P2, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
+        return finish_train(m2, grid32, P2, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
     }
     if (fwd32) {
         const size_t lds32 = gru32_lds_bytes(KP32);
@@ -1455,8 +1455,27 @@ extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail
     const int64_t P = cm_gru_param_count(din, hidden, n_actions);
     MlpArgs m = {};
     m.partial = a.partial; m.PS = a.PS;
-    if (!fwd32) return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");
-    return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd");  // both sweeps: grid32 partial rows
+    if (!fwd32) return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
+    return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);  // both sweeps: grid32 partial rows
+}
+
+extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
+                                          const float* logp_old, const float* adv, const int32_t* ep_len,
+                                          int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                                          const float* params, const float* h_in, float* h_out,
+                                          double ppo_clip, double entropy_coef,
+                                          float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    return gru_chunk_pass(obs, avail, action, logp_old, adv, ep_len, E, A, T, t0, t1, din, hidden, n_actions, params, h_in, h_out, ppo_clip,
+                          entropy_coef, grad_and_stats, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int cm_gru_actor_chunk_train_step(const float* obs, const uint8_t* avail, const int32_t* action,
+                                             const float* logp_old, const float* adv, const int32_t* ep_len,
+                                             int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                                             const float* h_in, float* h_out, double ppo_clip, double entropy_coef,
+                                             float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream) {
+    CM_REQUIRE(opt && opt->params, "cm_gru_actor_chunk_train_step: cm_opt_step_t / params is NULL");
+    return gru_chunk_pass(obs, avail, action, logp_old, adv, ep_len, E, A, T, t0, t1, din, hidden, n_actions, opt->params, h_in, h_out, ppo_clip,
+                          entropy_coef, grad_and_stats, ws, ws_bytes, stream, opt);
 }
 
 extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,

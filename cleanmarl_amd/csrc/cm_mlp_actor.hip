@@ -16,11 +16,18 @@ extern "C" size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int
     return train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
 }
 
-extern "C" int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
-                                       const float* logp_old, const float* adv, const int32_t* ep_len,
-                                    int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
-                                    const float* params, double ppo_clip, double entropy_coef,
-                                    float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+// the stand-alone optimiser step behind a schedule that cannot carry it in its reduction launch (layered shapes)
+static int step_after(int rc, float* grad_and_stats, int64_t P, const cm_opt_step_t* o, cm_stream_t stream) {
+    if (rc || !o) return rc;
+    return cm_grad_norm_clip_adam(o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq, P, o->step, o->lr, o->beta1, o->beta2, o->eps,
+                                  o->weight_decay, o->opt_kind, o->max_norm, o->grad_scale, o->out_norm, stream);
+}
+
+static int actor_pass(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                      const float* logp_old, const float* adv, const int32_t* ep_len,
+                      int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                      const float* params, double ppo_clip, double entropy_coef,
+                      float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream, const cm_opt_step_t* opt) {
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_ld >= din, "cm_ppo_actor_fwd_bwd: bad dims E=%d A=%d T=%d ld=%lld din=%d", E, A, T, (long long)obs_ld, din);
     if (wide_shape(hidden, n_hidden_layers)) {  // layered schedule (cm_mlp_wide.h)
         MlpArgs a = {};
@@ -29,7 +36,8 @@ extern "C" int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const u
         a.action = action; a.logp_old = logp_old; a.adv = adv; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
         a.clip_lo = (float)(1.0 - ppo_clip); a.clip_hi = (float)(1.0 + ppo_clip); a.clip_eps = (float)ppo_clip;
         a.ent_coef = (float)entropy_coef;
-        return wide_train<M_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");
+        return step_after(wide_train<M_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd"), grad_and_stats,
+                          cm_mlp_param_count(din, hidden, n_hidden_layers, n_actions), opt, stream);
     }
     if (int rc = check_shapes("cm_ppo_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     const size_t need = train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
@@ -50,7 +58,26 @@ extern "C" int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const u
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     if (int rc = launch_train<M_ACTOR>(a, grid, lds_bytes, (hipStream_t)stream)) return rc;
     CM_CHECK_LAUNCH("cm_ppo_actor_fwd_bwd");
-    return finish_train(a, grid, P, grad_and_stats, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd");
+    return finish_train(a, grid, P, grad_and_stats, (hipStream_t)stream, "cm_ppo_actor_fwd_bwd", 0, opt);
+}
+
+extern "C" int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                                       const float* logp_old, const float* adv, const int32_t* ep_len,
+                                       int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                                       const float* params, double ppo_clip, double entropy_coef,
+                                       float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    return actor_pass(obs, obs_ld, avail, action, logp_old, adv, ep_len, E, A, T, din, hidden, n_hidden_layers, n_actions, params, ppo_clip,
+                      entropy_coef, grad_and_stats, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int cm_ppo_actor_train_step_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                                          const float* logp_old, const float* adv, const int32_t* ep_len,
+                                          int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                                          double ppo_clip, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                          const cm_opt_step_t* opt, cm_stream_t stream) {
+    CM_REQUIRE(opt && opt->params, "cm_ppo_actor_train_step: cm_opt_step_t / params is NULL");
+    return actor_pass(obs, obs_ld, avail, action, logp_old, adv, ep_len, E, A, T, din, hidden, n_hidden_layers, n_actions, opt->params, ppo_clip,
+                      entropy_coef, grad_and_stats, ws, ws_bytes, stream, opt);
 }
 
 extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,

@@ -87,9 +87,10 @@ constexpr int DW0_GRID = 512;
 inline bool use_split(int din) { return (din + KC - 1) / KC > CM_WG2_MAX_NCH; }
 
 // dW[H x din] = dz0[rows][HP]^T X[rows][din]: per-workgroup partials -> out[H * din]
+// grid2_out != NULL: leave the partial rows unreduced and report their count (the caller folds them, e.g. with the optimiser step)
 template <bool GEN = false>
 inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H, float* part2, float* out, hipStream_t s, const char* who,
-                     int ldz = HP, long ldx = 0) {
+                     int ldz = HP, long ldx = 0, int* grid2_out = nullptr) {
     long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
     rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
     const int grid2 = (int)((rows + rpw - 1) / rpw);
@@ -104,6 +105,7 @@ inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H
         }
     }
     CM_CHECK_LAUNCH(who);
+    if (grid2_out) { *grid2_out = grid2; return 0; }
     hipLaunchKernelGGL(k_reduce_partials, dim3((PS2 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part2, grid2, PS2, 0, PS2, out);
     CM_CHECK_LAUNCH(who);
     return 0;
@@ -118,7 +120,7 @@ inline size_t split_ws_bytes(long rows, int din, int hidden, int L, int dout) {
 
 // a: fully populated MlpArgs except partial / PS / dz0 / prof.  Launches the schedule, reduces into grad_and_stats[P + 8].
 template <int MODE>
-inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who, const cm_opt_step_t* opt = nullptr) {
     const size_t need = split_ws_bytes(a.rows, a.din, a.H, a.L, a.dout);
     CM_REQUIRE(ws && ws_bytes >= need, "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     const int64_t P = cm_mlp_param_count(a.din, a.H, a.L, a.dout);
@@ -133,7 +135,7 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
         const int grid = grid_for(a.rows, nch);
         if (int rc = launch_train_small<MODE>(a, grid, lds_bytes, s)) return rc;
         CM_CHECK_LAUNCH(who);
-        return finish_train(a, grid, P, grad_and_stats, s, who);
+        return finish_train(a, grid, P, grad_and_stats, s, who, 0, opt);
     }
     // ---- split schedule: fused kernel without dW0 (two workgroups per CU) ...
     float* own = (float*)ws + (size_t)MAX_GRID * a.PS + w0_image_floats(a.din, a.H);
@@ -142,6 +144,11 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
     const int grid = grid_for(a.rows, 0);
     launch_variant<0, MODE>(a, grid, lds_bytes, s);
     CM_CHECK_LAUNCH(who);
+    if (opt) {  // both partial sets folded by the optimiser-step launch
+        int grid2 = 0;
+        if (int rc = stream_dw(a.dz0, a.x, a.rows, a.din, a.H, part2, grad_and_stats, s, who, HP, a.x_stride, &grid2)) return rc;
+        return cm_launch_reduce_step(a.partial, grid, a.PS, part2, grid2, a.H * a.din, a.H * a.din, P, grad_and_stats, opt, s, who);
+    }
     if (int rc = finish_train(a, grid, P, grad_and_stats, s, who, a.H * a.din)) return rc;  // all but W0
     // ---- ... then the streaming layer-0 weight gradient
     return stream_dw(a.dz0, a.x, a.rows, a.din, a.H, part2, grad_and_stats, s, who, HP, a.x_stride);

@@ -10,23 +10,166 @@
 // The parameter vectors are tiny (8k - 30k floats): a one-workgroup norm pass followed by an element-wise update over a handful of
 // workgroups (larger vectors: ONE workgroup of 1024 threads does both passes in a single launch).  No host sync, no atomics, deterministic.
 #include "cm_common.h"
+#include <atomic>
 
 #define OPT_THREADS 1024
 
+// ---- the optimiser step fused behind a training pass: ONE launch folds the per-workgroup partial gradients, scales by
+// grad_scale / N, takes the pre-clip norm and applies the update (a9 tail + a10 + a12; cleanmarl/mappo_multienvs.py:572-594).
+//
+// Before: k_reduce_partials -> k_grad_norm_small -> k_clip_adam_update, three dependent launches per network and optimiser step
+// (a 512-env share of config 3 spent ~75 us per actor epoch in them; the GRU learner takes 39 steps per iteration).  The update of a
+// column needs only that column's sum and N, so every workgroup of the reduction applies it at once; the norm (logged, :584-585) is
+// finished by workgroup 0 from per-workgroup sums of squares handed over through caller-owned scratch, in a fixed order.
+// Only clipping (max_norm > 0, off by default, :62-63) makes the update depend on the global norm: then this launch stops after
+// the norm and k_clip_adam_update follows (two launches instead of three).
+// The column sums are formed in exactly the order of k_reduce_partials and the update uses the same two roundings as
+// k_clip_adam_update, so parameters and moments are bit-identical to the three-launch path (tests/test_hip_parity.py).
+
 // one parameter's update; mi / vi are the two state slots (Adam: exp_avg, exp_avg_sq; RMSprop: vi = square_avg; SGD: unused)
-__device__ __forceinline__ float cm_opt_step(int kind, float p, float gi, float& mi, float& vi, float lr, float step_size, float beta1,
-                                             float beta2, float eps, float weight_decay, float bc2_sqrt) {
-    if (kind == CM_OPT_SGD) return p - lr * gi;
+// Every product / sum is an explicitly rounded operation (no fp contraction): the function is inlined into kernels with different
+// surrounding code, and the fused and the stand-alone step must round identically.
+__device__ __forceinline__ float cm_opt_apply(int kind, float p, float gi, float& mi, float& vi, float lr, float step_size, float beta1,
+                                              float beta2, float eps, float weight_decay, float bc2_sqrt) {
+    if (kind == CM_OPT_SGD) return __fsub_rn(p, __fmul_rn(lr, gi));
     if (kind == CM_OPT_RMSPROP) {
-        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
-        return p - lr * (gi / (sqrtf(vi) + eps));
+        vi = __fadd_rn(__fmul_rn(beta2, vi), __fmul_rn(__fmul_rn(1.0f - beta2, gi), gi));
+        return __fsub_rn(p, __fmul_rn(lr, gi / __fadd_rn(sqrtf(vi), eps)));
     }
-    if (kind == CM_OPT_ADAMW) p *= (1.0f - lr * weight_decay);
-    mi = beta1 * mi + (1.0f - beta1) * gi;
-    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    return p - step_size * (mi / denom);
+    if (kind == CM_OPT_ADAMW) p = __fmul_rn(p, 1.0f - __fmul_rn(lr, weight_decay));
+    mi = __fadd_rn(__fmul_rn(beta1, mi), __fmul_rn(1.0f - beta1, gi));
+    vi = __fadd_rn(__fmul_rn(beta2, vi), __fmul_rn(__fmul_rn(1.0f - beta2, gi), gi));
+    const float denom = __fadd_rn(sqrtf(vi) / bc2_sqrt, eps);
+    return __fsub_rn(p, __fmul_rn(step_size, mi / denom));
 }
+
+namespace {
+
+constexpr int STEP_COLS = 64, STEP_GROUPS = 16;       // the tiling of k_reduce_partials (cm_mlp_kernel.h): same summation order
+constexpr int STEP_MAX_WG = 1024;                     // sumsq slots in the scratch: n + 8 <= 65536 columns take the fused launch
+constexpr size_t STEP_SCRATCH_BYTES = 64 + STEP_MAX_WG * sizeof(unsigned long long);
+
+struct StepArgs {
+    const float* part1; int np1, PS1;  // partial rows holding columns [isplit, ntot) -- always the statistics
+    const float* part2; int np2, PS2;  // partial rows holding columns [0, isplit)    -- the split critic's streamed dW0; isplit = 0: none
+    int isplit, n, ntot;               // n parameters, ntot = n + CM_NUM_STATS columns
+    float* g; float* params; float* m; float* v;
+    float lr, bc1, beta1, beta2, eps, wd, grad_scale, bc2_sqrt; int kind;
+    float* out_norm; unsigned long long* nword; unsigned long long* slots; unsigned tag;
+};
+
+// sum of column i over the np partial rows, in the order of k_reduce_partials: row group g takes rows g, g + 16, g + 32, ... into two
+// alternating accumulators.  All loads of a batch of rows are issued before the first add (the loop of k_reduce_partials keeps two in flight).
+__device__ __forceinline__ float step_colsum(const float* __restrict__ p, int np, int PS, int i, int g) {
+    // STEP_BATCH loads in flight per thread (16 waves per workgroup keep the memory pipe busy); a larger batch only costs registers, and a
+    // 1024-thread workgroup at > 64 registers per lane no longer fits beside the critic's persistent workgroups on the other stream
+    // (32 in flight = 108 registers: the launch then waited for whole free CUs, 512-env share 1.54 -> 1.72 ms)
+    constexpr int STEP_BATCH = 8;
+    float s0 = 0.f, s1 = 0.f;
+    for (int w0 = g; w0 < np; w0 += STEP_BATCH * STEP_GROUPS) {
+        float v[STEP_BATCH];
+#pragma unroll
+        for (int k = 0; k < STEP_BATCH; ++k) {
+            const int w = w0 + k * STEP_GROUPS;
+            v[k] = (w < np) ? p[(size_t)w * PS + i] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < STEP_BATCH; k += 2) { s0 += v[k]; s1 += v[k + 1]; }
+    }
+    return s0 + s1;
+}
+
+// Cross-workgroup hand-offs WITHOUT fences.  The eight XCDs of the chip have private L2s, so an agent-scope release / acquire
+// (__threadfence, acquire loads) compiles to buffer_wbl2 / buffer_inv of a whole L2 -- per workgroup, under a concurrently running
+// critic kernel: the first version of this launch was SLOWER than the three it replaced (512-env share 1.54 -> 1.77 ms).  Every
+// hand-off here is therefore ONE relaxed 64-bit atomic word {launch tag, fp32 payload} (sc1: performed at the device coherence
+// point, no cache maintenance); a word is valid when its tag is this launch's -- nothing is reset, stale words carry older tags.
+//   * N = b_mask.sum() is the sum of one column (n + CM_STAT_COUNT) that every workgroup needs before it can scale.  Re-reading
+//     that column in every workgroup put np x grid requests on the same few L2 channels; instead workgroup 0 takes the slab that
+//     holds it and publishes {tag, N}; the others fold their own columns meanwhile and then wait for that word -- only ever for
+//     workgroup 0, which is dispatched before them (the dependence direction of a decoupled look-back scan).
+//   * the norm: every workgroup publishes {tag, sum of squares of its slab}; workgroup 0, done with its own slab, polls the slots
+//     and adds them in slot order (deterministic).  It waits for workgroups that wait for nothing but its own earlier N word.
+__device__ __forceinline__ unsigned long long step_word(unsigned tag, float v) {
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ float step_wait(const unsigned long long* p, unsigned tag) {
+    unsigned long long w;
+    while ((unsigned)((w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) __builtin_amdgcn_s_sleep(2);
+    return __uint_as_float((unsigned)w);
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(STEP_COLS * STEP_GROUPS) void k_reduce_step(const StepArgs a) {
+    __shared__ float sh[STEP_GROUPS][STEP_COLS];
+    const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;
+    const int icnt = a.n + CM_STAT_COUNT, slab_n = icnt / STEP_COLS;
+    const int slab = blockIdx.x == 0 ? slab_n : ((int)blockIdx.x <= slab_n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+    const int i = slab * STEP_COLS + c;
+    float s = 0.f;
+    if (i < a.ntot) s = (i < a.isplit) ? step_colsum(a.part2, a.np2, a.PS2, i, g) : step_colsum(a.part1, a.np1, a.PS1, i, g);
+    sh[g][c] = s;
+    __syncthreads();
+    if (g != 0) return;  // wave 0 finishes its 64 columns
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < STEP_GROUPS; ++q) t += sh[q][c];
+    float N;
+    if (blockIdx.x == 0) {
+        N = __shfl(t, icnt - slab_n * STEP_COLS, 64);
+        if (c == 0) __hip_atomic_store(a.nword, step_word(a.tag, N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        N = 0.f;
+        if (c == 0) N = step_wait(a.nword, a.tag);
+        N = __shfl(N, 0, 64);
+    }
+    const float scale = (N > 0.0f) ? a.grad_scale / N : 0.0f;
+    const float step_size = a.lr / a.bc1;
+    float ss = 0.f;
+    if (i < a.n) {
+        const float gi = __fmul_rn(t, scale);
+        ss = __fmul_rn(gi, gi);
+        if (UPDATE) {
+            a.g[i] = gi;  // what optimizer.step() consumed stays readable
+            float mi = a.m ? a.m[i] : 0.0f, vi = a.v ? a.v[i] : 0.0f;
+            a.params[i] = cm_opt_apply(a.kind, a.params[i], gi, mi, vi, a.lr, step_size, a.beta1, a.beta2, a.eps, a.wd, a.bc2_sqrt);
+            if (a.m) a.m[i] = mi;
+            if (a.v) a.v[i] = vi;
+        } else {
+            a.g[i] = t;   // k_clip_adam_update scales and clips
+        }
+    } else if (i < a.ntot) {
+        a.g[i] = t;       // statistics: un-normalised sums
+    }
+    ss = cm_wave_sum(ss);
+    if (c == 0) __hip_atomic_store(a.slots + blockIdx.x, step_word(a.tag, ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x != 0) return;
+    float tot = 0.f;
+    for (int j = c; j < (int)gridDim.x; j += STEP_COLS) tot += step_wait(a.slots + j, a.tag);
+    tot = cm_wave_sum(tot);
+    if (c == 0) a.out_norm[0] = sqrtf(tot);
+}
+
+// plain fold of the same two partial sets (vectors beyond the fused launch's scratch)
+__global__ __launch_bounds__(STEP_COLS * STEP_GROUPS) void k_reduce_cols(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2,
+                                                                         int isplit, int ntot, float* __restrict__ out) {
+    __shared__ float sh[STEP_GROUPS][STEP_COLS];
+    const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;
+    const int i = blockIdx.x * STEP_COLS + c;
+    float s = 0.f;
+    if (i < ntot) s = (part2 && i < isplit) ? step_colsum(part2, np2, PS2, i, g) : step_colsum(part1, np1, PS1, i, g);
+    sh[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < ntot) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < STEP_GROUPS; ++q) t += sh[q][c];
+        out[i] = t;
+    }
+}
+
+}  // namespace
+
 
 __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam(
     float* __restrict__ params, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
@@ -61,7 +204,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_clip_adam(
         const float gi = g[i] * coef;
         g[i] = gi;  // post-clip gradient stays readable (what optimizer.step() consumed)
         float mi = m[i], vi = v[i];
-        params[i] = cm_opt_step(opt_kind, params[i], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
+        params[i] = cm_opt_apply(opt_kind, params[i], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
         m[i] = mi; v[i] = vi;
     }
 }
@@ -120,10 +263,70 @@ __global__ __launch_bounds__(UPD_THREADS) void k_clip_adam_update(
             const float gi = (gv[k] * scale) * coef;  // same two roundings as the one-launch kernel
             g[i] = gi;
             float mi = mv[k], vi = vv[k];
-            params[i] = cm_opt_step(opt_kind, pv[k], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
+            params[i] = cm_opt_apply(opt_kind, pv[k], gi, mi, vi, lr, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
             m[i] = mi; v[i] = vi;
         }
     }
+}
+
+// tags of the hand-off words: unique per launch within the process, never 0 (a zeroed scratch holds tag 0).  A nonce, not state: no
+// result depends on its value.
+static unsigned next_step_tag() {
+    static std::atomic<unsigned> tag{0};
+    unsigned t;
+    do { t = tag.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (t == 0u);
+    return t;
+}
+
+static int opt_check(const char* who, int64_t n_params, const cm_opt_step_t* o) {
+    CM_REQUIRE(o && o->params && o->out_norm, "%s: cm_opt_step_t with NULL params / out_norm", who);
+    CM_REQUIRE(n_params > 0 && o->step >= 1, "%s: bad n_params=%ld step=%d", who, (long)n_params, (int)o->step);
+    CM_REQUIRE(o->opt_kind >= CM_OPT_ADAM && o->opt_kind <= CM_OPT_RMSPROP, "%s: unknown optimiser kind %d", who, (int)o->opt_kind);
+    CM_REQUIRE(o->opt_kind == CM_OPT_SGD || (o->exp_avg_sq && (o->opt_kind == CM_OPT_RMSPROP || o->exp_avg)), "%s: optimiser state pointer is NULL", who);
+    return 0;
+}
+
+extern "C" size_t cm_opt_step_scratch_bytes(void) { return STEP_SCRATCH_BYTES; }
+
+// [part1 | part2] partial rows -> grad_and_stats + optimiser step.  part2 == NULL: every column comes from part1.
+int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
+                          float* grad_and_stats, const cm_opt_step_t* o, hipStream_t s, const char* who) {
+    if (int rc = opt_check(who, n_params, o)) return rc;
+    const int64_t ntot = n_params + CM_NUM_STATS;
+    const int grid = (int)((ntot + STEP_COLS - 1) / STEP_COLS);
+    const double bc1 = 1.0 - pow(o->beta1, (double)o->step), bc2 = 1.0 - pow(o->beta2, (double)o->step);
+    if (grid > STEP_MAX_WG || !o->scratch) {
+        // beyond the scratch's sumsq slots (or no scratch): plain reduction + the stand-alone step
+        hipLaunchKernelGGL(k_reduce_cols, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, part1, np1, PS1, part2, np2, PS2, isplit, (int)ntot, grad_and_stats);
+        CM_CHECK_LAUNCH(who);
+        return cm_grad_norm_clip_adam(o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq, n_params, o->step, o->lr, o->beta1, o->beta2, o->eps,
+                                      o->weight_decay, o->opt_kind, o->max_norm, o->grad_scale, o->out_norm, (cm_stream_t)s);
+    }
+    CM_REQUIRE((reinterpret_cast<uintptr_t>(o->scratch) & 15) == 0, "%s: cm_opt_step_t scratch must be 16-byte aligned", who);
+    StepArgs a = {};
+    a.part1 = part1; a.np1 = np1; a.PS1 = PS1; a.part2 = part2; a.np2 = np2; a.PS2 = PS2; a.isplit = part2 ? isplit : 0;
+    a.n = (int)n_params; a.ntot = (int)ntot;
+    a.g = grad_and_stats; a.params = o->params; a.m = o->exp_avg; a.v = o->exp_avg_sq;
+    a.lr = (float)o->lr; a.bc1 = (float)bc1; a.beta1 = (float)o->beta1; a.beta2 = (float)o->beta2; a.eps = (float)o->eps;
+    a.wd = (float)o->weight_decay; a.grad_scale = (float)o->grad_scale; a.bc2_sqrt = (float)sqrt(bc2); a.kind = o->opt_kind;
+    a.out_norm = o->out_norm; a.nword = (unsigned long long*)o->scratch; a.slots = a.nword + 8;
+    a.tag = next_step_tag();
+    if (o->max_norm > 0.0) {
+        hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        const int ugrid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
+        hipLaunchKernelGGL(k_clip_adam_update, dim3(ugrid), dim3(UPD_THREADS), 0, s, o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq,
+                           (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm);
+    } else {
+        hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+    }
+    CM_CHECK_LAUNCH(who);
+    return 0;
+}
+
+extern "C" int cm_optimizer_step(float* grad_and_stats, int64_t n_params, const cm_opt_step_t* opt, cm_stream_t stream) {
+    CM_REQUIRE(grad_and_stats, "cm_optimizer_step: grad_and_stats is NULL");
+    // the reduced buffer is its own single "partial row" (row stride irrelevant)
+    return cm_launch_reduce_step(grad_and_stats, 1, 0, nullptr, 0, 0, 0, n_params, grad_and_stats, opt, (hipStream_t)stream, "cm_optimizer_step");
 }
 
 extern "C" int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, float* exp_avg, float* exp_avg_sq,

@@ -17,6 +17,15 @@ extern unsigned long long* g_prof;
 
 namespace {
 
+// The rollout is a latency chain (a few waves per CU, each step a sequence of dependent LDS / MFMA / DPP operations) that the learner
+// deliberately overlaps with the critic's epochs of the previous iteration (learner.overlap_critic): its waves are rarely ready, but
+// when they are, every issue slot lost to a co-resident throughput kernel lengthens the chain (512-env share: 0.475 ms alone, 0.51 -
+// 0.68 ms beside the critic's k_mlp).  Highest wave priority makes the SIMD's arbiter pick them first; CM_ROLLOUT_PRIO=0 builds without.
+#ifndef CM_ROLLOUT_PRIO
+#define CM_ROLLOUT_PRIO 3
+#endif
+#define ROLLOUT_WAVE_PRIO() __builtin_amdgcn_s_setprio(CM_ROLLOUT_PRIO)
+
 constexpr float DAMP = 0.25f, DT = 0.1f, ACCEL = 5.0f, COLLIDE = 0.3f;
 
 struct RolloutArgs {
@@ -33,6 +42,7 @@ struct RolloutArgs {
 
 __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROLLOUT_WAVE_PRIO();
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
@@ -414,6 +424,7 @@ __device__ __forceinline__ f32x4 head_logits_reg(const float* HL, const float (&
 
 __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    ROLLOUT_WAVE_PRIO();
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g16 = lane >> 4;

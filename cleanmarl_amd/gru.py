@@ -52,6 +52,7 @@ class GRUPPOLearner(PPOLearner):
         # sweeps -- E*A/32 workgroups, fewer than the 256 CUs at config 5 -- and strictly sequential, so the critic kernels fill the
         # idle CUs instead of extending the serial chain.  Issue order (critic epoch, then that epoch's chunks) is identical on all
         # ranks, so the collectives still pair up.
+        ride = self.fused_step and not self._coll
         main = torch.cuda.current_stream()
         if self._critic_stream is None:
             self._critic_stream = N.side_stream(self.device)  # one per process: see _native.low_priority_stream
@@ -61,9 +62,12 @@ class GRUPPOLearner(PPOLearner):
         for ep in range(nE):
             with torch.cuda.stream(side):
                 sc = N.stream_ptr()
-                self._timed("critic", self.critic_pass, b, sc)
-                dist.allreduce_sum_(self.g_critic, self.pg_c, self.world)  # own communicator: never queues ahead of a chunk's message
-                self._adam(self.critic, self.g_critic, self.opt_c, 1, sc)
+                if ride:  # one process: the optimiser step rides on the pass's reduction launch
+                    self._timed("critic", self.critic_pass, b, sc, None, self.norms[1:])
+                else:
+                    self._timed("critic", self.critic_pass, b, sc)
+                    self._allreduce(self.g_critic, self.pg_c)  # own communicator: never queues ahead of a chunk's message
+                    self._adam(self.critic, self.g_critic, self.opt_c, 1, sc)
                 rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
                 rec_c[ep, N.NUM_STATS] = self.norms[1]
                 if keep_grads:
@@ -76,13 +80,21 @@ class GRUPPOLearner(PPOLearner):
             for ci, (t0, t1) in enumerate(chunks):
                 h_out = self.h[ci & 1]
                 g = self.g_rows[ci]  # one [grads | stats] row per chunk: the statistics survive without per-chunk copies
-                N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
-                    N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
-                    b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(self.actor), N.ptr(h_in), N.ptr(h_out),
-                    hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
-                    "cm_gru_actor_chunk_fwd_bwd")
-                self._allreduce(g)
-                self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:])
+                if ride:
+                    o = self.opt_a.next_step(self.actor, rec_a[ep, ci, N.NUM_STATS:], hp.clip_gradients, 1.0 / (t1 - t0))
+                    N.check(self.lib.cm_gru_actor_chunk_train_step(
+                        N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
+                        b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(h_in), N.ptr(h_out),
+                        hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), o, s),
+                        "cm_gru_actor_chunk_train_step")
+                else:
+                    N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
+                        N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
+                        b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(self.actor), N.ptr(h_in), N.ptr(h_out),
+                        hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
+                        "cm_gru_actor_chunk_fwd_bwd")
+                    self._allreduce(g)
+                    self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:])
                 if keep_grads:
                     steps.append((g[:Pa].clone(), self.actor.clone()))
                 h_in = h_out

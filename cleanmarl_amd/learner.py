@@ -157,6 +157,15 @@ class _Adam:
         self.m = torch.zeros(nparams, dtype=torch.float32, device=device)
         self.v = torch.zeros(nparams, dtype=torch.float32, device=device)
         self.step = 0
+        # ticket + per-workgroup sums of squares of the fused step launch (cm_opt_step_t.scratch): zeroed once, left zeroed by the kernels
+        self.scratch = torch.zeros(N.load().cm_opt_step_scratch_bytes(), dtype=torch.uint8, device=device)
+
+    def next_step(self, params, out_norm, max_norm, grad_scale=1.0):
+        """cm_opt_step_t of the NEXT optimiser step on `params` (advances the step counter)."""
+        self.step += 1
+        return N.OptStep(params=params.data_ptr(), exp_avg=self.m.data_ptr(), exp_avg_sq=self.v.data_ptr(), out_norm=out_norm.data_ptr(),
+                         scratch=self.scratch.data_ptr(), lr=self.lr, beta1=0.9, beta2=self.beta2, eps=1e-8, weight_decay=self.wd,
+                         max_norm=float(max_norm), grad_scale=float(grad_scale), step=self.step, opt_kind=self.kind)
 
 
 class LazyRecords:
@@ -264,16 +273,27 @@ class PPOLearner:
         # RCCL (backend "nccl") on the one GPU it has; a 1-rank sum is the identity, so the results must equal the plain run
         import os
         self._coll = world_size > 1 or (process_group is not None and os.environ.get("CM_FORCE_COLLECTIVES") == "1")
-        self.pg_c = torch.distributed.new_group() if (self._coll and process_group is not None) else process_group
+        # ... spanning exactly the ranks of `process_group` (the default group when None): new_group() must be entered by every rank of
+        # the world, which env-sharded runs do (every rank builds the same learner); a learner on a sub-group gets a sub-group
+        self.pg_c = process_group
+        if self._coll and torch.distributed.is_initialized():
+            ranks = torch.distributed.get_process_group_ranks(process_group if process_group is not None else torch.distributed.group.WORLD)
+            self.pg_c = torch.distributed.new_group(ranks=ranks)
+        self.global_envs = None  # env count of the WHOLE run (driver / bench set it): the schedule choice must not depend on the local shard
+        self._sched_rows = {}
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
         self.events = None  # bench.py sets this to a list to collect per-launch (kind, start, end) HIP events
         self._ring = _HostRing()
+        # optimiser steps as ONE launch (cm_optimizer_step), riding on the reduction launch of the pass when no all-reduce comes between
+        # the two (cm_*_train_step); False: the stand-alone reduce / norm / update launches (A/B runs; bit-identical, tests/test_hip_parity.py)
+        self.fused_step = os.environ.get("CM_FUSED_STEP", "1") != "0"
 
     # ------------------------------------------------------------------ helpers
-    def _allreduce(self, t):
-        dist.allreduce_sum_(t, self.pg, self.world)
+    def _allreduce(self, t, pg=None):
+        if self._coll:
+            torch.distributed.all_reduce(t, group=self.pg if pg is None else pg)
 
     def _moments(self, x, ep_len, E, A, T, s):
         """(count, mean, M2) of the agent-mean over valid steps; merged across ranks (Chan et al.)."""
@@ -315,12 +335,16 @@ class PPOLearner:
     # ------------------------------------------------------------------ a8 - a12
     def _adam(self, params, g, opt, which, s, grad_scale=1.0, out_norm=None):
         """out_norm: 1-element device view that receives the pre-clip gradient norm (default: self.norms[which])."""
-        opt.step += 1
         hp = self.hp
-        N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
-                                                opt.lr, 0.9, opt.beta2, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
-                                                grad_scale, N.ptr(self.norms[which:] if out_norm is None else out_norm), s),
-                "cm_grad_norm_clip_adam")
+        if not self.fused_step:  # the stand-alone two-launch step (A/B runs, tests of the fused launch against it)
+            opt.step += 1
+            N.check(self.lib.cm_grad_norm_clip_adam(N.ptr(params), N.ptr(g), N.ptr(opt.m), N.ptr(opt.v), params.numel(), opt.step,
+                                                    opt.lr, 0.9, opt.beta2, 1e-8, opt.wd, opt.kind, float(hp.clip_gradients),
+                                                    grad_scale, N.ptr(self.norms[which:] if out_norm is None else out_norm), s),
+                    "cm_grad_norm_clip_adam")
+            return
+        o = opt.next_step(params, self.norms[which:] if out_norm is None else out_norm, hp.clip_gradients, grad_scale)
+        N.check(self.lib.cm_optimizer_step(N.ptr(g), params.numel(), o, s), "cm_optimizer_step")
 
     def _timed(self, kind, fn, *a):
         if self.events is None:
@@ -344,26 +368,50 @@ class PPOLearner:
             if self.ws is None or self.ws.numel() < need:
                 self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
 
+    def critic_params(self):
+        """The critic's flat parameters once the epochs still in flight on the critic stream are done (readers of `self.critic` on
+        another stream -- .cpu(), clone() -- must go through here or call wait_critic() first)."""
+        self.wait_critic()
+        return self.critic
+
     def wait_critic(self):
         """Make the current stream wait for the critic epochs of the last update() (they run on their own stream and are not joined
         there).  Called by every reader of the critic parameters / optimiser state: the value pass, state_dict(), single passes."""
         if self._critic_done is not None:
             torch.cuda.current_stream().wait_event(self._critic_done)
 
-    def critic_pass(self, b, s, g=None):
-        """g: [Pc + 8] gradient + statistics buffer to fill (default self.g_critic)."""
+    def critic_pass(self, b, s, g=None, step=None):
+        """g: [Pc + 8] gradient + statistics buffer to fill (default self.g_critic).  step: 1-element device view for the pre-clip norm --
+        the critic's optimiser step then rides on the pass's reduction launch (cm_critic_train_step_ld; one process only: no all-reduce
+        can come between the two)."""
+        self.wait_critic()  # a no-op on the critic stream itself; any other caller must not race the epochs still in flight there
         self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
+        if step is not None:
+            o = self.opt_c.next_step(self.critic, step, self.hp.clip_gradients)
+            N.check(self.lib.cm_critic_train_step_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len),
+                                                     b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
+                                                     N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), o, s),
+                    "cm_critic_train_step")
+            return
         N.check(self.lib.cm_critic_fwd_bwd_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
                                            0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
                                            N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), s),
                 "cm_critic_fwd_bwd")
 
-    def actor_pass(self, b, s, g=None):
-        """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor)."""
+    def actor_pass(self, b, s, g=None, step=None):
+        """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor).  step: see critic_pass."""
         self._ensure_ws(b)
         a = self.actor_spec
+        if step is not None:
+            o = self.opt_a.next_step(self.actor, step, self.hp.clip_gradients)
+            N.check(self.lib.cm_ppo_actor_train_step_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
+                                                        N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
+                                                        self.hp.ppo_clip, self.hp.entropy_coef,
+                                                        N.ptr(self.g_actor if g is None else g), N.ptr(self.ws), self.ws.numel(), o, s),
+                    "cm_ppo_actor_train_step")
+            return
         N.check(self.lib.cm_ppo_actor_fwd_bwd_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
                                               N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
                                               N.ptr(self.actor), self.hp.ppo_clip, self.hp.entropy_coef,
@@ -386,8 +434,24 @@ class PPOLearner:
         v = os.environ.get("CM_CRITIC_OVERLAP")
         if v in ("0", "1", "2"):
             return int(v)
-        rows = b.E * b.A * b.T
-        return 1 if rows <= (1 << 18) else 2 if rows <= (1 << 21) else 0
+        rows = self._schedule_rows(b)
+        return 1 if rows <= (1 << 19) else 2 if rows <= (1 << 21) else 0
+
+    def _schedule_rows(self, b):
+        """Row count the schedule is chosen from -- the SAME number on every rank: env shards may differ by one env (dist.shard), and
+        ranks on different sides of a threshold would interleave their collectives differently (schedule 0 waits for the critic's
+        message before the next actor pass, schedule 1 issues it after the actor's epochs: a cross-rank deadlock).  With
+        `global_envs` set (driver, bench) it is the largest shard's; otherwise the maximum over the ranks, agreed once per batch shape."""
+        if not self._coll or self.world <= 1:
+            return b.E * b.A * b.T
+        if self.global_envs is not None:
+            return -(-int(self.global_envs) // self.world) * b.A * b.T
+        key = (b.E, b.A, b.T)
+        if key not in self._sched_rows:
+            t = torch.tensor([b.E * b.A * b.T], dtype=torch.int64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            self._sched_rows[key] = int(t.item())
+        return self._sched_rows[key]
 
     def update(self, b, keep_grads=False):
         """`epochs` full-batch PPO steps (cleanmarl/mappo_multienvs.py:521-594).  The two networks are independent (separate losses,
@@ -415,8 +479,14 @@ class PPOLearner:
         timed = self.events is not None
         self.critic_span = None
 
+        ride = self.fused_step and not self._coll  # the optimiser step rides on the pass's reduction launch
+
         def actor_step(ep, wa):
             g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
+            if ride:
+                if keep_grads:
+                    kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
+                return
             if wa is not None:
                 wa.wait()
             self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
@@ -425,6 +495,10 @@ class PPOLearner:
 
         def critic_step(ep, wc, sc):
             g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
+            if ride:
+                if keep_grads:
+                    kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
+                return
             if wc is not None:
                 wc.wait()
             self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
@@ -435,11 +509,11 @@ class PPOLearner:
             pending = None  # the critic's optimiser step of the previous epoch, due before the next critic pass
             for ep in range(nE0):
                 g = self.gbuf_rows[ep]
-                self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS])
+                self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS], rec[ep, 2 * N.NUM_STATS:] if ride else None)
                 wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if self._coll else None
                 if pending is not None:
                     critic_step(*pending, s)
-                self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:])
+                self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:], rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
                 wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if self._coll else None
                 actor_step(ep, wa)
                 if self._coll:
@@ -459,7 +533,7 @@ class PPOLearner:
 
             def actor_epoch(ep):
                 g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
-                self._timed("actor", self.actor_pass, b, s, g_actor)
+                self._timed("actor", self.actor_pass, b, s, g_actor, rec[ep, 2 * N.NUM_STATS:] if ride else None)
                 actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self._coll else None)
 
             def critic_epoch(ep):
@@ -469,7 +543,7 @@ class PPOLearner:
                         self._c0 = torch.cuda.Event(enable_timing=True)
                         self._c0.record()
                     g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
-                    self._timed("critic", self.critic_pass, b, sc, g_critic)
+                    self._timed("critic", self.critic_pass, b, sc, g_critic, rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
                     critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self._coll else None, sc)
                     if ep == nE0 - 1:
                         rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]

@@ -63,7 +63,9 @@ class SyntheticSpreadRollout:
             return b
         if b.obs_ld != Do or b.state_ld != b.Ds:
             # the per-step env kernels (cm_synth_env_reset / _step) write contiguous rows: shapes the fused kernel does not cover (and
-            # explicit fused=False runs) switch this rollout to unpadded buffers, once
+            # explicit fused=False runs) switch this rollout to unpadded buffers, once.  The learner's critic epochs may still read the
+            # old buffers on their own stream: wait for the device before their storage goes back to the allocator (one-time cost)
+            torch.cuda.synchronize(self.device)
             self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
             for bb in self.batches:
                 bb.avail.fill_(1)

@@ -171,6 +171,37 @@ int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, float* exp_avg,
                            double weight_decay, int opt_kind, double max_norm, double grad_scale,
                            float* out_norm, cm_stream_t stream);
 
+/* ---- a9 tail + a10 / a11 / a12 fused BEHIND a training pass ("train_step" entry points) ----
+ * With one process the gradient of a pass goes straight into that network's optimiser step (mappo_multienvs.py:572-594 without an
+ * all-reduce in between): the *_train_step* variants of the three training passes take a cm_opt_step_t and fold the per-workgroup
+ * partial gradients, scale by grad_scale / N, take the pre-clip norm and apply the update in ONE launch behind the pass (two when
+ * max_norm > 0: the clip coefficient needs the global norm) instead of three.  Results are bit-identical to the pass followed by
+ * cm_grad_norm_clip_adam.  grad_and_stats receives the scaled (and clipped) gradient and the un-normalised statistics as before.
+ * scratch: caller-owned, cm_opt_step_scratch_bytes() bytes, 16-byte aligned, ZEROED ONCE when allocated and from then on touched
+ * only by these launches (tagged hand-off words between the workgroups of one launch; never reset, never read by the host);
+ * one scratch per optimiser if steps of different networks may overlap on different streams.
+ * cm_optimizer_step is the same single launch for a gradient that is already reduced (e.g. all-reduced across ranks). */
+typedef struct cm_opt_step {
+    float* params;      /* [n_params] updated in place (the pass may read the same buffer: the update launch follows it) */
+    float* exp_avg;     /* [n_params] Adam m            (unused by SGD / RMSprop) */
+    float* exp_avg_sq;  /* [n_params] Adam v / RMSprop square_avg (unused by SGD) */
+    float* out_norm;    /* [1] pre-clip global L2 norm of the scaled gradient */
+    void* scratch;
+    double lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale;
+    int32_t step;       /* 1-based optimiser step (bias correction) */
+    int32_t opt_kind;   /* CM_OPT_* */
+} cm_opt_step_t;
+size_t cm_opt_step_scratch_bytes(void);
+int cm_optimizer_step(float* grad_and_stats, int64_t n_params, const cm_opt_step_t* opt, cm_stream_t stream);
+int cm_ppo_actor_train_step_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
+                               const float* logp_old, const float* adv, const int32_t* ep_len,
+                               int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                               double ppo_clip, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
+                               const cm_opt_step_t* opt, cm_stream_t stream);
+int cm_critic_train_step_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
+                            int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                            float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream);
+
 /* ---- a13 / a14: GRU actor, TBPTT chunk  (cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620) ----
  * Forward + backward-through-time over steps [t0, t1) for all E*A sequences starting from the detached
  * hidden state h_in[E*A][H]; writes h_out (= h at t1, to be used detached for the next chunk) and the
@@ -182,6 +213,12 @@ int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int
                                const float* params, const float* h_in, float* h_out,
                                double ppo_clip, double entropy_coef,
                                float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* the chunk pass followed by the actor's optimiser step of mappo_lstm_multienvs.py:608-618 (grad_scale = 1 / chunk length), see cm_opt_step_t */
+int cm_gru_actor_chunk_train_step(const float* obs, const uint8_t* avail, const int32_t* action,
+                                  const float* logp_old, const float* adv, const int32_t* ep_len,
+                                  int E, int A, int T, int t0, int t1, int din, int hidden, int n_actions,
+                                  const float* h_in, float* h_out, double ppo_clip, double entropy_coef,
+                                  float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream);
 /* single rollout step of the GRU actor (mappo_lstm_multienvs.py:170-174, 421-425): h updated in place */
 int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
                       int64_t rows, int din, int hidden, int n_actions, const float* params, float* h,
