@@ -38,6 +38,8 @@ SIGNATURES = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (_i, []),
     "cm_mfma_mode": (_i, []),
+    "cm_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "cm_get_option": (C.c_char_p, [C.c_char_p]),
     "cm_mlp_forward_ld": (_i, [_p, _l, _l, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "cm_w0_image_bytes": (_sz, [_i, _i]),
     "cm_policy_act_episode_ld": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p, _sz, _p]),
@@ -126,7 +128,47 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    sync_env_options()
     return lib
+
+
+# The C library never reads the environment (include/cleanmarl_hip.h: cm_set_option).  The CM_* variables below are a convenience of
+# THIS package for A/B runs and tests: they are mapped onto cm_set_option when the library is loaded and again at the entry of every
+# learner update / target computation / rollout (sync_env_options is a few dictionary look-ups; the library is called on a change only).
+ENV_OPTIONS = {"CM_MLP_FORMS": "mlp_forms", "CM_CRITIC_SCHEDULE": "critic_schedule", "CM_GRU_TILE": "gru_tile",
+               "CM_ROLLOUT_TILE": "rollout_tile", "CM_MFMA": "mfma"}
+_DEFAULTS = {"mlp_forms": "auto", "critic_schedule": "auto", "gru_tile": "auto", "rollout_tile": "auto", "mfma": "fp32"}
+_applied = {}
+_env_seen = {}
+
+
+def set_option(key, value):
+    """cm_set_option(key, value); raises on an unknown key / value."""
+    check(load().cm_set_option(key.encode(), str(value).encode()), f"cm_set_option({key}, {value})")
+    _applied[key] = str(value)
+
+
+def get_option(key):
+    v = load().cm_get_option(key.encode())
+    if v is None:
+        raise NativeError(f"unknown option {key!r}")
+    return v.decode()
+
+
+def sync_env_options():
+    """Apply CM_* variables whose value CHANGED since the last look (an explicit set_option stays until its variable changes)."""
+    for env, key in ENV_OPTIONS.items():
+        cur = os.environ.get(env)
+        if _env_seen.get(env, None) == cur and env in _env_seen:
+            continue
+        if _lib is None:
+            return
+        want = cur or _DEFAULTS[key]
+        rc = _lib.cm_set_option(key.encode(), want.encode())
+        if rc != 0:
+            raise NativeError(f"{env}={want!r}: {(_lib.cm_last_error() or b'?').decode()}")
+        _env_seen[env] = cur
+        _applied[key] = want
 
 
 def check(rc, what):

@@ -113,6 +113,7 @@ class COMALearner:
 
     # ------------------------------------------------------------------ :553-618
     def compute_targets(self, b):
+        N.sync_env_options()
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
         self._ensure(b)
         E, A, T, K = b.E, b.A, b.T, b.K
@@ -133,6 +134,7 @@ class COMALearner:
 
     # ------------------------------------------------------------------ :620-684
     def update(self, b, keep_grads=False):
+        N.sync_env_options()
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
         self._ensure(b)
         E, A, T, K = b.E, b.A, b.T, b.K

@@ -1,6 +1,7 @@
 // cm_api.hip -- error plumbing + small C-ABI helpers of libcleanmarl_hip.so
 #include "cm_common.h"
 #include <string.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -14,11 +15,45 @@ void cm_set_error(const char* fmt, ...) {
 extern "C" const char* cm_last_error(void) { return g_err; }
 extern "C" int cm_version(void) { return 100; }
 
-// 0 = exact fp32 MFMA (default), 1 = CM_MFMA=bf16x3 (error-compensated bf16 GEMM loops in the PPO training passes)
-extern "C" int cm_mfma_mode(void) {
-    static const int mode = [] { const char* e = getenv("CM_MFMA"); return (e && strcmp(e, "bf16x3") == 0) ? 1 : 0; }();
-    return mode;
+// ---- schedule / arithmetic options (include/cleanmarl_hip.h: cm_set_option).  The library never reads the process environment:
+// a caller that wants to force a schedule says so through this entry point (cleanmarl_amd/_native.py maps its CM_* test hooks onto it).
+namespace {
+struct OptDef { const char* key; const char* const* names; const int* values; int n; };
+const char* const kFormsN[] = {"auto", "hand", "loop"};          const int kFormsV[] = {0, 1, 2};
+const char* const kCriticN[] = {"auto", "fused", "split"};       const int kCriticV[] = {0, 1, 2};
+const char* const kGruN[] = {"auto", "64"};                      const int kGruV[] = {0, 64};
+const char* const kRollN[] = {"auto", "64", "16", "16s"};        const int kRollV[] = {0, 64, 16, 17};
+const char* const kMfmaN[] = {"fp32", "bf16x3"};                 const int kMfmaV[] = {0, 1};
+const OptDef kOpts[CM_OPTION_COUNT] = {
+    {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 3}, {"gru_tile", kGruN, kGruV, 2},
+    {"rollout_tile", kRollN, kRollV, 4}, {"mfma", kMfmaN, kMfmaV, 2}};
+std::atomic<int> g_opt[CM_OPTION_COUNT];  // zero-initialised: every option starts at its first value
+}  // namespace
+
+int cm_option(int which) { return g_opt[which].load(std::memory_order_relaxed); }
+
+extern "C" int cm_set_option(const char* key, const char* value) {
+    CM_REQUIRE(key && value, "cm_set_option: NULL key / value");
+    for (int o = 0; o < CM_OPTION_COUNT; ++o) {
+        if (strcmp(key, kOpts[o].key) != 0) continue;
+        for (int i = 0; i < kOpts[o].n; ++i)
+            if (strcmp(value, kOpts[o].names[i]) == 0) { g_opt[o].store(kOpts[o].values[i], std::memory_order_relaxed); return 0; }
+        CM_FAIL(-1, "cm_set_option: option %s has no value \"%s\"", key, value);
+    }
+    CM_FAIL(-1, "cm_set_option: unknown option \"%s\"", key);
 }
+extern "C" const char* cm_get_option(const char* key) {
+    for (int o = 0; key && o < CM_OPTION_COUNT; ++o) {
+        if (strcmp(key, kOpts[o].key) != 0) continue;
+        const int v = cm_option(o);
+        for (int i = 0; i < kOpts[o].n; ++i) if (kOpts[o].values[i] == v) return kOpts[o].names[i];
+    }
+    cm_set_error("cm_get_option: unknown option \"%s\"", key ? key : "(null)");
+    return nullptr;
+}
+
+// 0 = exact fp32 MFMA (default), 1 = option mfma=bf16x3 (error-compensated bf16 GEMM loops in the PPO training passes)
+extern "C" int cm_mfma_mode(void) { return cm_option(CM_OPTION_MFMA); }
 
 extern "C" int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout) {
     return (int64_t)din * hidden + hidden + (int64_t)n_hidden_layers * ((int64_t)hidden * hidden + hidden) +

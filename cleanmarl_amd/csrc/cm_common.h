@@ -17,6 +17,10 @@ void cm_set_error(const char* fmt, ...);
     if (e_ != hipSuccess) CM_FAIL(-2, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 #define CM_REQUIRE(cond, ...) do { if (!(cond)) CM_FAIL(-1, __VA_ARGS__); } while (0)
 
+// options set through cm_set_option (cm_api.hip); values are the ints listed there (0 = the default / "auto")
+enum { CM_OPTION_MLP_FORMS = 0, CM_OPTION_CRITIC_SCHEDULE, CM_OPTION_GRU_TILE, CM_OPTION_ROLLOUT_TILE, CM_OPTION_MFMA, CM_OPTION_COUNT };
+int cm_option(int which);
+
 // fold per-workgroup partial gradient rows and apply the optimiser step in one launch (cm_optim.hip); part2 / isplit: a second partial
 // set holding columns [0, isplit) (the split critic's streamed dW0), NULL if none
 int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,

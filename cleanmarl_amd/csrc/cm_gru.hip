@@ -345,111 +345,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
     }
 }
 
-// ============================================================================================ 32-row, weights-stationary forward
-// Small batches (cfg 5: 5120 sequences) give the 64-row kernels only 80 workgroups for 256 CUs and every step re-stages its
-// seven weight blocks through LDS.  k_gru32_chunk_fwd walks the same chunk with 32-row tiles (twice the workgroups) and ALL
-// weight blocks resident in LDS for the whole chunk (7 x 17 KB + three 32-row activation buffers = 152 KB): no staging and six
-// barriers per step instead of fourteen.  The four waves split every phase between them: wn = column half, role g:
-//   F1  g0: x1 = relu(fc1(obs))            (g1 idle; the next step's obs tile is already in flight in registers)
-//   F2  g0: r = sigma(..)   g1: z = sigma(..)   in parallel, results stay in the registers of their wave
-//   F3  g0: W_in x1         g1: W_hn h + b_hn -> LDS;  g0: n = tanh(.. + r * ghn) -> LDS;  g1: h' = (1 - z) n + z h -> LDS
-// Same workspace format and statistics as k_gru_chunk_fwd, so either backward kernel consumes it.  KJ = 2 (K <= 8) or 8 (K <= 32).
+// 32-row tiles (cm_gru_v2.h, the fused rollout below): tile height and the register-staged obs tile
 constexpr int T32 = 32;
-constexpr int g32_lds_floats(int KP) { return 7 * HP * LDT + 3 * T32 * LDT + KP * HP + HP + 6 * HP + KMAX + 64; }
-constexpr int G32_LDS_FLOATS = g32_lds_floats(8);  // K <= 8 (the fused rollout)
-inline size_t gru32_lds_bytes(int KP) { return (size_t)g32_lds_floats(KP) * sizeof(float); }
-
-template <bool SAVE>
-__device__ __forceinline__ void gru32_step(float* const* Wt, float* XA, float* hp, float* hn, const float* b1, const float* bih,
-                                           const float* bhh, int din, int H, long row0, long nrows, float* wsrow) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave & 1, g = wave >> 1, h = lane >> 5, lc = lane & 31;
-    const int col = 32 * wn + lc;
-    f32x16 acc;
-    // ---- F1
-    __syncthreads();  // obs tile in XA, h_{t-1} in hp
-    if (g == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        rowpar_nt(acc, XA, Wt[0] + 32 * wn * LDT, (din + 7) >> 3);
-    }
-    __syncthreads();  // every read of the obs tile is done: x1 may overwrite it
-    if (g == 0) {
-        const float bias = b1[col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float v = fmaxf(acc[i] + bias, 0.0f);
-            XA[row * LDT + col] = v;
-        }
-    }
-    __syncthreads();
-    // ---- F2: gate g (0 = r, 1 = z) on wave group g
-    float gate[16];
-    {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        rowpar_nt(acc, XA, Wt[1 + g] + 32 * wn * LDT, HP / 8);
-        rowpar_nt(acc, hp, Wt[4 + g] + 32 * wn * LDT, HP / 8);
-        const float bias = bih[g * HP + col] + bhh[g * HP + col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            gate[i] = sigmoidf_(acc[i] + bias);
-            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + (1 + g) * HP + col] = gate[i];
-        }
-    }
-    // ---- F3: g0 = W_in x1, g1 = W_hn h
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    if (g == 0) rowpar_nt(acc, XA, Wt[3] + 32 * wn * LDT, HP / 8);
-    else rowpar_nt(acc, hp, Wt[6] + 32 * wn * LDT, HP / 8);
-    if (g == 1) {
-        const float bh = bhh[2 * HP + col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float ghn = acc[i] + bh;
-            hn[row * LDT + col] = ghn;
-            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 4 * HP + col] = ghn;
-        }
-    }
-    __syncthreads();
-    if (g == 0) {
-        const float bi = bih[2 * HP + col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float n = tanhf_(acc[i] + bi + gate[i] * hn[row * LDT + col]);
-            hn[row * LDT + col] = n;
-            if (SAVE && row0 + row < nrows) wsrow[(long)row * WS_ACT + 3 * HP + col] = n;
-        }
-    }
-    __syncthreads();
-    if (g == 1) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float n = hn[row * LDT + col], hprev = hp[row * LDT + col];
-            const float hv = (col < H) ? (1.0f - gate[i]) * n + gate[i] * hprev : 0.0f;
-            hn[row * LDT + col] = hv;
-        }
-    }
-    __syncthreads();  // hn = h'
-    if (SAVE) {
-        // x1 (still in XA) and h' (now in hn) leave as 16-byte stores from their row-major LDS tiles: 4 store instructions per thread
-        // instead of 32 scattered 4-byte ones from the accumulator layout (the forward step is store-issue bound)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = threadIdx.x + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
-            if (row0 + r < nrows) {
-                float* w = wsrow + (long)r * WS_ACT + c4;
-                *reinterpret_cast<float4*>(w) = *reinterpret_cast<const float4*>(XA + r * LDT + c4);
-                *reinterpret_cast<float4*>(w + 5 * HP) = *reinterpret_cast<const float4*>(hn + r * LDT + c4);
-            }
-        }
-    }
-}
 
 // obs tile of 32 rows x din (<= 64) columns: 8 lanes per row, 8 columns each, register-staged one step ahead
 struct X32 { float v[8]; };
@@ -466,152 +363,11 @@ __device__ __forceinline__ void x32_store(float* XA, const X32& x) {
     *reinterpret_cast<float4*>(XA + r * LDT + c0 + 4) = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
-template <int KJ>
-__global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_fwd(const GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KP = KJ * 4;
-    const GruOff off = gru_offsets(a.din, a.H, a.K);
-    float* Wt[7];
-    float* p = smem;
-    for (int i = 0; i < 7; ++i) { Wt[i] = p; p += HP * LDT; }
-    float* XA = p; p += T32 * LDT;
-    float* hp = p; p += T32 * LDT;
-    float* hn = p; p += T32 * LDT;
-    GruLds L = {};
-    L.wouts = p; p += KP * HP;
-    L.b1 = p; p += HP; L.bih = p; p += 3 * HP; L.bhh = p; p += 3 * HP; L.b2 = p; p += KMAX;
-    L.red = p;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hrow = tid >> 2, hq = tid & 3;  // head mapping: 4 lanes per row -> threads 0..127 own the 32 rows
-    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
-    const long R = (long)a.E * a.A;
-    // ---- one-time staging: every weight block, head weights, biases
-    stage_rows(Wt[0], a.params + off.W1, 0, H, din, 0, din);
-#pragma unroll 1
-    for (int q = 0; q < 3; ++q) {
-        stage_rows(Wt[1 + q], a.params + off.Wih + q * H * H, 0, H, H, 0, H);
-        stage_rows(Wt[4 + q], a.params + off.Whh + q * H * H, 0, H, H, 0, H);
-    }
-    for (int i = tid; i < KP * HP; i += NTHREADS) {
-        const int k = i / HP, c = i % HP;
-        L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
-    }
-    for (int i = tid; i < HP; i += NTHREADS) L.b1[i] = (i < H) ? a.params[off.b1 + i] : 0.0f;
-    for (int i = tid; i < 3 * HP; i += NTHREADS) {
-        const int gg = i / HP, c = i % HP;
-        L.bih[i] = (c < H) ? a.params[off.bih + gg * H + c] : 0.0f;
-        L.bhh[i] = (c < H) ? a.params[off.bhh + gg * H + c] : 0.0f;
-    }
-    for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
-
-    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
-    const long ntiles = (R + T32 - 1) / T32;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row0 = tile * T32;
-        const int grow = (int)row0 + hrow;
-        const bool hlane = hrow < T32;            // this thread takes part in the head
-        const bool rvalid = hlane && grow < R;
-        const int e_row = rvalid ? grow / a.A : 0;
-        const int ag = grow - e_row * a.A;
-        const int eplen = rvalid ? a.ep_len[e_row] : 0;
-        __syncthreads();
-        for (int i = tid; i < T32 * HP; i += NTHREADS) {
-            const int r = i >> 6, c = i & 63;
-            hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
-        }
-        X32 xr;
-        x32_load(xr, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
-        x32_store(XA, xr);
-        for (int s = 0; s < CL; ++s) {
-            const int t = a.t0 + s;
-            if (s + 1 < CL) x32_load(xr, a.obs + (long)(t + 1) * din, row0, R, (long)T * din, din);  // lands under this step
-            // per-row head inputs of this step: requested now, consumed after the step (their latency hides under its MFMAs)
-            unsigned char avb[KJ];
-#pragma unroll
-            for (int j = 0; j < KJ; ++j) {
-                avb[j] = 1;
-                if (rvalid && 4 * j + hq < K) avb[j] = a.avail[((long)grow * T + t) * K + 4 * j + hq];
-            }
-            const long o = (long)grow * T + t;
-            const int act = rvalid ? a.action[o] : 0;
-            const float lpo = rvalid ? a.logp_old[o] : 0.f, advv = rvalid ? a.adv[o] : 0.f;
-            gru32_step<true>(Wt, XA, hp, hn, L.b1, L.bih, L.bhh, din, H, row0, R, a.ws_act + (s * R + row0) * WS_ACT);
-            if (s + 1 < CL) x32_store(XA, xr);  // x1 is dead (the step's last barrier is behind us); visible after the next step's first barrier
-            if (hlane) {
-                // ---- PPO head on relu(h'): statistics + dlogits (saved for the backward sweep); same arithmetic as k_gru_chunk_fwd
-                float zreg[KJ];
-                gru_head_logits<KJ>(L, hn, K, avb, zreg);
-                const bool valid = rvalid && t < eplen;
-                const float invA = 1.0f / (float)a.A;
-                float m = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
-                m = quad_max(m);
-                float ssum = 0.0f, pj[KJ];
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
-                ssum = quad_sum(ssum);
-                const float lse = m + logf(ssum), rs = 1.0f / ssum;
-                float ent = 0.f, lpa = 0.f;
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) {
-                    const float lp = zreg[j] - lse;
-                    pj[j] *= rs; ent -= pj[j] * lp;
-                    if (4 * j + hq == act) lpa = lp;
-                }
-                ent = quad_sum(ent); lpa = quad_sum(lpa);
-                const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
-                const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
-                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
-                float gsel;
-                if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
-                if (valid && hq == 0) {
-                    st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
-                    st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
-                    if (ag == 0) st_cnt += 1.f;
-                }
-                const float gr = gsel * ratio;
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) {
-                    const int k = 4 * j + hq;
-                    if (k < K && rvalid) {
-                        const float lp = zreg[j] - lse;
-                        float d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
-                        if (!valid || zreg[j] <= -5e8f) d = 0.f;
-                        a.ws_dl[(s * R + grow) * WS_DL + k] = d;
-                    }
-                }
-            }
-            float* tmp = hp; hp = hn; hn = tmp;
-        }
-        __syncthreads();
-        if (a.h_out)
-            for (int i = tid; i < T32 * HP; i += NTHREADS) {
-                const int r = i >> 6, c = i & 63;
-                if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
-            }
-    }
-    float* out = a.partial + (size_t)blockIdx.x * a.PS;
-    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const float v = cm_wave_sum(sv6[q]);
-        if (lane == 0) L.red[q * 4 + wave] = v;
-    }
-    __syncthreads();
-    if (tid < CM_NUM_STATS) {
-        float v = 0.f;
-        if (tid < 6) v = L.red[tid * 4] + L.red[tid * 4 + 1] + L.red[tid * 4 + 2] + L.red[tid * 4 + 3];
-        out[off.P + tid] = v;
-    }
-}
-
 // ============================================================================================ fused GRU rollout
 // The whole episode of the synthetic MPE-like env with the GRU actor in ONE persistent launch (replaces T x (cm_gru_policy_act +
 // cm_synth_env_step), cleanmarl/mappo_lstm_multienvs.py:392-479 on the synthetic configs): a workgroup keeps floor(32 / A) envs
 // (positions, velocities, landmarks) and their agents' hidden states in LDS for all T steps, the seven weight blocks stay
-// resident (gru32_step), observations / states / actions / log-probs / rewards are written straight into the [E,A,T,F] buffers.
+// resident, observations / states / actions / log-probs / rewards are written straight into the [E,A,T,F] buffers.
 // Same Philox keys and the same arithmetic as the per-step kernels, so both paths produce the same rollout.
 struct GruRollArgs {
     float* env_state; int E, A, T, agent_ids;
@@ -1023,275 +779,6 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
 }
 
 // ============================================================================================ rollout step
-// ============================================================================================ 32-row backward sweep
-// Same arithmetic and workspace as k_gru_chunk_bwd on 32-row tiles (twice the workgroups, half the MFMA work per workgroup and
-// step).  Waves: wn = column half, role = wave >> 1.  Weight gradients: wave (role, wn) owns the (n-half = role, k-half = wn)
-// 32x32 tile of every 64x64 gradient block, contraction over the tile's 32 rows.  Data path: role 0 accumulates
-// dx1 = sum_g dG_i[g] W_ih[g], role 1 accumulates dh_prev = sum_g dG_h[g] W_hh[g] -- concurrently, W_ih[g] / W_hh[g] streamed as
-// a pair through two LDS buffers (three staging rounds per step instead of six).  Head: role 1 does the fc2 weight gradient on
-// the MFMA, role 0 (threads 0..127 = the 4-lanes-per-row mapping of 32 rows) the VALU part.
-__device__ __forceinline__ void colred32(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const float* ap = Zs_n0 + h * LDT + r;
-    const float* bp = Xs_k0 + h * LDT + r;
-#pragma unroll
-    for (int kk = 0; kk < T32 / 2; kk += 4) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { av[i] = ap[2 * (kk + i) * LDT]; bv[i] = bp[2 * (kk + i) * LDT]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc = mfma32(av[i], bv[i], acc);
-    }
-}
-
-inline size_t gru32b_lds_bytes(int KP) { return (size_t)(7 * T32 * LDT + 2 * HP * LDT + KP * HP + T32 * LSP + 2 * NTHREADS) * sizeof(float); }
-
-template <int KJ, bool WV>
-__global__ __launch_bounds__(NTHREADS) void k_gru32_chunk_bwd(const GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KP = KJ * 4, NDL = KP / 8;  // dlogits entries per thread: 32 rows x KP / 256 threads
-    const GruOff off = gru_offsets(a.din, a.H, a.K);
-    float* p = smem;
-    float* DH = p; p += T32 * LDT;
-    float* A1 = p; p += T32 * LDT;
-    float* HPV = p; p += T32 * LDT;
-    float* G0 = p; p += T32 * LDT;
-    float* G1 = p; p += T32 * LDT;
-    float* G2 = p; p += T32 * LDT;
-    float* G3 = p; p += T32 * LDT;
-    float* W = p; p += HP * LDT;
-    float* W2 = p; p += HP * LDT;
-    float* wouts = p; p += KP * HP;
-    float* ls = p; p += T32 * LSP;
-    float* red = p;  // 2 * NTHREADS floats
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave & 1, role = wave >> 1, h = lane >> 5, lc = lane & 31;
-    const int hrow = tid >> 2, hq = tid & 3;
-    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
-    const long R = (long)a.E * a.A;
-    const int col = 32 * wn + lc;
-    for (int i = tid; i < KP * HP; i += NTHREADS) {
-        const int k = i / HP, c = i % HP;
-        wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
-    }
-    for (int i = tid; i < T32 * LSP; i += NTHREADS) ls[i] = 0.0f;
-
-    f32x16 accW1, accWih[3], accWhh[3], accWo;
-    float db1 = 0.f, dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbo = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        accW1[g] = 0.f; accWo[g] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { accWih[q][g] = 0.f; accWhh[q][g] = 0.f; }
-    }
-    const long ntiles = (R + T32 - 1) / T32;
-    // Everything a step reads from the HBM workspace (8 elements of the flat 32 x 64 mapping per thread + one dlogit) is
-    // requested one step AHEAD, under the MFMA phases of the step before, instead of right where it is consumed.
-    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], hrelu[8], dl[NDL]; } P;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row0 = tile * T32;
-        auto load_pre = [&](int s) {
-            const float* wsS = a.ws_act + (s * R + row0) * WS_ACT;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
-                const bool rok = row0 + r < R;
-                const float* w = wsS + (long)r * WS_ACT;
-                P.hrelu[e] = rok ? w[5 * HP + c] : 0.0f;
-                P.x1[e] = P.rr[e] = P.zz[e] = P.nn[e] = P.ghn[e] = P.hprev[e] = 0.0f;
-                if (rok && c < H) {
-                    P.x1[e] = w[c]; P.rr[e] = w[HP + c]; P.zz[e] = w[2 * HP + c]; P.nn[e] = w[3 * HP + c]; P.ghn[e] = w[4 * HP + c];
-                    if (s > 0) P.hprev[e] = a.ws_act[((s - 1) * R + row0 + r) * WS_ACT + 5 * HP + c];
-                    else if (a.h_in) P.hprev[e] = a.h_in[(row0 + r) * H + c];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NDL; ++q) {
-                const int i = tid + NTHREADS * q, r = i / KP, kk = i - r * KP;
-                P.dl[q] = (row0 + r < R && kk < K) ? a.ws_dl[(s * R + row0 + r) * WS_DL + kk] : 0.0f;
-            }
-        };
-        __syncthreads();
-        for (int i = tid; i < T32 * LDT; i += NTHREADS) DH[i] = 0.0f;
-        load_pre(CL - 1);
-        for (int s = CL - 1; s >= 0; --s) {
-            const int t = a.t0 + s;
-            // ---- B1: head backward. ls <- dlogits[s], G3 <- relu(h'_s)
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NDL; ++q) {
-                const int i = tid + NTHREADS * q, r = i / KP;
-                ls[r * LSP + (i - r * KP)] = P.dl[q];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
-                G3[r * LDT + c] = fmaxf(P.hrelu[e], 0.0f);
-            }
-            __syncthreads();
-            if (role == 1) colred_head(accWo, ls, G3 + 32 * wn);  // fc2 weight gradient: [32 k] x [32 columns of this wave]
-            {
-                const int k = tid & 31, part = tid >> 5;
-                float sb = 0.f;
-                if (part < T32 / 8) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) sb += ls[(part * 8 + r) * LSP + k];
-                }
-                dbo += sb;
-            }
-            if (hrow < T32) {  // DH += (dlogits * W2) .* (h' > 0): 4 lanes per row, 16 columns each
-                float dz[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dz[i] = 0.f;
-                for (int k0 = 0; k0 < K; k0 += 4) {
-                    const float4 d4 = *reinterpret_cast<const float4*>(ls + hrow * LSP + k0);
-                    const float dk[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4* wp4 = reinterpret_cast<const float4*>(wouts + (k0 + q) * HP + 16 * hq);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 w4 = wp4[i];
-                            dz[4 * i] = fmaf(dk[q], w4.x, dz[4 * i]); dz[4 * i + 1] = fmaf(dk[q], w4.y, dz[4 * i + 1]);
-                            dz[4 * i + 2] = fmaf(dk[q], w4.z, dz[4 * i + 2]); dz[4 * i + 3] = fmaf(dk[q], w4.w, dz[4 * i + 3]);
-                        }
-                    }
-                }
-                float* dp = DH + hrow * LDT + 16 * hq;
-                const float* gp = G3 + hrow * LDT + 16 * hq;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) if (gp[i] > 0.0f) dp[i] += dz[i];
-            }
-            __syncthreads();
-            // ---- B2: gate derivatives (elementwise, flat mapping), h_prev -> HPV, x1 -> A1
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int i = tid + NTHREADS * e, r = i >> 6, c = i & 63;
-                const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e], x1 = P.x1[e];
-                const float dh = DH[r * LDT + c];
-                const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
-                const float dn_pre = dn * (1.0f - nn * nn);
-                const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
-                const float dz_pre = dzg * zz * (1.0f - zz);
-                G0[r * LDT + c] = dr_pre; G1[r * LDT + c] = dz_pre; G2[r * LDT + c] = dn_pre; G3[r * LDT + c] = dn_pre * rr;
-                HPV[r * LDT + c] = hprev; A1[r * LDT + c] = x1;
-                DH[r * LDT + c] = dh * zz;
-            }
-            __syncthreads();
-            if (s > 0) load_pre(s - 1);  // the next (earlier) step's workspace rows land under this step's MFMA phases
-            // ---- B3: weight gradients of the gates (the first weight pair of B4/B5 is requested now, under these MFMAs)
-            Tile16 tw, tw2;
-            gate_load<WV>(tw, a.params + off.Wih, H);
-            gate_load<WV>(tw2, a.params + off.Whh, H);
-            colred32(accWih[0], G0 + 32 * role, A1 + 32 * wn);
-            colred32(accWih[1], G1 + 32 * role, A1 + 32 * wn);
-            colred32(accWih[2], G2 + 32 * role, A1 + 32 * wn);
-            colred32(accWhh[0], G0 + 32 * role, HPV + 32 * wn);
-            colred32(accWhh[1], G1 + 32 * role, HPV + 32 * wn);
-            colred32(accWhh[2], G3 + 32 * role, HPV + 32 * wn);
-            {
-                const int c = tid & 63, part = tid >> 6;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                for (int r = 0; r < T32 / 4; ++r) {
-                    const int o = (part * (T32 / 4) + r) * LDT + c;
-                    s0 += G0[o]; s1 += G1[o]; s2 += G2[o]; s3 += G3[o];
-                }
-                dbg[0] += s0; dbg[1] += s1; dbg[2] += s2; dbg[3] += s3;
-            }
-            // ---- B4 (role 0): dx1 = sum_g dgi_g W_ih[g]   |   B5 (role 1): dh_prev = sum_g dgh_g W_hh[g]
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-            X32 xo;
-#pragma unroll
-            for (int gate = 0; gate < 3; ++gate) {
-                __syncthreads();
-                tile_store<WV>(W, tw);
-                tile_store<WV>(W2, tw2);
-                if (gate < 2) {
-                    gate_load<WV>(tw, a.params + off.Wih + (gate + 1) * H * H, H);
-                    gate_load<WV>(tw2, a.params + off.Whh + (gate + 1) * H * H, H);
-                } else {
-                    x32_load(xo, a.obs + (long)t * din, row0, R, (long)T * din, din);  // obs tile for B6
-                }
-                __syncthreads();
-                if (role == 0) rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G2), W + 32 * wn);
-                else rowpar_tn(acc, (gate == 0 ? G0 : gate == 1 ? G1 : G3), W2 + 32 * wn);
-            }
-            __syncthreads();  // every wave is done with A1 (B3) and G* (B4/B5)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (role == 0) {
-                    float* q = A1 + row * LDT + col;
-                    *q = (*q > 0.0f) ? acc[g] : 0.0f;
-                } else {
-                    DH[row * LDT + col] += acc[g];
-                }
-            }
-            // ---- B6: fc1 weight gradient: obs tile -> G0
-            x32_store(G0, xo);
-            __syncthreads();
-            colred32(accW1, A1 + 32 * role, G0 + 32 * wn);
-            {
-                const int c = tid & 63, part = tid >> 6;
-                float s0 = 0.f;
-#pragma unroll
-                for (int r = 0; r < T32 / 4; ++r) s0 += A1[(part * (T32 / 4) + r) * LDT + c];
-                db1 += s0;
-            }
-        }
-    }
-    // ================================ partial gradient of this workgroup (statistics come from the forward kernel)
-    float* out = a.partial + (size_t)blockIdx.x * a.PS;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int n = 32 * role + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (n < H && col < din) out[off.W1 + n * din + col] = accW1[g];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (n < H && col < H) {
-                out[off.Wih + (q * H + n) * H + col] = accWih[q][g];
-                out[off.Whh + (q * H + n) * H + col] = accWhh[q][g];
-            }
-        }
-    }
-    if (role == 1) {  // fc2 weight: rows k of the 32 x 32 tile, columns of this wave
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int k = (g & 3) + 8 * (g >> 2) + 4 * h;
-            if (k < K && col < H) out[off.W2 + k * H + col] = accWo[g];
-        }
-    }
-    __syncthreads();
-    red[tid] = dbo;
-    __syncthreads();
-    if (tid < K) {
-        float sb = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sb += red[q * 32 + tid];
-        out[off.b2 + tid] = sb;
-    }
-    {   // column-sum biases: 4 row parts per column
-        float vals[5] = {db1, dbg[0], dbg[1], dbg[2], dbg[3]};
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            __syncthreads();
-            red[(tid >> 6) * HP + (tid & 63)] = vals[q];
-            __syncthreads();
-            if (tid < H) {
-                const float sv = red[tid] + red[HP + tid] + red[2 * HP + tid] + red[3 * HP + tid];
-                if (q == 0) out[off.b1 + tid] = sv;
-                else if (q == 1) { out[off.bih + tid] = sv; out[off.bhh + tid] = sv; }
-                else if (q == 2) { out[off.bih + H + tid] = sv; out[off.bhh + H + tid] = sv; }
-                else if (q == 3) out[off.bih + 2 * H + tid] = sv;
-                else out[off.bhh + 2 * H + tid] = sv;
-            }
-        }
-    }
-}
-
 template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1397,18 +884,17 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_gru_chunk_fwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); \
         hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    // small / medium batch: 32-row forward (weights-stationary) + 32-row backward sweeps, grid32 partial rows;
-    // otherwise the 64-row streaming kernels (same workspace format)
-    // 32-row sweeps pay off while the 64-row tiling leaves CUs idle or barely filled (measured: 5k and 20k sequences faster,
-    // 82k sequences slower than the 64-row kernels); above 512 64-row tiles the streaming 64-row kernels take over
-    const char* tile_env = getenv("CM_GRU_TILE");  // test hook: CM_GRU_TILE=64 forces the 64-row kernels at any batch size,
-    const bool force64 = tile_env && atoi(tile_env) == 64;  // CM_GRU_TILE=32 the first-generation 32-row sweeps (default: cm_gru_v2.h)
-    const bool force_v1 = tile_env && atoi(tile_env) == 32;
-    const bool fwd32 = !force64 && din <= KC && (long)R <= 512L * TM;
-    const long nt32 = ((long)R + T32 - 1) / T32;
-    const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
-    const int KP32 = n_actions <= 8 ? 8 : KMAX;
-    if (fwd32 && !force_v1) {  // second-generation sweeps: weights in registers, head outside the recurrence
+    // small / medium batch (<= 512 64-row tiles): the 32-row sweeps of cm_gru_v2.h (weights in registers, head outside the recurrence,
+    // one partial row per 32-row tile) -- they pay off while the 64-row tiling leaves CUs idle or barely filled (measured: 5k and 20k
+    // sequences faster, 82k sequences slower); above, or with cm_set_option("gru_tile", "64"), the 64-row streaming kernels (same
+    // workspace format).  Both are pinned to the reference goldens (tests/test_hip_parity.py).
+    const bool force64 = cm_option(CM_OPTION_GRU_TILE) == 64;
+    const int64_t P = cm_gru_param_count(din, hidden, n_actions);
+    MlpArgs m = {};
+    m.partial = a.partial; m.PS = a.PS;
+    if (!force64 && din <= KC && (long)R <= 512L * TM) {
+        const long nt32 = ((long)R + T32 - 1) / T32;
+        const int grid32 = (int)(nt32 < MAX_GRID ? nt32 : MAX_GRID);
         const int KP = n_actions <= 16 ? 16 : 32;
         const size_t lf = gru2_fwd_lds_bytes(KP), lb = gru2_bwd_lds_bytes();
 #define CM_GRU2_F(WV_, KP_) do { \
@@ -1420,43 +906,13 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);
         CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
-        const int64_t P2 = cm_gru_param_count(din, hidden, n_actions);
-        MlpArgs m2 = {};
-        m2.partial = a.partial; m2.PS = a.PS;
-        return finish_train(m2, grid32, P2, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
+        return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
     }
-    if (fwd32) {
-        const size_t lds32 = gru32_lds_bytes(KP32);
-        if (n_actions <= 8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-            hipLaunchKernelGGL(k_gru32_chunk_fwd<2>, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_fwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-            hipLaunchKernelGGL(k_gru32_chunk_fwd<8>, dim3(grid32), dim3(NTHREADS), lds32, (hipStream_t)stream, a);
-        }
-    }
-#define CM_GRU_LAUNCH_B(KJ_, WV_) do { \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_gru_chunk_bwd<KJ_, WV_>), dim3(grid), dim3(NTHREADS), lds, (hipStream_t)stream, a); } while (0)
-    if (fwd32) {  // 32-row backward sweep: one partial row per 32-row tile, like the forward
-        const size_t ldsb = gru32b_lds_bytes(KP32);
-#define CM_GRU32_B(KJ_, WV_) do { \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_chunk_bwd<KJ_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
-        hipLaunchKernelGGL((k_gru32_chunk_bwd<KJ_, WV_>), dim3(grid32), dim3(NTHREADS), ldsb, (hipStream_t)stream, a); } while (0)
-        if (n_actions <= 8) { if (wv) CM_GRU32_B(2, true); else CM_GRU32_B(2, false); }
-        else { if (wv) CM_GRU32_B(8, true); else CM_GRU32_B(8, false); }
-#undef CM_GRU32_B
-    }
-    else if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
+    if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
     else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }
-#undef CM_GRU_LAUNCH_B
 #undef CM_GRU_LAUNCH2
     CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
-    const int64_t P = cm_gru_param_count(din, hidden, n_actions);
-    MlpArgs m = {};
-    m.partial = a.partial; m.PS = a.PS;
-    if (!fwd32) return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
-    return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);  // both sweeps: grid32 partial rows
+    return finish_train(m, grid, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
 }
 
 extern "C" int cm_gru_actor_chunk_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,

@@ -1,6 +1,6 @@
 // cm_gru_v2.h -- second generation of the 32-row TBPTT sweeps (included by cm_gru.hip inside its anonymous namespace).
 //
-// Same arithmetic as k_gru32_chunk_fwd / k_gru32_chunk_bwd (reference: cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620); what
+// Same arithmetic as the 64-row sweeps k_gru_chunk_fwd / k_gru_chunk_bwd (reference: cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620); what
 // changes is where things live, because at config 5 the sweeps are a latency chain (5120 sequences = 160 workgroups on 256 CUs, one
 // per CU, time strictly sequential), not a throughput problem:
 //   * WEIGHTS IN REGISTERS.  Every gate block is the B operand of a 32x32x2 MFMA whose lane (n = lane & 31, h = lane >> 5) always
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
             }
             lds_barrier();
             PH(8);
-            {   // PPO clipped-surrogate head (arithmetic of k_gru32_chunk_fwd): statistics + dlogits -> ls2
+            {   // PPO clipped-surrogate head (arithmetic of k_gru_chunk_fwd): statistics + dlogits -> ls2
                 float zreg[KJ];
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) zreg[j] = (4 * j + hq < K && avb[j]) ? ls[hrow * KP + 4 * j + hq] : -1e9f;

@@ -32,9 +32,9 @@ static int critic_pass(const float* x, int64_t x_ld, const float* ret, const int
     // wide inputs (65 .. 448 columns, one hidden layer): ONE pass over the input with W0 and dW0 in registers (cm_critic_fused.h);
     // -- from CM_FUSED_MIN_ROWS rows on: the kernel wants whole CUs (one 256-thread workgroup with 512 registers per lane and ~140 KB
     // of LDS), so a small batch neither amortises its per-workgroup prologue / partial-gradient row nor shares CUs with the rollout
-    // it is overlapped with (learner.overlap_critic).  CM_CRITIC_SCHEDULE=fused / split force either schedule (A/B runs, tests).
-    const char* sched = getenv("CM_CRITIC_SCHEDULE");
-    const bool force_fused = sched && strcmp(sched, "fused") == 0, force_split = sched && strcmp(sched, "split") == 0;
+    // it is overlapped with (learner.overlap_critic).  cm_set_option("critic_schedule", "fused" / "split") forces either schedule (A/B runs, tests).
+    const int sched = cm_option(CM_OPTION_CRITIC_SCHEDULE);
+    const bool force_fused = sched == 1, force_split = sched == 2;
     if (critic_fused_shape(a) && !force_split && (force_fused || a.rows >= CM_FUSED_MIN_ROWS))
         return run_critic_fused(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd", opt);
     return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd", opt);

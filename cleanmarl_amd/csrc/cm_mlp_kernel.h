@@ -1231,11 +1231,11 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
     }
     // hand-ordered LDS reads (see rowpar_nt): the single-chunk actor pass of a batch too large to share the GPU with the critic's
     // epochs (learner.overlap_critic's 2^21-row limit), and every forward pass (the value pass follows the rollout and the join with
-    // the critic stream: nothing runs beside it).  CM_MLP_FORMS=hand|loop forces one form wherever both are compiled (A/B runs, tests).
+    // the critic stream: nothing runs beside it).  cm_set_option("mlp_forms", "hand"|"loop") forces one form wherever both are compiled (A/B runs, tests).
     if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH == 0)) {
-        const char* f = getenv("CM_MLP_FORMS");
+        const int f = cm_option(CM_OPTION_MLP_FORMS);  // 0 auto, 1 hand, 2 loop
         const bool big = MODE == M_FWD || a.rows > (1L << 21);
-        const bool hand = f ? (f[0] == 'h') : big;
+        const bool hand = f ? (f == 1) : big;
         if (vec && l1 && k8 && hand) { launch_one<NCH, MODE, 1, 1, 2, false, true>(a, grid, lds_bytes, s); return; }
     }
     if (vec) {

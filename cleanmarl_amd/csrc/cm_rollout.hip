@@ -25,6 +25,13 @@ namespace {
 #define CM_ROLLOUT_PRIO 3
 #endif
 #define ROLLOUT_WAVE_PRIO() __builtin_amdgcn_s_setprio(CM_ROLLOUT_PRIO)
+#ifdef CM_PHASE_PROF  // the store wave's own slots 8..15 of the workgroup's profile row (tools/phase_prof.py rollout)
+#define PH_FLUSH_SW do { if (a.prof && threadIdx.x == NTHREADS) { _Pragma("unroll") for (int i_ = 8; i_ < 16; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
+#define PH_FLUSH_C do { if (a.prof && threadIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
+#else
+#define PH_FLUSH_SW
+#define PH_FLUSH_C
+#endif
 
 constexpr float DAMP = 0.25f, DT = 0.1f, ACCEL = 5.0f, COLLIDE = 0.3f;
 
@@ -679,6 +686,395 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
     PH_FLUSH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Store-wave form of the 16-row rollout (round 3): the same four compute waves plus a FIFTH wave that owns everything nothing in
+// the step chain waits for.  One GPU's share of a sharded batch (512 envs x 8 agents = 256 tiles, one workgroup per CU) is a pure
+// latency chain  positions -> obs tile -> layer 0 -> layer 1 -> logits -> sample -> physics -> positions,  and in k_rollout_spread16
+// the rollout-buffer stores (0.43 us), the reward partials + reward store (0.6 us), the Philox draws and the action / log-prob stores
+// all sat on it (3.64 us per step, profiles/r02_rollout16_ablation.txt).  Here the compute waves only build the obs tile, run the
+// MLP, sample and move the agents; the store wave, in the same four barrier intervals of the step,
+//   * computes the reward partials of step t-1 from the positions (stable until the physics at the end of step t) and stores the reward,
+//   * copies the obs tile to the obs / state rollout buffers (16-byte stores) while layer 0 runs -- the tile is recycled as H1 afterwards,
+//   * draws the sampler's uniforms 16 steps ahead (one Philox evaluation per lane on 4 of every 16 steps) into an LDS ring,
+//   * flushes actions / log-probs from an LDS ring every 4 steps as 16-byte stores (a row's time axis is contiguous).
+// It only has to arrive at each barrier before the compute waves do.  Same arithmetic, same Philox keys, same summation orders:
+// bit-identical rollouts to both other tilings (tests/test_hip_parity.py).
+// tile16_nt_reg with every A-operand quad requested before the first MFMA (16 registers): the chain of 2 kb dependent MFMAs then never
+// waits for LDS (one quad ahead, as in tile16_nt_reg, leaves ~64 cycles between a read and its use).  Same operands, same order.
+__device__ __forceinline__ void tile16_nt_reg_pre(f32x4& acc, const float* As, const float (&w)[16], int kb) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const float4* ap = reinterpret_cast<const float4*>(As + n * LDT + 4 * (g & 1));
+    const bool lo = g < 2;
+    float a0[8], a1[8];  // this lane group's two k values of every quad (selected at once: 16 registers, and no lane-indexed array)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = ap[2 * (j < kb ? j : 0)];
+        a0[j] = lo ? v.x : v.y; a1[j] = lo ? v.z : v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < kb) {
+            acc = mfma16(a0[j], w[2 * j], acc);
+            acc = mfma16(a1[j], w[2 * j + 1], acc);
+        }
+    }
+}
+// cm_categorical_sample / cm_categorical_sample_eps (cm_common.h) on K <= 8 logits held in REGISTERS: the same operations in the same
+// order (one exp per action, left-to-right sums, first available action whose cumulative mass exceeds the threshold), with the chosen
+// logit / probability tracked in the loop instead of indexed afterwards.
+__device__ __forceinline__ void sample_row8(const float (&z)[8], int K, float u, float eps, int* action, float* logp) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < K) m = fmaxf(m, z[k]);
+    float e[8], s = 0.0f;
+    int chosen = -1, last = 0;
+    if (eps > 0.0f) {
+        int navail = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < K) navail += (z[k] > -5e8f) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e[k] = (k < K) ? expf(z[k] - m) : 0.0f; if (k < K) s += e[k]; }
+        const float ca = (1.0f - eps) / s, cb = eps / (float)max(navail, 1);
+        float cum = 0.0f, pc = 0.0f, plast = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K && z[k] > -5e8f) {
+                const float p = ca * e[k] + cb;
+                cum += p;
+                last = k; plast = p;
+                if (chosen < 0 && u < cum) { chosen = k; pc = p; }
+            }
+        }
+        if (chosen < 0) { chosen = last; pc = plast; }
+        *action = chosen;
+        *logp = logf(pc);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { e[k] = (k < K) ? expf(z[k] - m) : 0.0f; s += e[k]; }
+    const float thr = u * s;
+    float cum = 0.0f, zc = 0.0f, zl = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < K && z[k] > -5e8f) {
+            cum += e[k];
+            last = k; zl = z[k];
+            if (chosen < 0 && thr < cum) { chosen = k; zc = z[k]; }
+        }
+    }
+    if (chosen < 0) { chosen = last; zc = zl; }
+    *action = chosen;
+    *logp = zc - (m + logf(s));
+}
+
+constexpr int NT_SW = NTHREADS + 128;  // four compute waves + the writer wave + the scorer wave
+
+__global__ __launch_bounds__(NT_SW, 1) void k_rollout_spread16s(const RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = wave == 4, scorer = wave == 5;
+    if (wave < 4) ROLLOUT_WAVE_PRIO();  // the chain only: writer and scorer have slack and leave their issue slots to co-resident kernels
+    const int n16 = lane & 15, g16 = lane >> 4;
+    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    const int EPT = TS / A, RT = EPT * A;  // envs / valid rows per tile
+    float* Xs = smem;                     // [TS][LDT] obs tile; aliased by H1 once layer 0 has consumed it
+    float* H0 = Xs + TS * LDT;            // [TS][LDT]
+    float* epos = H0 + TS * LDT;          // [TS][2]
+    float* evel = epos + TS * 2;
+    float* elm = evel + TS * 2;
+    float* rscr = elm + TS * 2;           // [2][TS] reward partials
+    float* ubuf = rscr + 2 * TS;          // [2][16 steps][TS] uniforms, two blocks of 16 steps
+    float* alog = ubuf + 2 * 16 * TS;     // [2][TS][4] action bits / log-prob of four steps per row
+
+    // ---- compute waves: the policy in registers (wave w = hidden columns 16w .. 16w+15 of both layers, the whole padded head)
+    float w0r[16], w1r[16], wor[16];
+    float b0r = 0.f, b1r = 0.f, bor = 0.f;
+    if (wave < 4) {
+        load_nt16_k8(w0r, a.params + off.W0, 16 * wave, H, din, din);
+        if (L > 0) load_nt16_k8(w1r, a.params + off.Wl(0), 16 * wave, H, H, H);
+        else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w1r[i] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 16 * j + 4 * g16 + i;
+                wor[4 * j + i] = (n16 < K && k < H) ? a.params[off.Wout + n16 * H + k] : 0.0f;
+            }
+        const int hc = 16 * wave + n16;
+        b0r = hc < H ? a.params[off.b0 + hc] : 0.0f; b1r = (hc < H && L > 0) ? a.params[off.bl(0) + hc] : 0.0f;
+        bor = n16 < K ? a.params[off.bout + n16] : 0.0f;
+    }
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const int orow = (tid >> 4) & 15, oq = tid & 15;  // obs phase: 16 lanes per row (compute waves)
+    const int srow = 4 * g16 + (wave & 3);             // sampling phase: lane group g of compute wave w owns row 4g + w
+    const int nq = (din + 3) >> 2, ns = (6 * A) >> 2;
+    const bool vo = (a.obs_ld % 4 == 0) && (4 * nq <= a.obs_ld);
+    const bool vs = ((6 * A) % 4 == 0) && (a.state_ld % 4 == 0);
+    const bool v4 = (T % 4) == 0;                      // 16-byte action / log-prob flushes need 4-aligned rows of the time axis
+    PH_DECL
+    // The two roles run separate tile loops with the SAME barrier sequence (one at the top of a tile, four per step, one after the last
+    // step): as one loop the compute waves' 50 weight registers stayed live across the store wave's code (236 registers per lane).
+    if (writer) {
+        // ======================================= the writer wave: obs / state rollout buffers + the sampler's uniforms
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int e0 = tile * EPT;
+            __syncthreads();
+            // 16-byte store slots of this lane: <= 16 x 16 obs quads and <= 16 x 15 state quads over 64 lanes.  Source (LDS) and
+            // destination (t = 0) addresses are per-tile constants
+            const float* osrc[4]; float* odst[4]; const float* ssrc[4]; float* sdst[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = lane + 64 * it;
+                const int r = idx / nq, c4 = idx - r * nq;
+                const bool ok = vo && r < RT && e0 + r / A < a.E;
+                osrc[it] = Xs + (ok ? r * LDT + 4 * c4 : 0);
+                odst[it] = ok ? a.obs + ((long)(e0 + r / A) * A + (r % A)) * (long)T * a.obs_ld + 4 * c4 : nullptr;
+                const int r2 = vs ? idx / ns : 0, c42 = idx - r2 * ns;
+                const bool ok2 = vs && r2 < RT && e0 + r2 / A < a.E;
+                ssrc[it] = Xs + (ok2 ? r2 * LDT + 4 * c42 : 0);
+                sdst[it] = ok2 ? a.state + (long)(e0 + r2 / A) * (long)T * a.state_ld + (long)(r2 % A) * 6 * A + 4 * c42 : nullptr;
+            }
+            // uniforms: lane = (row n16, step offset g16) of a 4-step quarter of a 16-step block
+            const int u_el = n16 / A, u_i = n16 - u_el * A;
+            const unsigned long long u_gr = (unsigned long long)((a.env_offset + e0 + u_el) * A + u_i);
+            auto draw = [&](int step) {
+                const cm_u4 rnd = cm_philox4x32((uint32_t)u_gr, (uint32_t)(u_gr >> 32), (uint32_t)step, CM_STREAM_ACT,
+                                                (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                ubuf[((step >> 4) & 1) * 16 * TS + (step & 15) * TS + n16] = cm_u01(rnd.x);
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) draw(4 * q + g16);  // block 0, before the first step's barrier
+            for (int t = 0; t < T; ++t) {
+                PH(8);
+                __syncthreads();  // B0
+                PH(9);
+                if ((t & 15) < 4 && ((t >> 4) + 1) * 16 < T) draw(((t >> 4) + 1) * 16 + 4 * (t & 15) + g16);  // next block, a quarter per step
+                PH(10);
+                __syncthreads();  // B1: obs tile of step t complete
+                PH(11);
+                if (vo) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        if (odst[it]) *reinterpret_cast<float4*>(odst[it] + (long)t * a.obs_ld) = *reinterpret_cast<const float4*>(osrc[it]);
+                } else {
+                    for (int idx = lane; idx < RT * din; idx += 64) {
+                        const int r = idx / din, c = idx - r * din;
+                        if (e0 + r / A < a.E) a.obs[((long)(e0 + r / A) * A + (r % A)) * (long)T * a.obs_ld + (long)t * a.obs_ld + c] = Xs[r * LDT + c];
+                    }
+                }
+                if (vs) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        if (sdst[it]) *reinterpret_cast<float4*>(sdst[it] + (long)t * a.state_ld) = *reinterpret_cast<const float4*>(ssrc[it]);
+                } else {
+                    for (int idx = lane; idx < RT * 6 * A; idx += 64) {
+                        const int r = idx / (6 * A), c = idx - r * 6 * A;
+                        if (e0 + r / A < a.E) a.state[(long)(e0 + r / A) * (long)T * a.state_ld + (long)(r % A) * 6 * A + (long)t * a.state_ld + c] = Xs[r * LDT + c];
+                    }
+                }
+                PH(12);
+                __syncthreads();  // B2: layer 0 done -- the LDS reads above are complete (the barrier waits for them); the tile becomes H1
+                PH(13);
+                __syncthreads();  // B3
+            }
+            __syncthreads();      // after the last physics update
+        }
+        PH_FLUSH_SW;
+        return;
+    }
+    if (scorer) {
+        // ======================================= the scorer wave: team rewards + action / log-prob flushes
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int e0 = tile * EPT;
+            __syncthreads();
+            // reward partials of the CURRENT positions (stable from B0 to B3 of a step): pass p covers rows 4p + g16, lane n16 = agent j
+            // -- nearest-agent distance of landmark i, collisions of agent i; the expressions of k_rollout_spread16
+            auto partials = [&](int p) {
+                const int r = 4 * p + g16, el = r / A, i = r - el * A, j = n16;
+                const bool live = r < RT && (e0 + el) < a.E;
+                float dmin = 3.0e38f, ccol = 0.0f;
+                if (live && j < A) {
+                    const float* pos = epos + el * 2 * A;
+                    const float px = pos[2 * i], py = pos[2 * i + 1];
+                    const float pjx = pos[2 * j], pjy = pos[2 * j + 1];
+                    const float ax = pjx - px, ay = pjy - py;
+                    const float dx = pjx - elm[2 * r], dy = pjy - elm[2 * r + 1];
+                    dmin = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+                    if (j > i && __builtin_amdgcn_sqrtf(ax * ax + ay * ay) < COLLIDE) ccol = 1.0f;
+                }
+                dmin = row16_min(dmin); ccol = row16_sum(ccol);
+                if (n16 == 0 && r < RT) { rscr[r] = dmin; rscr[TS + r] = ccol; }
+            };
+            // the serial sums of k_rollout_spread16's reward_write (all 2 x 16 LDS words requested before the first subtraction)
+            auto reward_store = [&](int t_out) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane < EPT && e0 + lane < a.E) {
+                    float d[TS], c[TS];
+#pragma unroll
+                    for (int l = 0; l < TS; ++l) { d[l] = l < A ? rscr[lane * A + l] : 0.0f; c[l] = l < A ? rscr[TS + lane * A + l] : 0.0f; }
+                    float r = 0.0f;
+#pragma unroll
+                    for (int l = 0; l < TS; ++l) if (l < A) r -= d[l];
+#pragma unroll
+                    for (int l = 0; l < TS; ++l) if (l < A) r -= c[l];
+                    a.reward[(long)(e0 + lane) * T + t_out] = r;
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            // actions / log-probs of steps [t4, t4 + n) from the ring: lanes 0..15 the action rows, 16..31 the log-prob rows
+            auto flush_alog = [&](int t4, int n) {
+                if (lane < 32) {
+                    const int r = lane & 15, which = lane >> 4;
+                    const int el = r / A, i = r - el * A;
+                    if (r < RT && e0 + el < a.E) {
+                        const long o = ((long)(e0 + el) * A + i) * (long)T + t4;
+                        const float4 v = *reinterpret_cast<const float4*>(alog + (which * TS + r) * 4);
+                        float* dst = which ? a.logp + o : reinterpret_cast<float*>(a.action) + o;
+                        if (v4 && n == 4) *reinterpret_cast<float4*>(dst) = v;
+                        else {
+                            if (n > 0) dst[0] = v.x;
+                            if (n > 1) dst[1] = v.y;
+                            if (n > 2) dst[2] = v.z;
+                            if (n > 3) dst[3] = v.w;
+                        }
+                    }
+                }
+            };
+            for (int t = 0; t < T; ++t) {
+                __syncthreads();  // B0: positions after the physics of step t-1
+                if (t > 0) {
+                    if ((t & 3) == 0) flush_alog(t - 4, 4);  // the ring entries of steps t-4 .. t-1 (written before B0)
+                    partials(0); partials(1);
+                }
+                __syncthreads();  // B1
+                if (t > 0) { partials(2); partials(3); }
+                __syncthreads();  // B2
+                if (t > 0) reward_store(t - 1);
+                __syncthreads();  // B3: the compute waves move the agents after this one
+            }
+            __syncthreads();      // positions after the last physics update
+            partials(0); partials(1); partials(2); partials(3);
+            reward_store(T - 1);
+            { const int t4 = (T - 1) & ~3; flush_alog(t4, T - t4); }
+        }
+        return;
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();
+        if (tid < TS) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            if (live) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+            // =============================================== the compute waves ===============================================
+            const int o_el = orow / A, o_i = orow - o_el * A;
+            const bool o_live = orow < RT && (e0 + o_el) < a.E;
+            const int s_el = srow / A;
+            const bool s_live = srow < RT && (e0 + s_el) < a.E;
+            for (int t = 0; t < T; ++t) {
+                __syncthreads();  // B0
+                PH(0);  // wait at B0 (+ the tail of the previous step after PH(7))
+                {   // observations of step t -> Xs (lane oq = entity oq: landmark, other agent, id)
+                    float* xr = Xs + orow * LDT;
+                    if (o_live) {
+                        const float* pos = epos + o_el * 2 * A; const float* vel = evel + o_el * 2 * A; const float* lm = elm + o_el * 2 * A;
+                        const float px = pos[2 * o_i], py = pos[2 * o_i + 1];
+                        if (oq == 0) { xr[0] = vel[2 * o_i]; xr[1] = vel[2 * o_i + 1]; xr[2] = px; xr[3] = py; }
+                        const int j = oq;
+                        if (j < A) {
+                            const float pjx = pos[2 * j], pjy = pos[2 * j + 1];
+                            xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                            const float ax = pjx - px, ay = pjy - py;
+                            if (j != o_i) {
+                                const int jj = j < o_i ? j : j - 1;
+                                xr[4 + 2 * A + 2 * jj] = ax; xr[5 + 2 * A + 2 * jj] = ay;
+                                xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                            }
+                            if (a.agent_ids) xr[6 * A + j] = (j == o_i) ? 1.0f : 0.0f;
+                        }
+                        for (int c = din + oq; c < KC; c += 16) xr[c] = 0.0f;  // MFMA padding (H1 recycles this buffer)
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < KC / 16; ++j) xr[16 * j + oq] = 0.0f;
+                    }
+                }
+                const float u_row = ubuf[((t >> 4) & 1) * 16 * TS + (t & 15) * TS + srow];  // drawn >= 12 steps ago; consumed after the head
+                PH(1);  // obs build
+                __syncthreads();  // B1
+                PH(2);  // wait at B1
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                tile16_nt_reg_pre(acc, Xs, w0r, (din + 7) >> 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) H0[(4 * g16 + q) * LDT + 16 * wave + n16] = fmaxf(acc[q] + b0r, 0.0f);
+                PH(3);  // layer 0
+                __syncthreads();  // B2
+                PH(4);  // wait at B2
+                const float* HL = H0;
+                if (L > 0) {  // hidden layer; H1 aliases Xs (every reader of the obs tile is past B2)
+                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    tile16_nt_reg_pre(acc, H0, w1r, HP / 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Xs[(4 * g16 + q) * LDT + 16 * wave + n16] = fmaxf(acc[q] + b1r, 0.0f);
+                    HL = Xs;
+                }
+                PH(5);  // layer 1
+                __syncthreads();  // B3
+                PH(6);  // wait at B3
+                // head: the whole 16 x 16 logit tile per wave, row 4g + w kept by lane group g
+                const f32x4 lg = head_logits_reg(HL, wor);
+                const float zraw = wave == 0 ? lg[0] : (wave == 1 ? lg[1] : (wave == 2 ? lg[2] : lg[3]));
+                const float zl = zraw + bor;
+                // the K <= 8 logits of the row from the first lanes of its DPP row into EVERY lane's registers (row_shl:k, independent moves),
+                // then the serial sampler of the per-step kernels in registers: ~30 dependent DPP steps (max, two serial prefix sums, hand-
+                // down, argmin / argmax) were 1.7 k cycles of the step
+                float zr[8];
+                zr[0] = zl; zr[1] = dpp_f<0x101>(zl); zr[2] = dpp_f<0x102>(zl); zr[3] = dpp_f<0x103>(zl);
+                zr[4] = dpp_f<0x104>(zl); zr[5] = dpp_f<0x105>(zl); zr[6] = dpp_f<0x106>(zl); zr[7] = dpp_f<0x107>(zl);
+                int chosen; float lpv;
+                sample_row8(zr, K, u_row, a.act_eps, &chosen, &lpv);   // valid in lane n16 == 0 of each row
+                if (n16 == 0 && s_live) {
+                    // point-mass physics (cm_env.hip k_env_step) first: the next step's chain starts from these positions
+                    const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
+                    const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);
+                    const float vx = evel[2 * srow] * (1.0f - DAMP) + ux * DT;
+                    const float vy = evel[2 * srow + 1] * (1.0f - DAMP) + uy * DT;
+                    evel[2 * srow] = vx; evel[2 * srow + 1] = vy;
+                    epos[2 * srow] += vx * DT; epos[2 * srow + 1] += vy * DT;
+                    alog[srow * 4 + (t & 3)] = __builtin_bit_cast(float, chosen);   // flushed by the store wave every 4 steps
+                    alog[(TS + srow) * 4 + (t & 3)] = lpv;
+                }
+                PH(7);  // head + sample + physics
+            }
+            __syncthreads();
+            if (tid < RT) {  // final env state back to global (pos | vel | landmarks)
+                const int el = tid / A, i = tid - el * A;
+                const long e = e0 + el;
+                if (e < a.E) {
+                    float* es = a.env_state + e * 6 * A;
+                    es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                    es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                    es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+                }
+            }
+    }
+    PH_FLUSH_C;
+}
+
 }  // namespace
 
 extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int n_hidden_layers) {
@@ -706,13 +1102,21 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
     const int EPT = TM / A;
     const int ntiles = (E + EPT - 1) / EPT;
     // Few 64-row tiles (a GPU's share of a sharded batch, config 2) leave most CUs idle and every step a 64-row serial chain: while
-    // all 16-row tiles are resident at once (768 workgroups; a second pass would double the time) the 16-row form runs instead (same arithmetic; CM_ROLLOUT_TILE=16 / 64 forces one for A/B runs and tests)
-    const char* forced_s = getenv("CM_ROLLOUT_TILE");  // read per launch (tests flip it inside one process)
-    const int forced = forced_s ? atoi(forced_s) : 0;
+    // all 16-row tiles are resident at once (768 workgroups; a second pass would double the time) the 16-row form runs instead (same arithmetic; cm_set_option("rollout_tile", "16s" / "16" / "64") forces one for A/B runs and tests)
+    const int forced = cm_option(CM_OPTION_ROLLOUT_TILE);  // 0 auto, 64, 16 (four-wave form), 17 ("16s": store-wave form)
     const bool can16 = A <= TS;
     const int EPT16 = can16 ? TS / A : 1;
     const int nt16 = (E + EPT16 - 1) / EPT16;
-    const bool use16 = can16 && (forced == 16 || (forced != 64 && nt16 <= 768));  // one resident wave of 16-row workgroups (3 per CU)
+    const bool use16 = can16 && (forced == 16 || forced == 17 || (forced == 0 && nt16 <= 768));  // one resident wave of 16-row workgroups (3 per CU)
+    // at most one 16-row workgroup per CU: the store-wave form (four compute waves + writer + scorer)
+    const bool use16s = use16 && (forced == 17 || (forced == 0 && nt16 <= 256));  // one six-wave workgroup per CU
+    if (use16s) {
+        const size_t lds = ((size_t)TS * LDT * 2 + TS * 2 * 3 + 2 * TS + 2 * 16 * TS + 2 * TS * 4) * sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread16s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_rollout_spread16s, dim3(nt16 < 256 ? nt16 : 256), dim3(NT_SW), lds, (hipStream_t)stream, a);
+        CM_CHECK_LAUNCH("cm_rollout_spread");
+        return 0;
+    }
     if (use16) {
         const size_t lds16 = ((size_t)TS * LDT * 2 + TS * 2 * 3 + 4 * TS + 2 * TS) * sizeof(float);  // tiles + env scratch: the weights are in registers
         const int grid16 = nt16 < 768 ? nt16 : 768;  // three workgroups per CU (launch bounds)

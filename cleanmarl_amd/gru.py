@@ -36,6 +36,7 @@ class GRUPPOLearner(PPOLearner):
             self.h = [torch.zeros(b.E * b.A, a.hidden, dtype=torch.float32, device=self.device) for _ in range(2)]
 
     def update(self, b, keep_grads=False):
+        N.sync_env_options()
         hp, s, a = self.hp, N.stream_ptr(), self.actor_spec
         self._ensure(b)
         Pa, Pc = self.actor.numel(), self.critic.numel()
@@ -148,6 +149,7 @@ class GRUSyntheticRollout:
         self.episode = 0
 
     def collect(self, actor_flat, actor_spec, fused=None):
+        N.sync_env_options()
         self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K

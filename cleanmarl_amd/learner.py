@@ -307,6 +307,7 @@ class PPOLearner:
     # ------------------------------------------------------------------ a6 / a7
     def compute_targets(self, b):
         """TD(lambda) returns + advantages into b.ret / b.adv (cleanmarl/mappo_multienvs.py:484-512)."""
+        N.sync_env_options()
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
         E, A, T = b.E, b.A, b.T
         cs = self.critic_spec
@@ -435,7 +436,7 @@ class PPOLearner:
         if v in ("0", "1", "2"):
             return int(v)
         rows = self._schedule_rows(b)
-        return 1 if rows <= (1 << 19) else 2 if rows <= (1 << 21) else 0
+        return 1 if rows < (1 << 19) else 2 if rows <= (1 << 21) else 0
 
     def _schedule_rows(self, b):
         """Row count the schedule is chosen from -- the SAME number on every rank: env shards may differ by one env (dist.shard), and
@@ -463,6 +464,7 @@ class PPOLearner:
           * small batch (overlap_critic): the actor's epochs on the current stream, then the critic's epochs on a second stream that
             is NOT joined here -- the caller's next rollout overlaps them, the next value pass waits for them (wait_critic()).
         Returns per-epoch records (LazyRecords: no host wait)."""
+        N.sync_env_options()
         hp, s = self.hp, N.stream_ptr()
         Pa, Pc = self.actor.numel(), self.critic.numel()
         nE0 = int(hp.epochs)

@@ -43,6 +43,7 @@ class SyntheticSpreadRollout:
         current stream; returns the filled DeviceBatch without synchronising.
         fused=None picks the single-launch persistent kernel (cm_rollout_spread) whenever the shape allows,
         else T x (cm_policy_act + cm_synth_env_step); both produce the same rollout for the same seeds."""
+        N.sync_env_options()
         self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
@@ -108,6 +109,7 @@ class SyntheticShapeRollout:
         self.episode = 0
 
     def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
+        N.sync_env_options()
         self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K

@@ -55,8 +55,20 @@ enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1, CM_OPT_SGD = 2, CM_OPT_RMSPROP = 3 }; 
 
 const char* cm_last_error(void);
 int cm_version(void);
-/* GEMM arithmetic of the PPO training passes: 0 = exact fp32 MFMA (default), 1 = error-compensated bf16 (environment variable
- * CM_MFMA=bf16x3, read once per process; ~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8). */
+/* Schedule / arithmetic options.  The library picks schedules from the problem size (thresholds measured on MI355X);
+ * a caller can force one -- for A/B measurements, tests, or a box where the thresholds sit elsewhere.  The library never reads the
+ * process environment.  Options are process-wide, take effect at the next launch and may be changed at any time
+ * (value "auto" / the first value listed is the default):
+ *   "mlp_forms"        auto | hand | loop      hand-ordered vs compiler-scheduled LDS reads of the fused MLP product loops
+ *   "critic_schedule"  auto | fused | split    one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule
+ *   "gru_tile"         auto | 64               64: the 64-row streaming GRU sweeps at any batch size
+ *   "rollout_tile"     auto | 64 | 16 | 16s    tiling of the fused rollout (16s: 16-row tiles with a store wave)
+ *   "mfma"             fp32 | bf16x3           GEMM arithmetic of the PPO training passes: exact fp32 MFMA, or error-compensated
+ *                                              bf16 (~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8)
+ * cm_set_option returns 0, or -1 for an unknown key / value; cm_get_option returns the current value's name (NULL: unknown key). */
+int cm_set_option(const char* key, const char* value);
+const char* cm_get_option(const char* key);
+/* current "mfma" option: 0 = fp32, 1 = bf16x3 */
 int cm_mfma_mode(void);
 /* A HIP stream of the LOWEST priority the device offers (hipStreamCreateWithPriority, non-blocking), for work that has slack and
  * should only fill compute units the caller's main stream leaves idle: the critic epochs of iteration i run on it under the rollout
@@ -294,7 +306,7 @@ int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* ava
  * kernel (din <= 128), the two-kernel split schedule (wider inputs) and -- for 65 .. 448 input columns on 16-byte aligned rows, one
  * hidden layer, from 131072 rows on -- the one-pass kernel of csrc/cm_critic_fused.h, which reads x from HBM once.  The padding columns
  * [din, x_ld) must hold FINITE values (the library's own rollouts write zeros): they meet zero weights, never a mask.
- * Environment (read per call; for A/B runs and tests): CM_CRITIC_SCHEDULE=fused|split forces the one-pass / two-kernel schedule. */
+ * cm_set_option("critic_schedule", "fused" | "split") forces the one-pass / two-kernel schedule. */
 int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
                          int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                          const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);

@@ -17,3 +17,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_options_back_to_defaults():
+    """Schedule options are process-wide (cm_set_option): whatever a test forced -- directly or through the package's CM_* variables --
+    is undone after it, so the next test starts from the library's own choices."""
+    yield
+    try:
+        from cleanmarl_amd import _native as N
+    except Exception:
+        return
+    if N._lib is not None:
+        for key, default in N._DEFAULTS.items():
+            N._lib.cm_set_option(key.encode(), default.encode())
+        N._applied.clear()
+        N._env_seen.clear()
