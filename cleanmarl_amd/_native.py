@@ -92,6 +92,8 @@ SIGNATURES = {
     "cm_gru_actor_chunk_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _d, _d,
                                         _p, _p, _sz, _p]),
     "cm_gru_policy_act": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p, _u64, _l, _i, _p, _p, _l, _p]),
+    "cm_gru_policy_act_workspace_bytes": (_sz, [_l, _i, _i, _i]),
+    "cm_gru_policy_act_ws": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p, _d, _u64, _l, _i, _p, _p, _l, _p, _sz, _p]),
     "cm_synth_env_reset": (_i, [_p, _i, _i, _i, _u64, _l, _l, _p, _p, _i, _p]),
     "cm_synth_env_step": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "cm_shape_env_fill": (_i, [_i, _i, _i, _i, _i, _i, _i, _d, _u64, _l, _l, _p, _p, _p, _p]),

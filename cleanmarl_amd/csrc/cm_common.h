@@ -26,6 +26,16 @@ int cm_option(int which);
 int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
                           float* grad_and_stats, const cm_opt_step_t* opt, hipStream_t s, const char* who);
 
+// layered GRU schedule (cm_gru_wide.hip): obs wider than 64 columns and / or 65..256 hidden units
+size_t cm_gru_wide_ws_bytes(int64_t R, int chunk_len, int din, int H, int K, int train);
+int cm_gru_wide_chunk(const float* obs, const uint8_t* avail, const int32_t* action, const float* logp_old, const float* adv,
+                      const int32_t* ep_len, int E, int A, int T, int t0, int t1, int din, int H, int K, const float* params,
+                      const float* h_in, float* h_out, double ppo_clip, double entropy_coef, float* grad_and_stats, void* ws,
+                      size_t ws_bytes, hipStream_t s, const cm_opt_step_t* opt);
+int cm_gru_wide_act(const float* x, int64_t x_stride, const uint8_t* avail, int64_t avail_stride, int64_t rows, int din, int H, int K,
+                    const float* params, float* h, uint64_t seed, int64_t row_offset, int t, float eps, int32_t* action, float* logp,
+                    int64_t out_stride, void* ws, size_t ws_bytes, hipStream_t s);
+
 // ---------------------------------------------------------------- Philox4x32-10 (counter RNG)
 // Keyed by the run seed, counted by (global row, time step, stream id): the draw for a given
 // (env, agent, t) is the same no matter how envs are sharded over GPUs.

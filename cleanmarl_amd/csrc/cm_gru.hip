@@ -834,8 +834,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_act(const GruArgs a) {
 
 int gru_check(const char* who, int din, int H, int K) {
     CM_REQUIRE(din > 0 && H > 0 && K > 0, "%s: bad dims din=%d H=%d K=%d", who, din, H, K);
-    CM_REQUIRE(H <= HP, "%s: hidden_dim=%d > %d is not supported by this build", who, H, HP);
-    CM_REQUIRE(din <= KC, "%s: obs width %d > %d is not supported by the GRU kernels of this build", who, din, KC);
+    CM_REQUIRE(H <= HP, "%s: hidden_dim=%d > %d needs the layered schedule (workspace-taking entry points)", who, H, HP);
+    CM_REQUIRE(din <= KC, "%s: obs width %d > %d needs the layered schedule (workspace-taking entry points)", who, din, KC);
     CM_REQUIRE(K <= KMAX, "%s: n_actions=%d > %d is not supported by this build", who, K, KMAX);
     return 0;
 }
@@ -848,8 +848,11 @@ static size_t gru_ps(int din, int hidden, int K) {
     return (size_t)((cm_gru_param_count(din, hidden, K) + CM_NUM_STATS + 63) / 64 * 64);
 }
 
+static bool gru_wide(int din, int hidden) { return din > KC || hidden > HP; }  // layered schedule (cm_gru_wide.hip)
+
 extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int n_actions, int chunk_len) {
     const size_t R = (size_t)E * A;
+    if (gru_wide(din, hidden)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
     // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
     return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
 }
@@ -860,8 +863,11 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
                           const float* params, const float* h_in, float* h_out,
                           double ppo_clip, double entropy_coef,
                           float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream, const cm_opt_step_t* opt) {
-    if (int rc = gru_check("cm_gru_actor_chunk_fwd_bwd", din, hidden, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T, "cm_gru_actor_chunk_fwd_bwd: bad dims E=%d A=%d T=%d t0=%d t1=%d", E, A, T, t0, t1);
+    if (gru_wide(din, hidden))
+        return cm_gru_wide_chunk(obs, avail, action, logp_old, adv, ep_len, E, A, T, t0, t1, din, hidden, n_actions, params, h_in, h_out, ppo_clip,
+                                 entropy_coef, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, opt);
+    if (int rc = gru_check("cm_gru_actor_chunk_fwd_bwd", din, hidden, n_actions)) return rc;
     const size_t need = cm_gru_workspace_bytes(E, A, din, hidden, n_actions, t1 - t0);
     CM_REQUIRE(ws && ws_bytes >= need, "cm_gru_actor_chunk_fwd_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     const size_t R = (size_t)E * A;
@@ -956,6 +962,23 @@ extern "C" int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uin
 #undef CM_GRU_LAUNCH1
     CM_CHECK_LAUNCH("cm_gru_policy_act");
     return 0;
+}
+
+/* the same step with a caller workspace: also serves the layered shapes, and eps < 0 takes the argmax (greedy evaluation) */
+extern "C" size_t cm_gru_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_actions) {
+    return cm_gru_wide_ws_bytes(rows, 1, din, hidden, n_actions, 0);
+}
+extern "C" int cm_gru_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                                    int64_t rows, int din, int hidden, int n_actions, const float* params, float* h, double eps,
+                                    uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp, int64_t out_stride,
+                                    void* ws, size_t ws_bytes, cm_stream_t stream) {
+    CM_REQUIRE(h != nullptr, "cm_gru_policy_act_ws: hidden state pointer is NULL");
+    CM_REQUIRE(eps <= 0.0, "cm_gru_policy_act_ws: eps=%g (the recurrent scripts have no epsilon-mixed exploration; eps < 0 = greedy)", eps);
+    if (!gru_wide(din, hidden) && eps == 0.0)  // the fused step kernel
+        return cm_gru_policy_act(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_actions, params, h, seed, row_offset, t, action, logp,
+                                 out_stride, stream);
+    return cm_gru_wide_act(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_actions, params, h, seed, row_offset, t, (float)eps, action,
+                           logp, out_stride, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cm_gru_rollout_spread_supported(int A, int agent_ids, int hidden) {

@@ -55,9 +55,14 @@ class HostActor:
         if self.recurrent:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
-            N.check(self.lib.cm_gru_policy_act(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
-                                               N.ptr(self.L.actor), N.ptr(h), seed, self.row_offset, self.calls, N.ptr(action), N.ptr(logp), 1,
-                                               N.stream_ptr()), "cm_gru_policy_act")
+            # eps < 0: argmax (greedy evaluation); obs wider than 64 columns / more than 64 hidden units: the layered schedule's workspace
+            need = self.lib.cm_gru_policy_act_workspace_bytes(rows, spec.din, spec.hidden, spec.dout)
+            if self.ws is None or self.ws.numel() < need:
+                self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            N.check(self.lib.cm_gru_policy_act_ws(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
+                                                  N.ptr(self.L.actor), N.ptr(h), -1.0 if greedy else 0.0, seed, self.row_offset, self.calls,
+                                                  N.ptr(action), N.ptr(logp), 1, N.ptr(self.ws), self.ws.numel(), N.stream_ptr()),
+                    "cm_gru_policy_act_ws")
         else:
             # eps < 0: argmax of the masked logits (build option; the reference always samples); eps > 0: COMA exploration
             mode = -1.0 if greedy else float(eps)

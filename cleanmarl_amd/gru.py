@@ -172,10 +172,14 @@ class GRUSyntheticRollout:
                                        self.episode, N.ptr(b.obs), N.ptr(b.state), T, s), "cm_synth_env_reset")
         act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
         off = lambda t, nbytes: C.c_void_p(t.data_ptr() + nbytes)
+        need = lib.cm_gru_policy_act_workspace_bytes(E * A, actor_spec.din, actor_spec.hidden, K)  # used by the layered shapes only
+        if getattr(self, "act_ws", None) is None or self.act_ws.numel() < need:
+            self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         for t in range(T):
-            N.check(lib.cm_gru_policy_act(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                          actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
-                                          off(b.action, 4 * t), off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
+            N.check(lib.cm_gru_policy_act_ws(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                             actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), 0.0, act_seed, self.env_offset * A, t,
+                                             off(b.action, 4 * t), off(b.logp, 4 * t), T, N.ptr(self.act_ws), self.act_ws.numel(), s),
+                    "cm_gru_policy_act_ws")
             N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,
                                           N.ptr(b.reward), N.ptr(b.obs), N.ptr(b.state), s), "cm_synth_env_step")
         self.episode += 1

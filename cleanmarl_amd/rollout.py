@@ -141,11 +141,15 @@ class SyntheticShapeRollout:
             if self.h is None:
                 self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)
             self.h.zero_()
+            gneed = lib.cm_gru_policy_act_workspace_bytes(E * A, actor_spec.din, actor_spec.hidden, K)  # used by the layered shapes only
+            if getattr(self, "gru_ws", None) is None or self.gru_ws.numel() < gneed:
+                self.gru_ws = torch.empty(gneed, dtype=torch.uint8, device=self.device)
         for t in range(T):
             if gru:
-                N.check(lib.cm_gru_policy_act(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                              actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), act_seed, self.env_offset * A, t,
-                                              _off(b.action, 4 * t), _off(b.logp, 4 * t), T, s), "cm_gru_policy_act")
+                N.check(lib.cm_gru_policy_act_ws(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
+                                                 actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), 0.0, act_seed, self.env_offset * A, t,
+                                                 _off(b.action, 4 * t), _off(b.logp, 4 * t), T, N.ptr(self.gru_ws), self.gru_ws.numel(), s),
+                        "cm_gru_policy_act_ws")
             else:
                 N.check(lib.cm_policy_act_ws(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
                                              actor_spec.hidden, actor_spec.n_layers, K, N.ptr(actor_flat), float(eps), act_seed,

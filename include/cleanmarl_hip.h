@@ -237,6 +237,18 @@ int cm_gru_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail
                       uint64_t seed, int64_t row_offset, int t,
                       int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
 
+/* The GRU entry points above keep a 64-wide actor on <= 64 observation columns in registers / LDS (fused sweeps).  The reference's Actor
+ * takes any input_dim / hidden_dim (mappo_lstm_multienvs.py:162-184): wider observations or 65..256 hidden units run a LAYERED schedule
+ * (csrc/cm_gru_wide.hip: the h-independent parts batched over the chunk as GEMMs, one small GEMM group + one element-wise launch per
+ * recurrent step) behind the SAME training entry points -- cm_gru_workspace_bytes sizes either -- and behind this workspace-taking
+ * act entry point (the query is what the layered schedule needs; fused shapes accept ws = NULL unless eps < 0).
+ * eps = 0 samples Categorical(logits) with the usual Philox keying, eps < 0 takes the argmax (the build's --greedy_eval). */
+size_t cm_gru_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_actions);
+int cm_gru_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
+                         int64_t rows, int din, int hidden, int n_actions, const float* params, float* h, double eps,
+                         uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp, int64_t out_stride,
+                         void* ws, size_t ws_bytes, cm_stream_t stream);
+
 /* ---- a15: on-device synthetic MPE-like environment (replaces the pipe round trips at
  * cleanmarl/mappo_multienvs.py:393-453 for the synthetic configs; CommonInterface semantics of
  * cleanmarl/env/common_interface.py:5-23 and the obs/state construction of
