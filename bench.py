@@ -177,6 +177,10 @@ def summarize(w, r):
                 roofline_frac=(_bound(wk["actor"], r["actor_ms"]) or {}).get("frac"))
 
 
+def total_envs_of(args, world, E_glob):
+    return E_glob if args.scaling == "strong" else world * E_glob
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,11 +195,22 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=256, help="envs in the bounded CPU-baseline sample")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's command line does (one process per GPU
+        # under torch.distributed.run); rank 0's JSON line passes through on stdout
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus}: launched with WORLD_SIZE={world}")
     # CM_BENCH_BACKEND=gloo is a TEST hook (tests/test_dist_gpu.py): RCCL refuses two ranks on one device, gloo does
     # not, so the N > 1 code path of this file can be exercised on a 1-GPU box with every rank on cuda:0.
     backend = os.environ.get("CM_BENCH_BACKEND", "nccl")
@@ -225,6 +240,7 @@ def main():
     else:
         first, E = rank * E_glob, E_glob
     w = Workload(args.workload, E, first, dev, pg, world)
+    w.learner.global_envs = total_envs_of(args, world, E_glob)  # rank-invariant schedule choice (learner._schedule_rows)
     r = w.run(args.steps, args.warmup)
     A, T, hp = w.A, w.T, w.hp
     total_envs = E_glob if args.scaling == "strong" else world * E_glob

@@ -47,7 +47,10 @@ def run(script, argv=None):
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     pg = None
-    if world > 1:
+    force = world == 1 and os.environ.get("CM_FORCE_COLLECTIVES") == "1"  # test hook: see driver.run
+    if force:
+        os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -195,6 +198,6 @@ def run(script, argv=None):
         venv.close()
     if the_env is not None:
         the_env.close()
-    if world > 1:
+    if world > 1 or force:
         torch.distributed.destroy_process_group()
     return dict(step=step, training_step=learner.training_step, history=writer.history if writer else [], learner=learner)

@@ -194,7 +194,12 @@ def run(script, argv=None):
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     pg = None
-    if world > 1:
+    # CM_FORCE_COLLECTIVES=1 (test hook): a ONE-rank process group, so that the learners issue every collective of an env-sharded run --
+    # over RCCL itself on a one-GPU box (a one-rank sum is the identity: the run must equal the plain one)
+    force = world == 1 and os.environ.get("CM_FORCE_COLLECTIVES") == "1"
+    if force:
+        os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -223,6 +228,7 @@ def run(script, argv=None):
         learner = GRUPPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
     else:
         learner = PPOLearner(algo, actor_spec, critic_spec, A, hp, device, a_init, c_init, pg, world)
+    learner.global_envs = E_glob  # the update schedule is chosen from the largest shard, identically on every rank (learner._schedule_rows)
 
     device_env = args.env_type in ("synthetic", "synthetic_shape")
     venv = roll = the_env = pinned = None
@@ -381,6 +387,6 @@ def run(script, argv=None):
         venv.close()
     if the_env is not None:
         the_env.close()
-    if world > 1:
+    if world > 1 or force:
         torch.distributed.destroy_process_group()
     return dict(step=step, training_step=training_step, history=writer.history if writer else [], learner=learner)

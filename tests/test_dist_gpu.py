@@ -122,6 +122,24 @@ def test_bench_two_rank_launch_on_one_gpu():
     assert abs(out["value"] - 2 * 96 * 3 * 128 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 
+def test_bench_starts_its_own_ranks_without_torchrun():
+    """A bare `python bench.py --gpus 2` (no torch.distributed.run, WORLD_SIZE unset) must not die on the launcher check: it starts
+    its ranks itself and prints rank 0's line (gloo test hook: both ranks on cuda:0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CM_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg2",
+                        "--envs", "96", "--no-extras"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_envs"] == 96 and out["config"]["envs_per_gpu"] == 48 and out["value"] > 0
+
+
 def _coma_worker(rank, world, port, gold, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -367,6 +385,106 @@ def test_rccl_carries_the_all_reduces_of_every_update_schedule(golden_dir, tmp_p
         for e, r in enumerate(g["recs"]):
             assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL, sched
     assert torch.equal(got["1"]["actor"], got["2"]["actor"]) and torch.equal(got["1"]["critic"], got["2"]["critic"])
+
+
+def _worker_rccl_gru_coma(rank, world, port, gold_gru, gold_coma, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from oracle import coma as C
+    from oracle import restatement as R
+    from cleanmarl_amd.coma_learner import COMAHParams, COMALearner
+    from cleanmarl_amd.gru import GRUPPOLearner
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec
+    dev, pg = torch.device("cuda:0"), torch.distributed.group.WORLD
+    res = {}
+    # ---- GRU / TBPTT: one blocking all-reduce per chunk on the launch stream + the critic's on the side stream and its own communicator
+    batch, ap, cp, hp, z = R.load_golden(gold_gru)
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"], batch["states"], batch["avail"],
+                                          batch["mask"], dev)
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=False, normalize_advantage=bool(hp["normalize_advantage"]),
+                normalize_return=bool(hp["normalize_return"]), epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], tbptt=int(hp["tbptt"]),
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], 0, ap[-1].shape[0], "gru")
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    L = GRUPPOLearner("mappo", aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp, process_group=pg, world_size=world)
+    assert L._coll and L.pg_c is not L.pg
+    recs = [dict(r) for r in L.train_iteration(b)]
+    torch.cuda.synchronize()
+    res["gru"] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu())
+    # ---- COMA: gradient buffers + the float64 per-time-step advantage sums
+    batch, ap, cp, hp, z = C.load_golden(gold_coma)
+    b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), batch["reward"], batch["states"],
+                                          batch["avail"], batch["mask"], dev)
+    Hc = COMAHParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=False, normalize_advantage=bool(hp["normalize_advantage"]),
+                     normalize_return=bool(hp["normalize_return"]), target_network_update_freq=int(hp["target_network_update_freq"]),
+                     polyak=hp["polyak"], entropy_coef=hp["entropy_coef"], use_tdlamda=bool(hp["use_tdlamda"]), nsteps=int(hp["nsteps"]),
+                     clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"], learning_rate_actor=hp["learning_rate_actor"],
+                     learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, cp[-1].shape[0])
+    Lc = COMALearner(aspec, cspec, batch["obs"].shape[2], Hc, dev, actor_params=ap, critic_params=cp, process_group=pg, world_size=world)
+    assert Lc._coll
+    rec = Lc.train_iteration(b)
+    torch.cuda.synchronize()
+    res["coma"] = dict(rec=rec, actor=Lc.actor.cpu(), critic=Lc.critic.cpu(), target=Lc.target.cpu())
+    torch.save(res, f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_carries_the_all_reduces_of_the_gru_and_coma_learners(golden_dir, tmp_path, monkeypatch):
+    """The other two learners over RCCL (one rank, CM_FORCE_COLLECTIVES=1): GRUPPOLearner's blocking per-chunk all-reduce on the launch
+    stream with the critic's epoch on a second stream and communicator (gru.py), COMALearner's gradient and float64 moment
+    all-reduces -- a pattern no NCCL-backed run had executed before round 3.  One-rank sums are identities: both must land on the
+    unmodified reference's results."""
+    monkeypatch.setenv("CM_FORCE_COLLECTIVES", "1")
+    out = str(tmp_path / "rccl2")
+    gg, gc = os.path.join(golden_dir, "mappo_lstm_ragged.npz"), os.path.join(golden_dir, "coma_tdlambda.npz")
+    mp.spawn(_worker_rccl_gru_coma, args=(1, _free_port(), gg, gc, out), nprocs=1, join=True)
+    got = torch.load(f"{out}.0", weights_only=False)
+    z = np.load(gg)
+    g = got["gru"]
+    for e, r in enumerate(g["recs"]):
+        assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
+        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+    assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+    z = np.load(gc)
+    c = got["coma"]
+    assert _err(c["rec"]["critic_loss"], float(z["cr_loss"])) <= TOL and _err(c["rec"]["actor_loss"], float(z["ac_loss"])) <= TOL
+    assert _err(c["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(c["actor"].numpy(), z["actor_after"][0]) <= TOL
+    assert _err(c["target"].numpy(), z["target_after"]) <= 1e-6
+
+
+@pytest.mark.parametrize("script", ["mappo_multienvs", "mappo_lstm_multienvs", "coma_multienvs"])
+def test_cli_run_over_rccl_equals_the_plain_run(script, tmp_path):
+    """A whole CLI run (driver / coma_driver) with a one-rank RCCL process group and every collective issued (CM_FORCE_COLLECTIVES=1)
+    logs the scalars of the plain single-process run of the same command."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mod = "coma_driver" if script.startswith("coma") else "driver"
+    prog = ("import json, sys; sys.path.insert(0, %r); from cleanmarl_amd.%s import run; "
+            "out = run(%r, ['--env_type=synthetic', '--batch_size=6', '--synthetic_agents=3', '--synthetic_steps=12', "
+            "'--total_timesteps=216', '--eval_steps=100000', '--log_every=1']); print('HIST ' + json.dumps(out['history']))") % (root, mod, script)
+    path = str(tmp_path / "run_cli.py")
+    open(path, "w").write(prog + "\n")
+    hists = []
+    for force in ("0", "1"):
+        env = dict(os.environ, CM_FORCE_COLLECTIVES=force, MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, path], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        hists.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("HIST ")][0][5:]))
+    plain, forced = hists
+    assert len(plain) == len(forced) and len(plain) > 0
+    for (t1, v1, s1), (t2, v2, s2) in zip(plain, forced):
+        assert t1 == t2 and s1 == s2
+        if not t1.startswith("charts/") and "SPS" not in t1 and "time" not in t1:
+            assert abs(v1 - v2) <= 1e-5 * (1 + abs(v1)), (t1, v1, v2)
 
 
 def test_two_rank_cli_run_with_host_envs_matches_the_single_process_run(tmp_path):
