@@ -26,10 +26,12 @@ namespace {
 #endif
 #define ROLLOUT_WAVE_PRIO() __builtin_amdgcn_s_setprio(CM_ROLLOUT_PRIO)
 #ifdef CM_PHASE_PROF  // the store wave's own slots 8..15 of the workgroup's profile row (tools/phase_prof.py rollout)
-#define PH_FLUSH_SW do { if (a.prof && threadIdx.x == NTHREADS) { _Pragma("unroll") for (int i_ = 8; i_ < 16; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
+#define PH_FLUSH_SW do { if (a.prof && threadIdx.x == NTHREADS) { _Pragma("unroll") for (int i_ = 8; i_ < 14; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
+#define PH_FLUSH_SC do { if (a.prof && threadIdx.x == NTHREADS + 64) { a.prof[(size_t)blockIdx.x * 16 + 14] = ph_[14]; a.prof[(size_t)blockIdx.x * 16 + 15] = ph_[15]; } } while (0)
 #define PH_FLUSH_C do { if (a.prof && threadIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; } } while (0)
 #else
 #define PH_FLUSH_SW
+#define PH_FLUSH_SC
 #define PH_FLUSH_C
 #endif
 
@@ -769,7 +771,7 @@ __device__ __forceinline__ void sample_row8(const float (&z)[8], int K, float u,
 
 constexpr int NT_SW = NTHREADS + 128;  // four compute waves + the writer wave + the scorer wave
 
-__global__ __launch_bounds__(NT_SW, 1) void k_rollout_spread16s(const RolloutArgs a) {
+__global__ __launch_bounds__(NT_SW, 2) void k_rollout_spread16s(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1075,6 +1077,353 @@ __global__ __launch_bounds__(NT_SW, 1) void k_rollout_spread16s(const RolloutArg
     PH_FLUSH_C;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Six-wave form of the 64-row rollout (round 3): the role split of k_rollout_spread16s on 64-row tiles, for env counts that fill
+// the chip (config 3: 512 tiles, two workgroups per CU).  In k_rollout_spread the non-matrix phases were 56 % of a step
+// (profiles/r02_phase_rollout.txt: obs + reward partials 16 %, buffer writes 19 %, sample + physics 21 % -- the sampler and the reward
+// on ONE wave while three wait); here
+//   * the four compute waves build the obs tile, run the MLP, and EACH samples its own 16 rows straight after its head MFMAs
+//     (wave-private logits, no barrier, four samplers in parallel) and moves those agents: four barriers per step instead of six;
+//   * the writer wave copies the obs tile to the obs / state buffers while layer 0 runs and draws the uniforms four steps ahead;
+//   * the scorer wave computes the reward partials and team rewards and flushes actions / log-probs every four steps (16-byte stores).
+// Same arithmetic and keys as every other tiling: bit-identical rollouts (tests/test_hip_parity.py).
+__global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = wave == 4, scorer = wave == 5;
+    if (wave < 4) ROLLOUT_WAVE_PRIO();
+    const int wm = (wave >> 1) & 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
+    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    const int EPT = TM / A, RT = EPT * A;  // envs / valid rows per tile
+    // LDS carve (two workgroups per CU: 2 x 81.7 KB)
+    float* Xs = smem;                    // obs tile; aliased by H1 once layer 0 has consumed it
+    float* W0s = Xs + TM * LDT;
+    float* H0 = W0s + HP * LDT;
+    float* Ws = H0 + TM * LDT;
+    float* wouts = Ws + HP * LDT;        // [16][WLD], rows >= K zero (operand of the 16x16x4 MFMA head)
+    float* b0s = wouts + 16 * WLD;
+    float* b1s = b0s + HP;
+    float* bos = b1s + HP;               // [8]
+    float* ls = bos + 8;                 // [TM][8] logits (wave w: rows 16w .. 16w+15); the scorer's reward partials [2][TM] alias it between B0 and B1
+    float* epos = ls + TM * 8;           // [TM][2] per row (env-local agent)
+    float* evel = epos + TM * 2;
+    float* elm = evel + TM * 2;
+    float* ubuf = elm + TM * 2;                          // [4][TM] uniforms of steps t .. t+3 (slot t & 3)
+    float* alog = ubuf + 4 * TM;                         // [2][TM][4] action bits / log-prob of four steps per row
+    float* rscr = ls;
+
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const int nq = (din + 3) >> 2, ns = (6 * A) >> 2;
+    const bool vo = (a.obs_ld % 4 == 0) && (4 * nq <= a.obs_ld) && nq <= 16;
+    const bool vs = ((6 * A) % 4 == 0) && (a.state_ld % 4 == 0) && ns <= 16;
+    const bool v4 = (T % 4) == 0;
+    PH_DECL
+    if (writer) {
+        // ======================================= the writer wave: the obs tile -> obs / state rollout buffers
+        // 26 KB of 224- / 1536-byte row segments per step go through one CU's store path in ~5 k cycles whoever issues them (the
+        // four-wave kernel spends them on the step chain).  The tile is only valid between B1 and B2 (layer 1 recycles it as H1), so
+        // the wave copies its 16 quads to registers right after B1 -- 16 LDS reads -- and spreads the stores over the rest of the step,
+        // a few per barrier interval, never the last to arrive.
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int e0 = tile * EPT;
+            __syncthreads();  // tile top
+            const int wr = lane >> 4, wc = lane & 15;  // slot it: tile row wr + 4 it, quad column wc
+            // element offsets of this lane's 16 (row, quad) slots relative to the tile's first obs row / state row (a tile spans
+            // < 64 T ld floats: 32 bits always do).  Obs rows are one tile row apart: offset = o0 + it * ostep, valid below rmax live rows;
+            // the state segments are not linear in the row (env-major), their offsets are kept (-1 = nothing to store)
+            const int rmax = min(RT, (int)min((long)(a.E - e0) * A, (long)TM));
+            const int o0 = wr * T * (int)a.obs_ld + 4 * wc, ostep = 4 * T * (int)a.obs_ld;
+            const bool do_o = vo && wc < nq;
+            int so[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = wr + 4 * it, el = r / A, i = r - el * A;
+                so[it] = (r < rmax && vs && wc < ns) ? el * T * (int)a.state_ld + i * 6 * A + 4 * wc : -1;
+            }
+            float* const obase = a.obs + (long)e0 * A * T * a.obs_ld;
+            float* const sbase = a.state + (long)e0 * T * a.state_ld;
+            float4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;  // named, not an array: they live across barriers in registers
+#define CM_GET(it) v##it = *reinterpret_cast<const float4*>(Xs + (wr + 4 * (it)) * LDT + 4 * wc)
+#define CM_PUT(it) do { if (do_o && wr + 4 * (it) < rmax) *reinterpret_cast<float4*>(obase + (o0 + (it) * ostep + t * (int)a.obs_ld)) = v##it; \
+                        if (so[it] >= 0) *reinterpret_cast<float4*>(sbase + (so[it] + t * (int)a.state_ld)) = v##it; } while (0)
+            for (int t = 0; t < T; ++t) {
+                PH(8);
+                __syncthreads();  // B0
+                PH(9);
+                __syncthreads();  // B1: obs tile of step t complete
+                PH(10);
+                CM_GET(0); CM_GET(1); CM_GET(2); CM_GET(3); CM_GET(4); CM_GET(5); CM_GET(6); CM_GET(7);
+                CM_GET(8); CM_GET(9); CM_GET(10); CM_GET(11); CM_GET(12); CM_GET(13); CM_GET(14); CM_GET(15);
+                // feature widths that are not multiples of four floats: 4-byte stores in a flat (row, column) enumeration -- consecutive
+                // lanes -> consecutive addresses of a row (row = idx / width by an exact float reciprocal, idx < 2^22)
+                if (!vo) {
+                    const float inv = 1.0f / (float)din;
+                    for (int idx = lane; idx < RT * din; idx += 64) {
+                        const int r = (int)(((float)idx + 0.5f) * inv), c = idx - r * din, el = r / A;
+                        if (e0 + el < a.E) obase[(long)r * T * a.obs_ld + (long)t * a.obs_ld + c] = Xs[r * LDT + c];
+                    }
+                }
+                if (!vs) {
+                    const float inv = 1.0f / (float)(6 * A);
+                    for (int idx = lane; idx < RT * 6 * A; idx += 64) {
+                        const int r = (int)(((float)idx + 0.5f) * inv), c = idx - r * 6 * A, el = r / A, i = r - el * A;
+                        if (e0 + el < a.E) sbase[((long)el * T + t) * a.state_ld + i * 6 * A + c] = Xs[r * LDT + c];
+                    }
+                }
+                CM_PUT(0); CM_PUT(1); CM_PUT(2); CM_PUT(3);
+                PH(11);
+                __syncthreads();  // B2: the LDS reads above are complete (the barrier waits for them); the tile becomes H1
+                PH(12);
+                CM_PUT(4); CM_PUT(5); CM_PUT(6); CM_PUT(7); CM_PUT(8);
+                PH(13);
+                __syncthreads();  // B3
+                CM_PUT(9); CM_PUT(10); CM_PUT(11); CM_PUT(12); CM_PUT(13); CM_PUT(14); CM_PUT(15);  // under the compute waves' head + sampling phase
+            }
+            __syncthreads();      // after the last physics update
+#undef CM_PUT
+#undef CM_GET
+        }
+        PH_FLUSH_SW;
+        return;
+    }
+    if (scorer) {
+        // ======================================= the scorer wave: team rewards, action / log-prob flushes, the sampler's uniforms
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int e0 = tile * EPT;
+            __syncthreads();  // tile top
+            const int s_el = lane / A, s_l = lane - s_el * A;
+            const bool s_live = lane < RT && e0 + s_el < a.E;
+            const unsigned long long u_gr = (unsigned long long)((a.env_offset + e0 + s_el) * A + s_l);
+            auto draw = [&](int step) {  // uniform of (row = lane, step) into slot step & 3
+                if (s_live && step < T) {
+                    const cm_u4 rnd = cm_philox4x32((uint32_t)u_gr, (uint32_t)(u_gr >> 32), (uint32_t)step, CM_STREAM_ACT,
+                                                    (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                    ubuf[(step & 3) * TM + lane] = cm_u01(rnd.x);
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) draw(q);  // steps 0..3, before the first step's barrier
+            // nearest-agent distance of landmark s_l and collisions of agent s_l from the CURRENT positions (lane = row; stable from B0 to
+            // B3 of a step): the expressions of k_rollout_spread, agents [j0, j1) per call so that the work spreads over two barrier intervals
+            float best = 3.0e38f, col = 0.0f;
+            auto partials = [&](int j0, int j1) {
+                if (lane < RT) {
+                    const float* pos = epos + s_el * 2 * A;
+                    const float lx = elm[2 * lane], ly = elm[2 * lane + 1];
+                    const float qx = pos[2 * s_l], qy = pos[2 * s_l + 1];
+                    float pxs[5], pys[5];  // requested before the first use
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { const int j = j0 + q; pxs[q] = j < j1 ? pos[2 * j] : 0.0f; pys[q] = j < j1 ? pos[2 * j + 1] : 0.0f; }
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const int j = j0 + q;
+                        if (j < j1) {
+                            const float dx = pxs[q] - lx, dy = pys[q] - ly;
+                            best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
+                            if (j > s_l) {
+                                const float cx = qx - pxs[q], cy = qy - pys[q];
+                                if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < COLLIDE) col += 1.0f;
+                            }
+                        }
+                    }
+                }
+            };
+            // the team reward of every env: the serial sums of k_rollout_spread
+            auto reward_store = [&](int t_out) {
+                if (lane < RT) { rscr[lane] = best; rscr[TM + lane] = col; }
+                best = 3.0e38f; col = 0.0f;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < EPT && e0 + lane < a.E) {
+                    float d[10], c[10];
+#pragma unroll
+                    for (int l = 0; l < 10; ++l) { d[l] = l < A ? rscr[lane * A + l] : 0.0f; c[l] = l < A ? rscr[TM + lane * A + l] : 0.0f; }
+                    float r = 0.0f;
+#pragma unroll
+                    for (int l = 0; l < 10; ++l) if (l < A) r -= d[l];
+#pragma unroll
+                    for (int l = 0; l < 10; ++l) if (l < A) r -= c[l];
+                    a.reward[(long)(e0 + lane) * T + t_out] = r;
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto flush_alog = [&](int t4, int n) {  // lane = row: actions and log-probs of steps [t4, t4 + n)
+                if (s_live) {
+                    const long o = ((long)(e0 + s_el) * A + s_l) * (long)T + t4;
+                    const float4 va = *reinterpret_cast<const float4*>(alog + lane * 4);
+                    const float4 vl = *reinterpret_cast<const float4*>(alog + (TM + lane) * 4);
+                    float* da = reinterpret_cast<float*>(a.action) + o;
+                    float* dl = a.logp + o;
+                    if (v4 && n == 4) { *reinterpret_cast<float4*>(da) = va; *reinterpret_cast<float4*>(dl) = vl; }
+                    else {
+                        if (n > 0) { da[0] = va.x; dl[0] = vl.x; }
+                        if (n > 1) { da[1] = va.y; dl[1] = vl.y; }
+                        if (n > 2) { da[2] = va.z; dl[2] = vl.z; }
+                        if (n > 3) { da[3] = va.w; dl[3] = vl.w; }
+                    }
+                }
+            };
+            const int jh = (A + 1) / 2;  // A <= 10: two halves of at most five agents
+            for (int t = 0; t < T; ++t) {
+                __syncthreads();  // B0: positions after the physics of step t-1; the logit buffer (= rscr) is idle until after B3
+                PH(14);
+                if (t > 0) partials(0, jh);
+                PH(15);
+                __syncthreads();  // B1
+                if (t > 0) {
+                    partials(jh, A);
+                    reward_store(t - 1);
+                    if ((t & 3) == 0) flush_alog(t - 4, 4);  // ring entries of steps t-4 .. t-1; slot 0 is rewritten after B3
+                }
+                __syncthreads();  // B2
+                __syncthreads();  // B3
+                draw(t + 4);      // slot t & 3 was consumed before B1 of this step; under the compute waves' head + sampling phase
+            }
+            __syncthreads();      // positions after the last physics update
+            partials(0, jh); partials(jh, A);
+            reward_store(T - 1);
+            { const int t4 = (T - 1) & ~3; flush_alog(t4, T - t4); }
+        }
+        PH_FLUSH_SC;
+        return;
+    }
+    // =============================================== the compute waves ===============================================
+    for (int i = tid; i < 16 * HP; i += NTHREADS) {
+        const int k = i / HP, c = i % HP;
+        wouts[k * WLD + c] = (c < H && k < K) ? a.params[off.Wout + k * H + c] : 0.0f;
+    }
+    for (int i = tid; i < HP; i += NTHREADS) {
+        b0s[i] = (i < H) ? a.params[off.b0 + i] : 0.0f;
+        b1s[i] = (i < H && L > 0) ? a.params[off.bl(0) + i] : 0.0f;
+    }
+    if (tid < 8) bos[tid] = (tid < K) ? a.params[off.bout + tid] : 0.0f;
+    stage_rows(W0s, a.params + off.W0, 0, H, din, 0, din);
+    if (L > 0) stage_rows(Ws, a.params + off.Wl(0), 0, H, H, 0, H);
+    const int hrow = tid >> 2, hq = tid & 3;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();  // tile top
+        if (tid < TM) {  // reset (cm_env.hip k_env_reset): thread per (env, agent) row
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            if (live) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+        const int srow = 16 * wave + lane;  // sampling: lanes 0..15 of wave w own rows 16w .. 16w+15
+        const int s_el = srow / A;
+        const bool s_live = lane < 16 && srow < RT && (e0 + s_el) < a.E;
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();  // B0
+            PH(0);
+            {   // observations of step t -> Xs: 4 lanes per row, lane hq handles entities j = hq, hq+4, ... (landmark j, other agent j, id j)
+                const int el = hrow / A, i = hrow - el * A;
+                const bool live = hrow < RT && (e0 + el) < a.E;
+                float* xr = Xs + hrow * LDT;
+                if (live) {
+                    const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
+                    const float px = pos[2 * i], py = pos[2 * i + 1];
+                    if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
+                    for (int j = hq; j < A; j += 4) {
+                        xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                        if (j != i) {
+                            const int jj = j < i ? j : j - 1;
+                            xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
+                            xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                        }
+                        if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
+                    }
+                    for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;  // MFMA chunk padding (H1 recycles this buffer)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
+                }
+            }
+            const float u_row = s_live ? ubuf[(t & 3) * TM + srow] : 0.0f;  // drawn four steps ago
+            PH(1);
+            __syncthreads();  // B1
+            PH(2);
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+            rowpar_nt_hand(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (din + 7) >> 3);
+            {
+                const float bias = b0s[32 * wn + lc];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    H0[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                }
+            }
+            PH(3);
+            __syncthreads();  // B2
+            PH(4);
+            float* HL = H0;
+            if (L > 0) {  // hidden layer; H1 aliases Xs (every reader of the obs tile is past B2)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+                rowpar_nt_hand(acc, H0 + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
+                const float bias = b1s[32 * wn + lc];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    Xs[row * LDT + 32 * wn + lc] = fmaxf(acc[g] + bias, 0.0f);
+                }
+                HL = Xs;
+            }
+            PH(5);
+            __syncthreads();  // B3
+            PH(6);
+            {   // head: logits of this wave's 16 rows on the 16x16x4 MFMA (same routine and summation order as k_mlp<M_ACT>), wave-private
+                const f32x4 lg = head_logits_mfma(HL + 16 * wave * LDT, wouts);
+                const int n = lane & 15, g4 = lane >> 4;
+                if (n < 8) {
+                    const float bias = bos[n];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * 8 + n] = lg[q] + bias;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // same-wave LDS hand-off (DS operations of one wave execute in order)
+            if (s_live) {  // Categorical sample + log_prob (the per-step kernels' routines), then this agent's physics
+                const int i = srow - s_el * A;
+                int chosen; float lpv;
+                if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + srow * 8, K, u_row, a.act_eps, &chosen, &lpv);
+                else cm_categorical_sample(ls + srow * 8, K, u_row, &chosen, &lpv);
+                (void)i;
+                const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
+                const float uy = (chosen == 3) ? -ACCEL : (chosen == 4 ? ACCEL : 0.0f);
+                const float vx = evel[2 * srow] * (1.0f - DAMP) + ux * DT;
+                const float vy = evel[2 * srow + 1] * (1.0f - DAMP) + uy * DT;
+                evel[2 * srow] = vx; evel[2 * srow + 1] = vy;
+                epos[2 * srow] += vx * DT; epos[2 * srow + 1] += vy * DT;
+                alog[srow * 4 + (t & 3)] = __builtin_bit_cast(float, chosen);   // flushed by the scorer wave every 4 steps
+                alog[(TM + srow) * 4 + (t & 3)] = lpv;
+            }
+            PH(7);
+        }
+        __syncthreads();  // after the last physics update (the scorer wave reads the final positions)
+        if (tid < RT) {   // final env state back to global (pos | vel | landmarks): nothing writes these LDS words before the next tile's reset
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            if (e < a.E) {
+                float* es = a.env_state + e * 6 * A;
+                es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+            }
+        }
+    }
+    PH_FLUSH_C;
+}
+
 }  // namespace
 
 extern "C" int cm_rollout_spread_supported(int A, int agent_ids, int hidden, int n_hidden_layers) {
@@ -1107,7 +1456,7 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
     const bool can16 = A <= TS;
     const int EPT16 = can16 ? TS / A : 1;
     const int nt16 = (E + EPT16 - 1) / EPT16;
-    const bool use16 = can16 && (forced == 16 || forced == 17 || (forced == 0 && nt16 <= 768));  // one resident wave of 16-row workgroups (3 per CU)
+    const bool use16 = can16 && (forced == 16 || forced == 17 || (forced == 0 && nt16 <= 768));  // forced: 64 = four-wave 64-row, 65 = "64s"  // one resident wave of 16-row workgroups (3 per CU)
     // at most one 16-row workgroup per CU: the store-wave form (four compute waves + writer + scorer)
     const bool use16s = use16 && (forced == 17 || (forced == 0 && nt16 <= 256));  // one six-wave workgroup per CU
     if (use16s) {
@@ -1122,6 +1471,17 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
         const int grid16 = nt16 < 768 ? nt16 : 768;  // three workgroups per CU (launch bounds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         hipLaunchKernelGGL(k_rollout_spread16, dim3(grid16), dim3(NTHREADS), lds16, (hipStream_t)stream, a);
+        CM_CHECK_LAUNCH("cm_rollout_spread");
+        return 0;
+    }
+    // the six-wave form ("64s"; default for 64-row tiles): writer + scorer waves, per-wave samplers.  Buffers whose rows are not
+    // 16-byte aligned (unpadded odd widths) stay on the four-wave kernel, whose 256 threads share the 4-byte stores
+    const bool vec64 = (a.obs_ld % 4 == 0) && (4 * ((a.din + 3) >> 2) <= a.obs_ld) && ((6 * A) % 4 == 0) && (a.state_ld % 4 == 0);
+    if (forced == 65 || (forced != 64 && vec64)) {
+        const size_t lds64s = ((size_t)TM * LDT * 2 + (size_t)HP * LDT * 2 + 16 * WLD + 2 * HP + 8 + TM * 8 + TM * 2 * 3 + 4 * TM + 2 * TM * 4) * sizeof(float);  // 81 184 B: two per CU
+        const int grid64s = ntiles < 512 ? ntiles : 512;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread64s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64s);
+        hipLaunchKernelGGL(k_rollout_spread64s, dim3(grid64s), dim3(NT_SW), lds64s, (hipStream_t)stream, a);
         CM_CHECK_LAUNCH("cm_rollout_spread");
         return 0;
     }

@@ -62,7 +62,8 @@ int cm_version(void);
  *   "mlp_forms"        auto | hand | loop      hand-ordered vs compiler-scheduled LDS reads of the fused MLP product loops
  *   "critic_schedule"  auto | fused | split    one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule
  *   "gru_tile"         auto | 64               64: the 64-row streaming GRU sweeps at any batch size
- *   "rollout_tile"     auto | 64 | 16 | 16s    tiling of the fused rollout (16s: 16-row tiles with a store wave)
+ *   "rollout_tile"     auto | 64 | 16 | 16s | 64s   tiling of the fused rollout (64 / 16: four-wave workgroups; 64s / 16s: four compute
+ *                                              waves + a writer and a scorer wave, the defaults)
  *   "mfma"             fp32 | bf16x3           GEMM arithmetic of the PPO training passes: exact fp32 MFMA, or error-compensated
  *                                              bf16 (~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8)
  * cm_set_option returns 0, or -1 for an unknown key / value; cm_get_option returns the current value's name (NULL: unknown key). */

@@ -382,7 +382,7 @@ def test_wide_actor_rollout_and_training_run_end_to_end(env_type, tmp_path, monk
     assert out["training_step"] >= 3 and "eval/ep_reward" in {t for t, _, _ in out["history"]}
 
 
-@pytest.mark.parametrize("tile", [64, 16, "16s"])
+@pytest.mark.parametrize("tile", [64, "64s", 16, "16s"])
 @pytest.mark.parametrize("E,A,T,H,L", [(37, 8, 12, 64, 1), (50, 3, 9, 64, 1), (10, 5, 6, 32, 0), (21, 9, 7, 64, 1)])
 def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L, tile, monkeypatch):
     """cm_rollout_spread (one persistent launch; every tiling: 64-row workgroup tiles, the 16-row form and its store-wave variant that
@@ -418,8 +418,8 @@ def test_fused_rollout_matches_per_step_kernels(E, A, T, H, L, tile, monkeypatch
 @pytest.mark.parametrize("eps", [0.0, 0.3])
 @pytest.mark.parametrize("E,A,T,H,L", [(37, 8, 12, 64, 1), (50, 3, 9, 64, 1), (10, 5, 6, 32, 0), (21, 9, 7, 64, 1), (3, 1, 5, 48, 1), (512, 8, 128, 64, 1)])
 def test_rollout_tilings_are_bit_identical(E, A, T, H, L, eps, monkeypatch):
-    """The tiling -- hence the env count of a GPU's shard -- never changes a trajectory: 64-row tiles, 16-row tiles and the store-wave
-    form of the 16-row tiles feed the MFMA the same k order, sample with the same serial sums and draw the same Philox words, so every
+    """The tiling -- hence the env count of a GPU's shard -- never changes a trajectory: 64-row and 16-row tiles, each as a four-wave
+    workgroup and as the six-wave form (writer + scorer waves), feed the MFMA the same k order, sample with the same serial sums and draw the same Philox words, so every
     buffer of two consecutive episodes is bit-identical (T not a multiple of 4 exercises the store wave's partial action / log-prob
     flush, 9 agents the scalar state stores (54 floats per segment), eps > 0 COMA's mixture sampler)."""
     from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
@@ -427,7 +427,7 @@ def test_rollout_tilings_are_bit_identical(E, A, T, H, L, eps, monkeypatch):
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     outs = {}
-    for tile in ("64", "16", "16s"):
+    for tile in ("64", "64s", "16", "16s"):
         monkeypatch.setenv("CM_ROLLOUT_TILE", tile)
         r = SyntheticSpreadRollout(E, A, T, seed=7, device=dev, env_offset=5)
         spec = NetSpec(r.Do, H, L, 5)
@@ -440,7 +440,7 @@ def test_rollout_tilings_are_bit_identical(E, A, T, H, L, eps, monkeypatch):
             got.append({k: getattr(b, k).clone() for k in ("obs", "state", "action", "logp", "reward")})
         got.append({"env_state": r.env_state.clone()})
         outs[tile] = got
-    for tile in ("16", "16s"):
+    for tile in ("64s", "16", "16s"):
         for ep, (x, y) in enumerate(zip(outs["64"], outs[tile])):
             for k in x:
                 assert torch.equal(x[k], y[k]), (tile, ep, k)

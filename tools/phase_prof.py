@@ -96,14 +96,17 @@ if which == "rollout":
     used = prof[(prof.sum(1) > 0)]
     ph = used.double().mean(0).cpu(); tot = float(ph.sum())
     names = ["barrier_top", "obs+reward_partials", "buffer_writes", "fwd_mlp", "head_logits(mfma)", "sample+physics"]
-    tile = os.environ.get("CM_ROLLOUT_TILE") or ("16s" if (E + 16 // A - 1) // (16 // A) <= 256 else "16" if (E + 16 // A - 1) // (16 // A) <= 768 else "64")
+    tile = os.environ.get("CM_ROLLOUT_TILE") or ("16s" if (E + 16 // A - 1) // (16 // A) <= 256 else "16" if (E + 16 // A - 1) // (16 // A) <= 768 else "64s")
     if tile == "16":
         names = ["barrier_top", "reward_partials+obs", "buffer_writes+philox", "layer0", "layer1", "head(mfma)", "sample+physics"]
+    if tile == "64s":
+        names = ["c: wait B0", "c: obs build", "c: wait B1", "c: layer 0", "c: wait B2", "c: layer 1", "c: wait B3", "c: head+sample+physics",
+                 "w: (loop)", "w: wait B0 + B1", "w: obs/state stores", "w: wait B2", "w: philox", "w: wait B3", "s: B1..B3 + wait B0", "s: reward + flush"]
     if tile == "16s":  # compute wave 0: slots 0..7, store wave: slots 8..15 (work / wait at the barrier that follows it)
         names = ["c: wait B0", "c: obs build", "c: wait B1", "c: layer 0", "c: wait B2", "c: layer 1", "c: wait B3", "c: head+sample+physics",
                  "w: (loop)", "w: wait B0", "w: philox", "w: wait B1", "w: obs/state stores", "w: wait B2 (+B3)", "-", "-"]
     print(f"rollout: {ms:.3f} ms; ticks per (tile,step) per phase ({used.shape[0]} WGs):")
-    if tile == "16s":
+    if tile in ("16s", "64s"):
         tot = float(ph[:8].sum())
     for i, n in enumerate(names):
         print(f"  {n:24s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
