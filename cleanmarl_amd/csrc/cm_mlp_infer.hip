@@ -1,5 +1,11 @@
 // cm_mlp_infer.hip -- C-ABI entry points of the forward-only MLP kernels (a3/a4/a5)
 #include "cm_mlp_wide.h"
+#ifdef CM_PHASE_PROF
+extern unsigned long long* g_prof;
+#define CM_SET_PROF(a) (a).prof = g_prof
+#else
+#define CM_SET_PROF(a)
+#endif
 
 static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                           const float* params, const uint8_t* avail, float* y, cm_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
@@ -140,6 +146,7 @@ extern "C" int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint
     a.seed = seed; a.row_offset = row_offset; a.t = 0; a.t_decode = T; a.action_out = action; a.logp_out = logp; a.out_stride = 1;
     prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    CM_SET_PROF(a);
     launch_infer<M_ACT>(a, grid_for(a.rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_episode");
     return 0;

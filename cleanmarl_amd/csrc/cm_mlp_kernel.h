@@ -124,6 +124,65 @@ __device__ __forceinline__ float quad_xor2(float v) {
 }
 __device__ __forceinline__ float quad_sum(float v) { v += quad_xor1(v); v += quad_xor2(v); return v; }
 __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, quad_xor1(v)); v = fmaxf(v, quad_xor2(v)); return v; }
+__device__ __forceinline__ float quad_shr1(float v) {  // lane h of a quad <- lane h - 1 (lane 0 keeps its own)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_bcast3(float v) {  // every lane of a quad <- lane 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xFF, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int quad_imin(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true)); return min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int quad_imax(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true)); return max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+}
+
+// cm_categorical_sample for K > 8 on the FOUR lanes of a row (lane hq holds the masked logits of actions k = 4 j + hq in z[j]): the same
+// operations in the same order -- s = e_0 + e_1 + ... left to right (one exp per action), the first available action whose running sum
+// exceeds u * s, log_prob = z[a] - (max + log s) -- with the running sum handed from lane to lane inside the quad (DPP), so that a
+// lane evaluates K / 4 exponentials instead of one lane 2 K (cm_common.h sums twice for K > 8).  An unavailable action adds exactly 0,
+// so the running sum over all actions equals the serial sum over the available ones at every available k.  Every lane returns the row's
+// result.  (Config 4's act pass spent 41 % of its time in the one-lane sampler: profiles/r03_phase_act.txt.)
+template <int KJ>
+__device__ __forceinline__ void quad_categorical_sample(const float (&z)[KJ], int K, int hq, float u, int* action, float* logp) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, z[j]);
+    m = quad_max(m);
+    float pre[KJ];
+    float run = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        pre[j] = run;
+        if (4 * j < K) {  // wave-uniform: blocks beyond the last action are skipped
+            const float e = (4 * j + hq < K) ? expf(z[j] - m) : 0.0f;
+            float p = run + e;                         // lane 0 of the quad
+            float q = quad_shr1(p); if (hq == 1) p = q + e;
+            q = quad_shr1(p); if (hq == 2) p = q + e;
+            q = quad_shr1(p); if (hq == 3) p = q + e;
+            pre[j] = p;                                // inclusive running sum at action 4 j + hq
+            run = quad_bcast3(p);
+        }
+    }
+    const float s = run, thr = u * s;
+    int first = 1 << 20, last = 0;
+#pragma unroll
+    for (int j = KJ - 1; j >= 0; --j) {
+        const int k = 4 * j + hq;
+        if (k < K && z[j] > -5e8f) {
+            if (thr < pre[j]) first = k;
+            if (last == 0) last = k;                   // descending j: the largest available k of this lane comes first
+        }
+    }
+    first = quad_imin(first); last = quad_imax(last);
+    const int chosen = first < (1 << 20) ? first : last;
+    float zc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) if (4 * j + hq == chosen) zc = z[j];
+    zc = quad_max(zc);
+    *action = chosen;
+    *logp = zc - (m + logf(s));
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -761,21 +820,36 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             for (int j = 0; j < KJ; ++j)
                 if (rvalid && 4 * j + hq < dout) a.y[(long)grow * dout + 4 * j + hq] = zreg[j];
         }
-        if (MODE == M_ACT) {
+        // K > 8 heads (KJ == 8) sample on the four lanes of the row, straight from registers; the one-lane samplers (K <= 8: bit-identical to
+        // the fused rollouts; COMA's mixture; greedy) read the masked logits back from LDS
+        const bool quad_sampler = (MODE == M_ACT) && KJ == 8 && a.act_eps == 0.0f;
+        if (MODE == M_ACT && !quad_sampler) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j)
                 if (4 * j + hq < dout) ls[hrow * lstride + 4 * j + hq] = zreg[j];
         }
         if (MODE == M_FWD) continue;  // next tile (the loop-top barrier protects LDS reuse)
-        if (MODE == M_ACT) __syncthreads();
+        if (MODE == M_ACT && !quad_sampler) __syncthreads();
         PH(3);
 
-        // ================= per-row head math: lane hq == 0 of every row =================
+        // ================= per-row head math =================
         if (MODE == M_ACT) {
-            if (hq == 0 && rvalid) {
-                const int seq = a.t_decode > 0 ? grow / a.t_decode : grow;
-                const int tt = a.t_decode > 0 ? grow - seq * a.t_decode : a.t;
-                const unsigned long long gr = (unsigned long long)(a.row_offset + seq);
+            const int seq = a.t_decode > 0 ? grow / a.t_decode : grow;
+            const int tt = a.t_decode > 0 ? grow - seq * a.t_decode : a.t;
+            const unsigned long long gr = (unsigned long long)(a.row_offset + seq);
+            if (quad_sampler) {
+                if constexpr (KJ == 8) {
+                    // every lane of the quad draws the row's uniform (same instruction count as one lane of four)
+                    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)tt, CM_STREAM_ACT,
+                                                    (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                    int chosen; float lp;
+                    quad_categorical_sample<KJ>(zreg, dout, hq, cm_u01(rnd.x), &chosen, &lp);
+                    if (hq == 0 && rvalid) {
+                        a.action_out[(long)grow * a.out_stride] = chosen;
+                        a.logp_out[(long)grow * a.out_stride] = lp;
+                    }
+                }
+            } else if (hq == 0 && rvalid) {
                 const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)tt, CM_STREAM_ACT,
                                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
                 int chosen; float lp;
@@ -785,6 +859,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 a.action_out[(long)grow * a.out_stride] = chosen;
                 a.logp_out[(long)grow * a.out_stride] = lp;
             }
+            PH(4);
             continue;
         }
 

@@ -54,6 +54,18 @@ elif which == "gru":  # one TBPTT chunk of config 5 through the second-generatio
     h0 = torch.zeros(E * A, 64, device=dev); h1 = torch.zeros(E * A, 64, device=dev)
     run = lambda: N.check(lib.cm_gru_actor_chunk_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lp), N.ptr(adv), N.ptr(ep_len), E, A, T, 10, 20, Do,
                                                         64, K, N.ptr(p), N.ptr(h0), N.ptr(h1), 0.2, 1e-3, N.ptr(g), N.ptr(ws), ws.numel(), s), "gru chunk")
+elif which == "act":  # the whole-episode act pass of config 4 (cm_policy_act_episode_ld: 115-wide obs padded to 116, 17 actions, avail masks)
+    E, A, T, K = 2048, 10, 256, 17
+    Do, ld = 115, 116
+    spec = NetSpec(Do, 64, 1, K)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    obs = torch.zeros(E, A, T, ld, device=dev); obs[..., :Do] = torch.randn(E, A, T, Do, device=dev)
+    avail = (torch.rand(E, A, T, K, device=dev) < 0.7).to(torch.uint8); avail[..., 0] = 1
+    act = torch.zeros(E, A, T, dtype=torch.int32, device=dev); lp = torch.zeros(E, A, T, device=dev)
+    w0b = lib.cm_w0_image_bytes(Do, 64)
+    w0 = torch.empty(max(16, w0b), dtype=torch.uint8, device=dev)
+    run = lambda: N.check(lib.cm_policy_act_episode_ld(N.ptr(obs), ld, N.ptr(avail), E * A, T, Do, 64, 1, K, N.ptr(p), 7, 0, N.ptr(act), N.ptr(lp),
+                                                      N.ptr(w0), w0b, s), "act")
 elif which == "rollout":
     from cleanmarl_amd.rollout import SyntheticSpreadRollout
     prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
@@ -121,7 +133,9 @@ if which == "critic" and os.environ.get("CM_CRITIC_SCHEDULE") != "split" and 128
     print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
     sys.exit(0)
 names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
-rows = (E * A * T) if which == "actor" else E * T
+if which == "act":
+    names = ["stage x / W0 chunks + MFMAs of chunk 0", "fwd_L0 (last chunk) + epilogue", "fwd_hidden", "head_logits + mask", "philox + sampler + stores"]
+rows = (E * A * T) if which in ("actor", "act") else E * T
 tiles_per_wg = rows / 64 / 512  # two workgroups per CU
 print(f"{which}: {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks (100 MHz const clock?) per tile:")
 for i, n in enumerate(names):
