@@ -88,6 +88,14 @@ SIGNATURES = {
     "cm_ppo_actor_train_step_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _d, _p, _p, _sz, _po, _p]),
     "cm_critic_train_step_ld": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _po, _p]),
     "cm_gru_actor_chunk_train_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _d, _d, _p, _p, _sz, _po, _p]),
+    "cm_peer_handle_bytes": (_sz, []),
+    "cm_peer_mailbox_bytes": (_sz, [_i, _l]),
+    "cm_peer_mailbox_alloc": (_i, [_sz, C.POINTER(_p), _p]),
+    "cm_peer_mailbox_open": (_i, [_p, C.POINTER(_p)]),
+    "cm_peer_mailbox_close": (_i, [_p]),
+    "cm_peer_mailbox_free": (_i, [_p]),
+    "cm_peer_push": (_i, [_p, _l, _i, _i, C.POINTER(_p), C.c_uint32, _p]),
+    "cm_optimizer_step_peer": (_i, [_p, _l, _p, _i, C.c_uint32, _po, _p]),
     "cm_gru_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "cm_gru_actor_chunk_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _d, _d,
                                         _p, _p, _sz, _p]),

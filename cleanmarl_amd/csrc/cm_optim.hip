@@ -56,10 +56,12 @@ struct StepArgs {
     float* g; float* params; float* m; float* v;
     float lr, bc1, beta1, beta2, eps, wd, grad_scale, bc2_sqrt; int kind;
     float* out_norm; unsigned long long* nword; unsigned long long* slots; unsigned tag;
+    const unsigned long long* peer_tags; unsigned peer_seq;
 };
 
 // sum of column i over the np partial rows, in the order of k_reduce_partials: row group g takes rows g, g + 16, g + 32, ... into two
 // alternating accumulators.  All loads of a batch of rows are issued before the first add (the loop of k_reduce_partials keeps two in flight).
+template <bool PEER = false>
 __device__ __forceinline__ float step_colsum(const float* __restrict__ p, int np, int PS, int i, int g) {
     // STEP_BATCH loads in flight per thread (16 waves per workgroup keep the memory pipe busy); a larger batch only costs registers, and a
     // 1024-thread workgroup at > 64 registers per lane no longer fits beside the critic's persistent workgroups on the other stream
@@ -71,7 +73,8 @@ __device__ __forceinline__ float step_colsum(const float* __restrict__ p, int np
 #pragma unroll
         for (int k = 0; k < STEP_BATCH; ++k) {
             const int w = w0 + k * STEP_GROUPS;
-            v[k] = (w < np) ? p[(size_t)w * PS + i] : 0.0f;
+            v[k] = 0.0f;
+            if (w < np) v[k] = PEER ? __hip_atomic_load(p + (size_t)w * PS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : p[(size_t)w * PS + i];
         }
 #pragma unroll
         for (int k = 0; k < STEP_BATCH; k += 2) { s0 += v[k]; s1 += v[k + 1]; }
@@ -99,15 +102,21 @@ __device__ __forceinline__ float step_wait(const unsigned long long* p, unsigned
     return __uint_as_float((unsigned)w);
 }
 
-template <bool UPDATE>
+template <bool UPDATE, bool PEER = false>
 __global__ __launch_bounds__(STEP_COLS * STEP_GROUPS) void k_reduce_step(const StepArgs a) {
     __shared__ float sh[STEP_GROUPS][STEP_COLS];
     const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;
+    if (PEER) {  // the partial rows are mailbox slots: wait until every rank has published this step's (cm_peer.hip)
+        if (threadIdx.x < a.np1)
+            while (__hip_atomic_load(a.peer_tags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)a.peer_seq)
+                __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+    }
     const int icnt = a.n + CM_STAT_COUNT, slab_n = icnt / STEP_COLS;
     const int slab = blockIdx.x == 0 ? slab_n : ((int)blockIdx.x <= slab_n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
     const int i = slab * STEP_COLS + c;
     float s = 0.f;
-    if (i < a.ntot) s = (i < a.isplit) ? step_colsum(a.part2, a.np2, a.PS2, i, g) : step_colsum(a.part1, a.np1, a.PS1, i, g);
+    if (i < a.ntot) s = (i < a.isplit) ? step_colsum(a.part2, a.np2, a.PS2, i, g) : step_colsum<PEER>(a.part1, a.np1, a.PS1, i, g);
     sh[g][c] = s;
     __syncthreads();
     if (g != 0) return;  // wave 0 finishes its 64 columns
@@ -290,11 +299,13 @@ extern "C" size_t cm_opt_step_scratch_bytes(void) { return STEP_SCRATCH_BYTES; }
 
 // [part1 | part2] partial rows -> grad_and_stats + optimiser step.  part2 == NULL: every column comes from part1.
 int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
-                          float* grad_and_stats, const cm_opt_step_t* o, hipStream_t s, const char* who) {
+                          float* grad_and_stats, const cm_opt_step_t* o, hipStream_t s, const char* who,
+                          const unsigned long long* peer_tags, unsigned peer_seq) {
     if (int rc = opt_check(who, n_params, o)) return rc;
     const int64_t ntot = n_params + CM_NUM_STATS;
     const int grid = (int)((ntot + STEP_COLS - 1) / STEP_COLS);
     const double bc1 = 1.0 - pow(o->beta1, (double)o->step), bc2 = 1.0 - pow(o->beta2, (double)o->step);
+    CM_REQUIRE(!peer_tags || (grid <= STEP_MAX_WG && o->scratch), "%s: the peer step needs the fused launch (<= %d parameters, a scratch)", who, STEP_MAX_WG * STEP_COLS);
     if (grid > STEP_MAX_WG || !o->scratch) {
         // beyond the scratch's sumsq slots (or no scratch): plain reduction + the stand-alone step
         hipLaunchKernelGGL(k_reduce_cols, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, part1, np1, PS1, part2, np2, PS2, isplit, (int)ntot, grad_and_stats);
@@ -311,13 +322,16 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
     a.wd = (float)o->weight_decay; a.grad_scale = (float)o->grad_scale; a.bc2_sqrt = (float)sqrt(bc2); a.kind = o->opt_kind;
     a.out_norm = o->out_norm; a.nword = (unsigned long long*)o->scratch; a.slots = a.nword + 8;
     a.tag = next_step_tag();
+    a.peer_tags = peer_tags; a.peer_seq = peer_seq;
     if (o->max_norm > 0.0) {
-        hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<false, true>), dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        else hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
         const int ugrid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(ugrid), dim3(UPD_THREADS), 0, s, o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq,
                            (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm);
     } else {
-        hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<true, true>), dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        else hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
     }
     CM_CHECK_LAUNCH(who);
     return 0;

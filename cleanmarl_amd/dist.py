@@ -4,6 +4,8 @@ loss terms being masked SUMS divided by N = b_mask.sum() (cleanmarl/mappo_multie
 per-shard un-normalised gradient/statistic buffers and dividing by the global N reproduces the single-device
 step exactly (up to fp32 re-association).  These helpers are device-agnostic (RCCL on GPUs, gloo in CPU tests).
 """
+import os
+
 import torch
 
 
@@ -38,3 +40,59 @@ def merge_moments_(mom, pg=None, world=1):
         m2 = sum(p[2] + p[0] * (p[1] - mean) ** 2 for p in parts)
         mom.copy_(torch.stack([n, mean, m2]))
     return mom
+
+
+class PeerAllReduce:
+    """One-shot peer all-reduce + optimiser step over hipIpc-mapped mailboxes (csrc/cm_peer.hip, include/cleanmarl_hip.h): the
+    data-path replacement of `all_reduce(buf); optimiser step` for ONE gradient buffer of `n_floats` floats.  torch.distributed is used
+    once, at construction, to exchange the mailbox handles (control plane); afterwards a step is two launches on the caller's stream
+    and no library call.  One instance per network (the critic's steps run on their own stream)."""
+
+    def __init__(self, n_floats, process_group=None):
+        import ctypes as C
+        from . import _native as N
+        self.lib = lib = N.load()
+        self.pg = process_group
+        self.rank = torch.distributed.get_rank(process_group)
+        self.world = torch.distributed.get_world_size(process_group)
+        if self.world > 16:
+            raise N.NativeError("PeerAllReduce: at most 16 ranks")
+        self.n = int(n_floats)
+        nbytes = lib.cm_peer_mailbox_bytes(self.world, self.n)
+        own, handle = C.c_void_p(), C.create_string_buffer(lib.cm_peer_handle_bytes())
+        N.check(lib.cm_peer_mailbox_alloc(nbytes, C.byref(own), handle), "cm_peer_mailbox_alloc")
+        self.own = own
+        handles = [None] * self.world
+        torch.distributed.all_gather_object(handles, (os.getpid(), handle.raw), group=process_group)
+        self.boxes = (C.c_void_p * self.world)()
+        self._opened = []
+        for r, (pid, raw) in enumerate(handles):
+            if r == self.rank:
+                self.boxes[r] = own
+            else:
+                p = C.c_void_p()
+                N.check(lib.cm_peer_mailbox_open(C.create_string_buffer(raw, len(raw)), C.byref(p)), f"cm_peer_mailbox_open(rank {r})")
+                self.boxes[r] = p
+                self._opened.append(p)
+        self.seq = 0
+        torch.distributed.barrier(group=process_group)  # every mailbox is mapped everywhere before the first push
+
+    def step(self, buf, n_params, opt_step, stream_ptr):
+        """push `buf` ([n_params + 8] floats) to every mailbox, then the fused fold + optimiser step on the own mailbox."""
+        from . import _native as N
+        self.seq += 1
+        N.check(self.lib.cm_peer_push(N.ptr(buf), self.n, self.rank, self.world, self.boxes, self.seq, stream_ptr), "cm_peer_push")
+        N.check(self.lib.cm_optimizer_step_peer(N.ptr(buf), n_params, self.own, self.world, self.seq, opt_step, stream_ptr),
+                "cm_optimizer_step_peer")
+
+    def close(self):
+        """Unmap the peers' mailboxes and free the own one -- after a barrier: nobody may still push into a freed mailbox."""
+        torch.cuda.synchronize()
+        torch.distributed.barrier(group=self.pg)
+        for p in self._opened:
+            self.lib.cm_peer_mailbox_close(p)
+        self._opened = []
+        torch.distributed.barrier(group=self.pg)
+        if self.own is not None:
+            self.lib.cm_peer_mailbox_free(self.own)
+            self.own = None

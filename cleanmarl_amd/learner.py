@@ -279,6 +279,12 @@ class PPOLearner:
         if self._coll and torch.distributed.is_initialized():
             ranks = torch.distributed.get_process_group_ranks(process_group if process_group is not None else torch.distributed.group.WORLD)
             self.pg_c = torch.distributed.new_group(ranks=ranks)
+        # CM_PEER_ALLREDUCE=1 (opt-in; default: RCCL all-reduce): the [gradient | statistics] exchange of the MLP learner as a one-shot
+        # peer all-reduce over hipIpc-mapped mailboxes fused with the optimiser step (dist.PeerAllReduce, csrc/cm_peer.hip)
+        self.peer_a = self.peer_c = None
+        if self._coll and world_size > 1 and os.environ.get("CM_PEER_ALLREDUCE") == "1" and type(self) is PPOLearner:
+            self.peer_a = dist.PeerAllReduce(Pa + N.NUM_STATS, process_group)
+            self.peer_c = dist.PeerAllReduce(Pc + N.NUM_STATS, process_group)
         self.global_envs = None  # env count of the WHOLE run (driver / bench set it): the schedule choice must not depend on the local shard
         self._sched_rows = {}
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
@@ -489,9 +495,12 @@ class PPOLearner:
                 if keep_grads:
                     kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
                 return
-            if wa is not None:
-                wa.wait()
-            self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
+            if self.peer_a is not None:
+                self.peer_a.step(g_actor, Pa, self.opt_a.next_step(self.actor, rec[ep, 2 * N.NUM_STATS:], hp.clip_gradients), s)
+            else:
+                if wa is not None:
+                    wa.wait()
+                self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
             if keep_grads:
                 kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
 
@@ -501,9 +510,12 @@ class PPOLearner:
                 if keep_grads:
                     kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
                 return
-            if wc is not None:
-                wc.wait()
-            self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
+            if self.peer_c is not None:
+                self.peer_c.step(g_critic, Pc, self.opt_c.next_step(self.critic, rec[ep, 2 * N.NUM_STATS + 1:], hp.clip_gradients), sc)
+            else:
+                if wc is not None:
+                    wc.wait()
+                self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
             if keep_grads:
                 kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
 
@@ -512,11 +524,11 @@ class PPOLearner:
             for ep in range(nE0):
                 g = self.gbuf_rows[ep]
                 self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS], rec[ep, 2 * N.NUM_STATS:] if ride else None)
-                wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if self._coll else None
+                wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if (self._coll and self.peer_a is None) else None
                 if pending is not None:
                     critic_step(*pending, s)
                 self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:], rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
-                wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if self._coll else None
+                wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if (self._coll and self.peer_c is None) else None
                 actor_step(ep, wa)
                 if self._coll:
                     pending = (ep, wc)
@@ -536,7 +548,7 @@ class PPOLearner:
             def actor_epoch(ep):
                 g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
                 self._timed("actor", self.actor_pass, b, s, g_actor, rec[ep, 2 * N.NUM_STATS:] if ride else None)
-                actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if self._coll else None)
+                actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if (self._coll and self.peer_a is None) else None)
 
             def critic_epoch(ep):
                 with torch.cuda.stream(side):
@@ -546,7 +558,7 @@ class PPOLearner:
                         self._c0.record()
                     g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
                     self._timed("critic", self.critic_pass, b, sc, g_critic, rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
-                    critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if self._coll else None, sc)
+                    critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if (self._coll and self.peer_c is None) else None, sc)
                     if ep == nE0 - 1:
                         rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
                         if timed:

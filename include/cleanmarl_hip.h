@@ -215,6 +215,26 @@ int cm_critic_train_step_ld(const float* x, int64_t x_ld, const float* ret, cons
                             int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                             float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream);
 
+/* ---- one-shot peer all-reduce of the [gradient | statistics] buffer (csrc/cm_peer.hip) ----
+ * The exchange step of an env-sharded run without a collective library on the data path: every rank owns a MAILBOX (fine-grained device
+ * memory; 2 x world slots of n floats + one tag word each) that its peers map with hipIpc.  Per optimiser step a rank
+ *   1. reduces its pass's partials into grad_and_stats as usual (cm_*_fwd_bwd*),
+ *   2. cm_peer_push: copies that buffer into slot [seq & 1][rank] of EVERY mailbox and then publishes the slot's tag {seq},
+ *   3. cm_optimizer_step_peer: one launch that waits for the `world` tags of its OWN mailbox, folds the slots in rank order (every rank
+ *      the same order: bit-identical parameters everywhere), scales by grad_scale / N, takes the norm and applies the update.
+ * seq: 1, 2, 3, ... per mailbox, the same on every rank (two slot sets alternate by its parity; a peer is never more than one step
+ * ahead).  Setup (once): cm_peer_mailbox_alloc -> exchange the cm_peer_handle_bytes() handle bytes by any means (torch.distributed
+ * all_gather_object in cleanmarl_amd/dist.py) -> cm_peer_mailbox_open per peer.  At most 16 ranks; ranks may share a device. */
+size_t cm_peer_handle_bytes(void);
+size_t cm_peer_mailbox_bytes(int world, int64_t n_floats);
+int cm_peer_mailbox_alloc(size_t bytes, void** mailbox, void* handle_out);
+int cm_peer_mailbox_open(const void* handle, void** mailbox);
+int cm_peer_mailbox_close(void* mailbox);
+int cm_peer_mailbox_free(void* mailbox);
+int cm_peer_push(const float* buf, int64_t n_floats, int rank, int world, void* const* mailboxes, uint32_t seq, cm_stream_t stream);
+int cm_optimizer_step_peer(float* grad_and_stats, int64_t n_params, void* own_mailbox, int world, uint32_t seq,
+                           const cm_opt_step_t* opt, cm_stream_t stream);
+
 /* ---- a13 / a14: GRU actor, TBPTT chunk  (cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620) ----
  * Forward + backward-through-time over steps [t0, t1) for all E*A sequences starting from the detached
  * hidden state h_in[E*A][H]; writes h_out (= h at t1, to be used detached for the next chunk) and the

@@ -88,6 +88,71 @@ def test_two_ranks_reproduce_the_single_process_reference(golden_dir, tmp_path, 
         assert torch.equal(got[0]["recs"][e]["critic_after"], got[1]["recs"][e]["critic_after"])
 
 
+def _worker_peer(rank, world, port, gold, algo, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["CM_PEER_ALLREDUCE"] = "1"
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)  # control plane only: the gradients never touch it
+    from oracle import restatement as R
+    from cleanmarl_amd import dist
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner
+    batch, ap, cp, hp, z = R.load_golden(gold)
+    dev = torch.device("cuda:0")
+    reward = torch.from_numpy(z["b_reward_raw"]) if "b_reward_raw" in z.files else batch["reward"]
+    lo, n = dist.shard(batch["obs"].shape[0], rank, world)
+    sl = slice(lo, lo + n)
+    H = HParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
+                normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
+                epochs=int(hp["epochs"]), ppo_clip=hp["ppo_clip"], entropy_coef=hp["entropy_coef"],
+                clip_gradients=hp["clip_gradients"], optimizer=hp["optimizer"],
+                learning_rate_actor=hp["learning_rate_actor"], learning_rate_critic=hp["learning_rate_critic"])
+    aspec = NetSpec(ap[0].shape[1], ap[0].shape[0], len(ap) // 2 - 2, ap[-1].shape[0])
+    cspec = NetSpec(cp[0].shape[1], cp[0].shape[0], len(cp) // 2 - 2, 1)
+    res = {}
+    for sched in ("0", "1", "2"):
+        os.environ["CM_CRITIC_OVERLAP"] = sched
+        b = DeviceBatch.from_reference_layout(batch["obs"][sl], batch["actions"][sl], batch["log_probs"][sl], reward[sl],
+                                              batch["states"][sl], batch["avail"][sl], batch["mask"][sl], dev, pad=True)
+        L = PPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=[p.clone() for p in ap],
+                       critic_params=[p.clone() for p in cp], process_group=torch.distributed.group.WORLD, world_size=world)
+        assert L.peer_a is not None and L.peer_c is not None
+        recs = [dict(r) for r in L.train_iteration(b)]
+        more = [dict(r) for r in L.train_iteration(b)]  # a second iteration: the slot sets alternate, the tags keep counting
+        L.wait_critic()
+        torch.cuda.synchronize()
+        res[sched] = dict(recs=recs, more=more, actor=L.actor.cpu(), critic=L.critic.cpu(), seq=(L.peer_a.seq, L.peer_c.seq))
+        L.peer_a.close(); L.peer_c.close()
+    torch.save(res, f"{out}.{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,algo", [("mappo_ragged_norm", "mappo"), ("ippo_dense", "ippo")])
+def test_peer_allreduce_two_processes_share_one_gpu(golden_dir, tmp_path, name, algo):
+    """The one-shot peer all-reduce (csrc/cm_peer.hip; opt-in CM_PEER_ALLREDUCE=1): two processes on cuda:0 map each other's mailboxes
+    with hipIpc, push their halves of the reference batch's gradient sums and step from the slots in rank order -- no all-reduce call on
+    the data path.  The FIRST iteration must match the unmodified single-process reference per epoch, both ranks must hold bit-identical
+    parameters after two iterations, for the one-stream and both two-stream schedules (actor and critic mailboxes on two streams)."""
+    world, port, out = 2, _free_port(), str(tmp_path / "peer")
+    gold = os.path.join(golden_dir, name + ".npz")
+    mp.spawn(_worker_peer, args=(world, port, gold, algo, out), nprocs=world, join=True)
+    z = np.load(gold)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    nE = len(z["actor_losses"])
+    for g in got:
+        for sched, r in g.items():
+            assert r["seq"] == (2 * nE, 2 * nE)
+            for e, rec in enumerate(r["recs"]):
+                assert _err(rec["actor_loss"], z["actor_losses"][e]) <= TOL and _err(rec["critic_loss"], z["critic_losses"][e]) <= TOL, sched
+                assert _err(rec["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(rec["critic_gnorm"], z["critic_gradients"][e]) <= TOL, sched
+                assert _err(rec["entropy"], z["entropies_bonuses"][e]) <= TOL and _err(rec["kl"], z["kl_divergences"][e]) <= TOL, sched
+    for sched in ("0", "1", "2"):
+        assert torch.equal(got[0][sched]["actor"], got[1][sched]["actor"]) and torch.equal(got[0][sched]["critic"], got[1][sched]["critic"]), sched
+        assert torch.equal(got[0]["0"]["actor"], got[0][sched]["actor"]) and torch.equal(got[0]["0"]["critic"], got[0][sched]["critic"]), sched
+
+
 def test_bench_two_rank_launch_on_one_gpu():
     """bench.py's N > 1 branch (rendezvous, env_offset sharding, barriers, MAX-over-ranks timing, rank-0 JSON line)
     launched exactly as the driver launches it, but over gloo with both ranks on cuda:0 (CM_BENCH_BACKEND test hook)."""
