@@ -256,7 +256,8 @@ def main():
             "metric": "env-steps/sec (agents x envs x steps), MAPPO full iteration", "value": units / r["dt"],
             "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if N.load().cm_mfma_mode() == 0 else "bf16x3 (opt-in CM_MFMA=bf16x3: error-compensated bf16 MFMA products, fp32 accumulate and storage)",
+            "dtype": {0: "f32", 1: "bf16x3 (opt-in CM_MFMA=bf16x3: error-compensated bf16 MFMA products, fp32 accumulate and storage)",
+                      2: "bf16 (opt-in CM_MFMA=bf16: single-pass bf16 MFMA products in the training passes, fp32 accumulate and storage; looser parity tier)"}[N.load().cm_mfma_mode()],
             "data": "synthetic",
             "config": {"workload": desc, "global_envs": total_envs, "envs_per_gpu": E, "agents": A, "steps": T, "epochs": hp.epochs,
                        "parallelism": f"env-sharded x{world} ({args.scaling} scaling), one all-reduce per network and optimiser step"},

@@ -23,10 +23,10 @@ const char* const kFormsN[] = {"auto", "hand", "loop"};          const int kForm
 const char* const kCriticN[] = {"auto", "fused", "split"};       const int kCriticV[] = {0, 1, 2};
 const char* const kGruN[] = {"auto", "64"};                      const int kGruV[] = {0, 64};
 const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRollV[] = {0, 64, 16, 17, 65};
-const char* const kMfmaN[] = {"fp32", "bf16x3"};                 const int kMfmaV[] = {0, 1};
+const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};
 const OptDef kOpts[CM_OPTION_COUNT] = {
     {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 3}, {"gru_tile", kGruN, kGruV, 2},
-    {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 2}};
+    {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}};
 std::atomic<int> g_opt[CM_OPTION_COUNT];  // zero-initialised: every option starts at its first value
 }  // namespace
 
@@ -52,7 +52,7 @@ extern "C" const char* cm_get_option(const char* key) {
     return nullptr;
 }
 
-// 0 = exact fp32 MFMA (default), 1 = option mfma=bf16x3 (error-compensated bf16 GEMM loops in the PPO training passes)
+// 0 = exact fp32 MFMA (default), 1 = option mfma=bf16x3 (error-compensated bf16 GEMM loops in the PPO training passes), 2 = mfma=bf16 (single pass)
 extern "C" int cm_mfma_mode(void) { return cm_option(CM_OPTION_MFMA); }
 
 extern "C" int64_t cm_mlp_param_count(int din, int hidden, int n_hidden_layers, int dout) {

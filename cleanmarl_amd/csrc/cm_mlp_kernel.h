@@ -403,12 +403,17 @@ __device__ __forceinline__ void frag_split(const unsigned (&w)[8], FragBF& hi, F
         lo.u[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x05040100u);
     }
 }
+// ONE: single-pass bf16 (option mfma=bf16: the hi halves only -- one MFMA per product, ~2^-8 relative operand rounding, fp32 accumulate;
+// its own, looser parity tier, tests/test_hip_parity.py) instead of the error-compensated three
+template <bool ONE = false>
 __device__ __forceinline__ f32x16 mfma_bf3(const unsigned (&aw)[8], const unsigned (&bw)[8], f32x16 acc) {
     FragBF ahi, alo, bhi, blo;
     frag_split(aw, ahi, alo);
     frag_split(bw, bhi, blo);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo.b, bhi.b, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi.b, blo.b, acc, 0, 0, 0);
+    if (!ONE) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo.b, bhi.b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi.b, blo.b, acc, 0, 0, 0);
+    }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi.b, bhi.b, acc, 0, 0, 0);
     return acc;
 }
@@ -422,6 +427,7 @@ __device__ __forceinline__ void ld8s(unsigned (&w)[8], const float* p, int strid
 }
 // split-word twins of rowpar_nt / rowpar_tn / colred: k (or the contracted row index) is consumed 16 at a time, lane half h
 // owning elements [16j + 8h, 16j + 8h + 8) of BOTH operands
+template <bool ONE = false>
 __device__ __forceinline__ void rowpar_nt_bf(f32x16& acc, const float* As, const float* Bs, int k16) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float* ap = As + r * LDT + 8 * h;
@@ -430,9 +436,10 @@ __device__ __forceinline__ void rowpar_nt_bf(f32x16& acc, const float* As, const
         unsigned aw[8], bw[8];
         ld8(aw, ap + 16 * j);
         ld8(bw, bp + 16 * j);
-        acc = mfma_bf3(aw, bw, acc);
+        acc = mfma_bf3<ONE>(aw, bw, acc);
     }
 }
+template <bool ONE = false>
 __device__ __forceinline__ void rowpar_tn_bf(f32x16& acc, const float* As, const float* Ws_c0) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float* ap = As + r * LDT + 8 * h;
@@ -442,9 +449,10 @@ __device__ __forceinline__ void rowpar_tn_bf(f32x16& acc, const float* As, const
         unsigned aw[8], bw[8];
         ld8(aw, ap + 16 * j);
         ld8s(bw, bp + 16 * j * LDT, LDT);
-        acc = mfma_bf3(aw, bw, acc);
+        acc = mfma_bf3<ONE>(aw, bw, acc);
     }
 }
+template <bool ONE = false>
 __device__ __forceinline__ void colred_bf(f32x16& acc, const float* Zs_n0, const float* Xs_k0) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float* ap = Zs_n0 + (8 * h) * LDT + r;
@@ -454,7 +462,7 @@ __device__ __forceinline__ void colred_bf(f32x16& acc, const float* Zs_n0, const
         unsigned aw[8], bw[8];
         ld8s(aw, ap + 16 * j * LDT, LDT);
         ld8s(bw, bp + 16 * j * LDT, LDT);
-        acc = mfma_bf3(aw, bw, acc);
+        acc = mfma_bf3<ONE>(aw, bw, acc);
     }
 }
 
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             __syncthreads();
             PH(0);
             const int w = min(KC, din - c * KC);
-            if (BF) rowpar_nt_bf(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);
+            if (BF) rowpar_nt_bf<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);  // BF instantiations: HAND = single-pass bf16
             else rowpar_nt_sel<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
         }
         {
@@ -779,7 +787,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 }
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-                if (BF) rowpar_nt_bf(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 16);
+                if (BF) rowpar_nt_bf<HAND>(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 16);
                 else rowpar_nt_sel<HAND>(acc, smem + lds.Hs(l - 1) + 32 * wm * LDT, Ws + 32 * wn * LDT, HP / 8);
                 float* Hl = smem + lds.Hs(l);
                 const float bias = smem[lds.bl(l - 1) + 32 * wn + lc];
@@ -1068,11 +1076,11 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         for (int r = 0; r < TM / 4; ++r) s += dec<BF>(Zl[(part * (TM / 4) + r) * LDT + c]);
                         dbh[l] += s;
                     }
-                    if (BF) colred_bf(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
+                    if (BF) colred_bf<HAND>(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
                     else colred_sel<HAND>(accWl[l - 1], Zl + 32 * wm, Hm + 32 * wn);
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-                    if (BF) rowpar_tn_bf(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
+                    if (BF) rowpar_tn_bf<HAND>(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
                     else rowpar_tn_sel<HAND>(acc, Zl + 32 * wm * LDT, Ws + 32 * wn);
                     __syncthreads();
                     PH(7);
@@ -1124,7 +1132,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         if (last && !w0_resident) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
                         __syncthreads();
                     }
-                    if (BF) colred_bf(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
+                    if (BF) colred_bf<HAND>(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
                     else colred_sel<HAND>(accW0[c], Z0 + 32 * wm, Xs + 32 * wn);
                 }
             }
@@ -1294,15 +1302,20 @@ inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t
     hipLaunchKernelGGL((k_mlp<NCH, MODE, VEC, LCAP, KJ, BF, HAND>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a);
 }
 
-// CM_MFMA=bf16x3 opts the PPO training passes into the compensated-bf16 GEMM loops (default: exact fp32 MFMA)
-inline bool mfma_bf16x3() { return cm_mfma_mode() == 1; }
+// option mfma = bf16x3 / bf16 opts the PPO training passes into the compensated / single-pass bf16 GEMM loops (default: exact fp32 MFMA)
+inline bool mfma_bf16x3() { return cm_mfma_mode() != 0; }   // any bf16 mode: the split-word kernels
+inline bool mfma_bf16_one() { return cm_mfma_mode() == 2; } // single pass
 
 // runtime (vec, L <= 1, dout <= 8) -> compile-time (VEC, LCAP, KJ)
 template <int NCH, int MODE>
 inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
     const bool vec = can_vec(a), l1 = a.L <= 1, k8 = a.dout <= 8;
     if constexpr ((MODE == M_ACTOR || MODE == M_CRITIC) && NCH <= 2) {
-        if (vec && l1 && k8 && mfma_bf16x3()) { launch_one<NCH, MODE, 1, 1, 2, true>(a, grid, lds_bytes, s); return; }
+        if (vec && l1 && k8 && mfma_bf16x3()) {
+            if (mfma_bf16_one()) launch_one<NCH, MODE, 1, 1, 2, true, true>(a, grid, lds_bytes, s);
+            else launch_one<NCH, MODE, 1, 1, 2, true>(a, grid, lds_bytes, s);
+            return;
+        }
     }
     // hand-ordered LDS reads (see rowpar_nt): the single-chunk actor pass of a batch too large to share the GPU with the critic's
     // epochs (learner.overlap_critic's 2^21-row limit), and every forward pass (the value pass follows the rollout and the join with

@@ -64,12 +64,14 @@ int cm_version(void);
  *   "gru_tile"         auto | 64               64: the 64-row streaming GRU sweeps at any batch size
  *   "rollout_tile"     auto | 64 | 16 | 16s | 64s   tiling of the fused rollout (64 / 16: four-wave workgroups; 64s / 16s: four compute
  *                                              waves + a writer and a scorer wave, the defaults)
- *   "mfma"             fp32 | bf16x3           GEMM arithmetic of the PPO training passes: exact fp32 MFMA, or error-compensated
- *                                              bf16 (~3e-6 of sum|a b| per product, fp32 accumulate -- DESIGN.md section 8)
+ *   "mfma"             fp32 | bf16x3 | bf16    GEMM arithmetic of the PPO training passes: exact fp32 MFMA; error-compensated bf16
+ *                                              (3 MFMAs per product, ~3e-6 of sum|a b|, inside the 1e-4 parity bar); single-pass bf16
+ *                                              (1 MFMA per product, operands rounded to 8 bits: ~4e-3, its own looser parity tier);
+ *                                              fp32 accumulate either way -- DESIGN.md section 8
  * cm_set_option returns 0, or -1 for an unknown key / value; cm_get_option returns the current value's name (NULL: unknown key). */
 int cm_set_option(const char* key, const char* value);
 const char* cm_get_option(const char* key);
-/* current "mfma" option: 0 = fp32, 1 = bf16x3 */
+/* current "mfma" option: 0 = fp32, 1 = bf16x3, 2 = bf16 */
 int cm_mfma_mode(void);
 /* A HIP stream of the LOWEST priority the device offers (hipStreamCreateWithPriority, non-blocking), for work that has slack and
  * should only fill compute units the caller's main stream leaves idle: the critic epochs of iteration i run on it under the rollout

@@ -56,10 +56,14 @@ def test_shape_env_scripts(script, tmp_path, monkeypatch):
         assert TAGS <= {t for t, _, _ in out["history"]} and all(math.isfinite(v) for _, v, _ in out["history"])
 
 
-def test_learning_signal_on_synthetic_env(tmp_path, monkeypatch):
-    """A few hundred iterations of MAPPO on the on-device env must improve the episode return."""
+@pytest.mark.parametrize("mfma", ["", "bf16"])
+def test_learning_signal_on_synthetic_env(mfma, tmp_path, monkeypatch):
+    """A few hundred iterations of MAPPO on the on-device env must improve the episode return -- with the default exact-fp32 arithmetic
+    and with the opt-in single-pass bf16 training passes (CM_MFMA=bf16, looser parity tier: it must still learn)."""
     from cleanmarl_amd.driver import run
     monkeypatch.chdir(tmp_path)
+    if mfma:
+        monkeypatch.setenv("CM_MFMA", mfma)
     out = run("mappo_multienvs", ["--env_type=synthetic", "--batch_size=256", "--synthetic_agents=3", "--synthetic_steps=25",
                                   "--total_timesteps=1280000", "--eval_steps=100000", "--log_every=1",
                                   "--actor_hidden_dim=64", "--normalize_advantage"])
