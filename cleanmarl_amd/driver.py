@@ -287,6 +287,62 @@ def run(script, argv=None):
                             host_actor_calls=host_actor.calls, pinned_calls=pinned.calls if pinned is not None else 0), tmp)
             os.replace(tmp, args.checkpoint)
     iteration = 0
+    # Accounting (episode statistics, rollout/* and train/* scalars) of an iteration needs numbers that come off the device.  With a
+    # device env nothing on the host depends on them, so iteration i is accounted for AFTER iteration i + 1 has been enqueued: the host
+    # never waits for work it has just launched and the launch queue stays fed (the CLI's steady state was 1.75 ms per iteration at 512
+    # envs against 1.52 ms of bench.py's loop, profiles/r03_cli_steady_state.txt).  The accounting runs in iteration order with that
+    # iteration's step / training_step, so the logged history is exactly the undeferred one; evaluation, checkpoints and the end of
+    # the run flush it first.  Host envs account immediately (their rollouts wait for the host anyway).
+    pending = []
+    rew_ring = [None, None]
+
+    def flush():
+        while pending:
+            pending.pop(0)()
+
+    def make_account(stats_fn, recs, step, training_step, num_episodes):
+        def account():
+            nonlocal ep_rewards, ep_lengths, ep_stats
+            stats = stats_fn()
+            if world > 1:
+                # rollout/* scalars and their cadence must be those of ONE process owning all batch_size envs: gather every rank's episodes
+                # (variable counts per rank: pad to the largest shard) instead of logging rank 0's shard
+                won = [float(i["battle_won"]) for i in stats["infos"]] if args.env_type == "smaclite" else [0.0] * E
+                loc = torch.full((3, (E_glob + world - 1) // world), float("nan"), dtype=torch.float64, device=device)
+                loc[0, :E] = torch.tensor(stats["ep_reward"], dtype=torch.float64); loc[1, :E] = torch.tensor(stats["ep_len"], dtype=torch.float64)
+                loc[2, :E] = torch.tensor(won, dtype=torch.float64)
+                parts = [torch.empty_like(loc) for _ in range(world)]
+                torch.distributed.all_gather(parts, loc, group=pg)
+                allp = torch.cat(parts, dim=1).cpu()
+                keep = ~torch.isnan(allp[1])
+                ep_rewards.extend(allp[0][keep].tolist()); ep_lengths.extend(allp[1][keep].tolist())
+                if args.env_type == "smaclite":
+                    ep_stats.extend(allp[2][keep].tolist())
+            else:
+                ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
+                if args.env_type == "smaclite":
+                    ep_stats.extend([i["battle_won"] for i in stats["infos"]])
+            log_now = (training_step % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
+            if log_now:
+                if writer:
+                    writer.add_scalar("rollout/ep_reward", np.mean(ep_rewards), step)
+                    writer.add_scalar("rollout/ep_length", np.mean(ep_lengths), step)
+                    writer.add_scalar("rollout/num_episodes", num_episodes, step)
+                    if args.env_type == "smaclite":
+                        writer.add_scalar("rollout/battle_won", np.mean(ep_stats), step)
+                ep_rewards, ep_lengths, ep_stats = [], [], []
+            if writer:  # train/* are means over epochs (:605-612)
+                m = lambda k: float(np.mean([r[k] for r in recs]))
+                writer.add_scalar("train/critic_loss", m("critic_loss"), step)
+                writer.add_scalar("train/actor_loss", m("actor_loss"), step)
+                writer.add_scalar("train/entropy", m("entropy"), step)
+                writer.add_scalar("train/kl_divergence", m("kl"), step)
+                writer.add_scalar("train/clipped_ratios", m("clipfrac"), step)
+                writer.add_scalar("train/actor_gradients", m("actor_gnorm"), step)
+                writer.add_scalar("train/critic_gradients", m("critic_gnorm"), step)
+                writer.add_scalar("train/num_updates", training_step, step)
+        return account
+
     while step < args.total_timesteps:
         if not device_env:
             # host rollouts allocate a fresh batch per iteration: the previous one (still read by the critic epochs on their own
@@ -294,8 +350,18 @@ def run(script, argv=None):
             learner.wait_critic()
         if device_env:
             b = roll.collect(learner.actor, actor_spec)
-            rew = b.reward.sum(1).cpu().tolist()
-            stats = dict(ep_reward=rew, ep_len=[b.T] * E, infos=[None] * E)
+            # episode returns: summed on the device, copied to page-locked memory asynchronously, read when the iteration is accounted for
+            k = iteration & 1
+            if rew_ring[k] is None or rew_ring[k][0].numel() != E:
+                rew_ring[k] = [torch.empty(E, dtype=torch.float32, pin_memory=True), None]
+            rew_ring[k][0].copy_(b.reward.sum(1), non_blocking=True)
+            rew_ring[k][1] = torch.cuda.Event()
+            rew_ring[k][1].record()
+
+            def stats_fn(slot=rew_ring[k], T_=b.T):
+                slot[1].synchronize()
+                return dict(ep_reward=slot[0].tolist(), ep_len=[T_] * E, infos=[None] * E)
+            n_total = E_glob * b.T  # every env of a device rollout runs exactly T steps: no collective, no host wait
         elif single_env:
             b, stats = host_rollout_single(the_env, host_actor, E, A, args.seed + training_step, recurrent, device, pad=not recurrent)
         else:
@@ -304,59 +370,34 @@ def run(script, argv=None):
             else:
                 collect = host_rollout if args.vector_env == "pipe" else host_rollout_shm
                 b, stats = collect(venv, host_actor, E, A, args.seed + training_step, recurrent, device, pad=not recurrent)
-        n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
-        if world > 1:
-            torch.distributed.all_reduce(n_steps, group=pg)
-            if not device_env:  # host envs end at different steps on different ranks: agree on the padded length
+        if not device_env:
+            stats_fn = lambda stats=stats: stats
+            n_steps = torch.tensor([float(sum(stats["ep_len"]))], device=device)
+            if world > 1:
+                torch.distributed.all_reduce(n_steps, group=pg)
+                # host envs end at different steps on different ranks: agree on the padded length
                 t_max = torch.tensor([b.T], device=device)
                 torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX, group=pg)
                 b = pad_time(b, int(t_max.item()))
-        step += int(n_steps.item())  # counts ENV steps, like the reference (:435)
-        if world > 1:
-            # rollout/* scalars and their cadence must be those of ONE process owning all batch_size envs: gather every rank's episodes
-            # (variable counts per rank: pad to the largest shard) instead of logging rank 0's shard
-            won = [float(i["battle_won"]) for i in stats["infos"]] if args.env_type == "smaclite" else [0.0] * E
-            loc = torch.full((3, (E_glob + world - 1) // world), float("nan"), dtype=torch.float64, device=device)
-            loc[0, :E] = torch.tensor(stats["ep_reward"], dtype=torch.float64); loc[1, :E] = torch.tensor(stats["ep_len"], dtype=torch.float64)
-            loc[2, :E] = torch.tensor(won, dtype=torch.float64)
-            parts = [torch.empty_like(loc) for _ in range(world)]
-            torch.distributed.all_gather(parts, loc, group=pg)
-            allp = torch.cat(parts, dim=1).cpu()
-            keep = ~torch.isnan(allp[1])
-            ep_rewards.extend(allp[0][keep].tolist()); ep_lengths.extend(allp[1][keep].tolist())
-            if args.env_type == "smaclite":
-                ep_stats.extend(allp[2][keep].tolist())
-        else:
-            ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
-            if args.env_type == "smaclite":
-                ep_stats.extend([i["battle_won"] for i in stats["infos"]])
+            n_total = int(n_steps.item())
+        step += n_total  # counts ENV steps, like the reference (:435)
         num_episodes += E_glob
-        log_now = (training_step % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
-        if log_now:
-            if writer:
-                writer.add_scalar("rollout/ep_reward", np.mean(ep_rewards), step)
-                writer.add_scalar("rollout/ep_length", np.mean(ep_lengths), step)
-                writer.add_scalar("rollout/num_episodes", num_episodes, step)
-                if args.env_type == "smaclite":
-                    writer.add_scalar("rollout/battle_won", np.mean(ep_stats), step)
-            ep_rewards, ep_lengths, ep_stats = [], [], []
 
         recs = learner.train_iteration(b)
         training_step += len(recs)
         iteration += 1
+        acct = make_account(stats_fn, recs, step, training_step, num_episodes)
+        if device_env:
+            flush()                 # iteration i - 1, now that iteration i is enqueued
+            pending.append(acct)
+        else:
+            acct()
         if args.checkpoint_every and iteration % args.checkpoint_every == 0:
+            flush()
             save_checkpoint()
-        if writer:  # train/* are means over epochs (:605-612)
-            m = lambda k: float(np.mean([r[k] for r in recs]))
-            writer.add_scalar("train/critic_loss", m("critic_loss"), step)
-            writer.add_scalar("train/actor_loss", m("actor_loss"), step)
-            writer.add_scalar("train/entropy", m("entropy"), step)
-            writer.add_scalar("train/kl_divergence", m("kl"), step)
-            writer.add_scalar("train/clipped_ratios", m("clipfrac"), step)
-            writer.add_scalar("train/actor_gradients", m("actor_gnorm"), step)
-            writer.add_scalar("train/critic_gradients", m("critic_gnorm"), step)
-            writer.add_scalar("train/num_updates", training_step, step)
 
+        if (training_step / args.epochs) % args.eval_steps == 0:
+            flush()  # on every rank: the accounting contains collectives at world > 1
         if rank == 0 and (training_step / args.epochs) % args.eval_steps == 0:  # :614-650 (actions are SAMPLED)
             eval_obs, _ = eval_env.reset()
             rets, lens, infos_l, cur_r, cur_l, h_eval = [], [], [], 0.0, 0, None
@@ -374,6 +415,7 @@ def run(script, argv=None):
             if args.env_type == "smaclite":
                 writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
 
+    flush()
     save_checkpoint()
     if writer:
         writer.close()

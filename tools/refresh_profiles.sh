@@ -1,7 +1,7 @@
 # Regenerates the measurement artefacts of a round on a gpurun box:  bash tools/refresh_profiles.sh r02   (outputs: gpurun_out/<tag>/, copy
 # the summaries to profiles/<tag>_*).  Needs libcleanmarl_hip.so and, for the phase profiles, libcleanmarl_hip_prof.so (python -m cleanmarl_amd.build --prof).
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -28,7 +28,8 @@ done
 python $R/tools/phase_prof.py actor > $O/phase_actor.txt 2>&1
 python $R/tools/phase_prof.py critic > $O/phase_critic.txt 2>&1
 python $R/tools/phase_prof.py rollout > $O/phase_rollout.txt 2>&1
-python $R/tools/phase_prof.py rollout 512 8 > $O/phase_rollout16.txt 2>&1
+python $R/tools/phase_prof.py rollout 512 8 > $O/phase_rollout16s.txt 2>&1
+python $R/tools/phase_prof.py act > $O/phase_act.txt 2>&1
 CM_PROF_WARMUP=50 python $R/tools/phase_prof.py gru > $O/phase_gru.txt 2>&1
 python $R/tools/bench_configs.py > $O/configs_learner.txt 2>&1
 # ---- widened rows: COMA, host-env plumbing, layered schedule
@@ -37,4 +38,7 @@ python $R/tools/bench_host_env.py 256 8 128 > $O/host_env.txt 2>&1
 python $R/tools/bench_wide.py 2>&1 | grep -v amdgpu.ids > $O/wide_schedule.txt
 # ---- opt-in compensated-bf16 arithmetic (NOT the default)
 CM_MFMA=bf16x3 python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_bf16x3.json 2>/dev/null
+CM_MFMA=bf16 python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_bf16.json 2>/dev/null
+# ---- steady-state rate of the product surface (driver.run through the CLI), not only of bench.py's inner loop
+python $R/tools/cli_steady_state.py > $O/cli_steady_state.txt 2>&1
 ls -la $O
