@@ -85,3 +85,76 @@ def test_ctypes_recipe_reproduces_the_reference(golden_dir, name):
         assert _err(float(norms[0]), z["actor_gradients"][epoch]) <= TOL and _err(float(norms[1]), z["critic_gradients"][epoch]) <= TOL
         assert _err(actor_flat.cpu().numpy(), z["actor_after"][epoch]) <= TOL
         assert _err(critic_flat.cpu().numpy(), z["critic_after"][epoch]) <= TOL
+
+
+class OptStep(C.Structure):  # cm_opt_step_t exactly as INTEGRATION.md section 6c declares it
+    _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("out_norm", C.c_void_p), ("scratch", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("max_norm", C.c_double), ("grad_scale", C.c_double), ("step", C.c_int32), ("opt_kind", C.c_int32)]
+
+
+@pytest.mark.parametrize("name", ["mappo_dense", "mappo_ragged_norm"])
+def test_ctypes_train_step_recipe_reproduces_the_reference(golden_dir, name):
+    """INTEGRATION.md section 6c with nothing but ctypes: cm_set_option / cm_get_option, cm_opt_step_t, the *_train_step_ld entry points
+    (the optimiser step rides on the pass's reduction launch) -- per-epoch parameters of the unmodified reference."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "cleanmarl_amd", "libcleanmarl_hip.so"))
+    lib.cm_last_error.restype = C.c_char_p
+    lib.cm_get_option.restype = C.c_char_p
+    for f in (lib.cm_mlp_train_workspace_bytes, lib.cm_critic_workspace_bytes, lib.cm_opt_step_scratch_bytes):
+        f.restype = C.c_size_t
+
+    def chk(rc):
+        if rc:
+            raise RuntimeError(lib.cm_last_error().decode())
+    assert lib.cm_set_option(b"critic_schedule", b"nonsense") != 0 and lib.cm_set_option(b"no_such_option", b"auto") != 0
+    chk(lib.cm_set_option(b"critic_schedule", b"split"))
+    assert lib.cm_get_option(b"critic_schedule") == b"split" and lib.cm_get_option(b"mfma") == b"fp32"
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = C.c_double
+    t = lambda k: torch.from_numpy(z[k])
+    b_obs, b_states, b_avail, b_mask = t("b_obs"), t("b_states"), t("b_avail_actions"), t("b_mask")
+    E, T, A, Do = b_obs.shape
+    Ds, K = b_states.shape[-1], b_avail.shape[-1]
+    obs = b_obs.permute(0, 2, 1, 3).contiguous().cuda()
+    avail = b_avail.permute(0, 2, 1, 3).to(torch.uint8).contiguous().cuda()
+    action = t("b_actions").permute(0, 2, 1).to(torch.int32).contiguous().cuda()
+    logp = t("b_log_probs").permute(0, 2, 1).contiguous().cuda()
+    state = b_states.cuda()
+    ep_len = b_mask.sum(1).to(torch.int32).cuda()
+    # targets as the reference computed them (sections 1 / 1b are covered by the test above): the [E, A, T] permutation of the goldens
+    ret = t("return_lambda").permute(0, 2, 1).contiguous().cuda()
+    adv = t("advantages").permute(0, 2, 1).contiguous().cuda()
+    ap = [t(f"actor_init_{i}") for i in range(int(z["actor_nparam"]))]
+    cp = [t(f"critic_init_{i}") for i in range(int(z["critic_nparam"]))]
+    actor_flat = torch.cat([p.reshape(-1) for p in ap]).cuda()
+    critic_flat = torch.cat([p.reshape(-1) for p in cp]).cuda()
+    Ha, La, Hc, Lc = ap[0].shape[0], len(ap) // 2 - 2, cp[0].shape[0], len(cp) // 2 - 2
+    hp = {k[3:]: (float(z[k]) if z[k].dtype.kind == "f" else str(z[k])) for k in z.files if k.startswith("hp_")}
+    Pa, Pc = actor_flat.numel(), critic_flat.numel()
+    ga, gc = torch.zeros(Pa + 8, device="cuda"), torch.zeros(Pc + 8, device="cuda")
+    ws = torch.empty(max(lib.cm_mlp_train_workspace_bytes(Do, Ha, La, K), lib.cm_critic_workspace_bytes(E, A, T, 0, Ds, Hc, Lc)),
+                     dtype=torch.uint8, device="cuda")
+    m_a, v_a, m_c, v_c = (torch.zeros(n, device="cuda") for n in (Pa, Pa, Pc, Pc))
+    norms = torch.zeros(2, device="cuda")
+    scr_a, scr_c = (torch.zeros(lib.cm_opt_step_scratch_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2))
+    try:
+        for epoch in range(int(hp["epochs"])):
+            oa = OptStep(actor_flat.data_ptr(), m_a.data_ptr(), v_a.data_ptr(), norms.data_ptr(), scr_a.data_ptr(), hp["learning_rate_actor"], 0.9,
+                         0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0)
+            oc = OptStep(critic_flat.data_ptr(), m_c.data_ptr(), v_c.data_ptr(), norms[1:].data_ptr(), scr_c.data_ptr(), hp["learning_rate_critic"],
+                         0.9, 0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0)
+            chk(lib.cm_ppo_actor_train_step_ld(P(obs), C.c_int64(Do), P(avail), P(action), P(logp), P(adv), P(ep_len), E, A, T, Do, Ha, La, K,
+                                               d(hp["ppo_clip"]), d(hp["entropy_coef"]), P(ga), P(ws), C.c_size_t(ws.numel()), C.byref(oa), S()))
+            chk(lib.cm_critic_train_step_ld(P(state), C.c_int64(Ds), P(ret), P(ep_len), E, A, T, 0, Ds, Hc, Lc, P(gc), P(ws),
+                                            C.c_size_t(ws.numel()), C.byref(oc), S()))
+            st = ga[Pa:].cpu(); N = st[5]
+            assert _err(float((-st[0] - hp["entropy_coef"] * st[1]) / N), z["actor_losses"][epoch]) <= TOL
+            assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
+            assert _err(float(norms[0]), z["actor_gradients"][epoch]) <= TOL and _err(float(norms[1]), z["critic_gradients"][epoch]) <= TOL
+            assert _err(actor_flat.cpu().numpy(), z["actor_after"][epoch]) <= TOL
+            assert _err(critic_flat.cpu().numpy(), z["critic_after"][epoch]) <= TOL
+    finally:
+        chk(lib.cm_set_option(b"critic_schedule", b"auto"))
