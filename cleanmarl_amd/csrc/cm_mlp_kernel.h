@@ -621,6 +621,39 @@ __device__ __forceinline__ void tile_store(float* dst, const Tile16& t) {
 template <int KJ> struct RowIn { int act; float lpo, adv, ret; int eplen, ag, e, t; unsigned char avb[KJ]; };
 
 // VEC: 0 = 4-byte tile loads; 1 = 16-byte loads of the input rows and of streamed W0 chunks (can_vec)
+// B-operand register image of W[n0 .. n0+31][k0 .. k0+63] for the 32x32x2 products: w[4j + i] = W[(n0 + r) * ld + k0 + 8j + 4h + i]
+// (lane r = lane & 31, h = lane >> 5), zero outside [nrows) x [ncols); and the product on it, k order identical to rowpar_nt -- same bits.
+__device__ __forceinline__ void w0_regs_load(float (&w)[32], const float* W, int n0, int nrows, long ld, int k0, int ncols) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int n = n0 + r;
+    const float* p = W + (long)n * ld + k0 + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[4 * j + i] = (n < nrows && k0 + 8 * j + 4 * h + i < ncols) ? p[8 * j + i] : 0.0f;
+}
+__device__ __forceinline__ void rowpar_regb(f32x16& acc, const float* As, const float (&w)[32], int kb) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const float4* ap = reinterpret_cast<const float4*>(As + r * LDT + 4 * h);
+    float4 a = ap[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < kb) {
+            float4 an = a;
+            if (j + 1 < kb) an = ap[2 * (j + 1)];
+            acc = mfma32(a.x, w[4 * j], acc);
+            acc = mfma32(a.y, w[4 * j + 1], acc);
+            acc = mfma32(a.z, w[4 * j + 2], acc);
+            acc = mfma32(a.w, w[4 * j + 3], acc);
+            a = an;
+        }
+    }
+}
+
+// NCH: > 0 = training kernels compiled for that many 64-column input chunks; 0 = forward kernels, any width, W0 chunks streamed through
+// LDS per tile when the input is wider than one chunk; -2 = forward kernels for EXACTLY two chunks (65 .. 128 columns: config 4's 115) with
+// W0 as B operands in registers for the whole launch (64 registers) -- the streamed form re-staged two 16 KB W0 chunks for every 64-row
+// tile: 42 % of config 4's act pass (profiles/r03_phase_act.txt)
 template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false, bool HAND = false>
 __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -633,6 +666,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     const int H = a.H, L = a.L, dout = a.dout, din = a.din;
     const int nch = (din + KC - 1) / KC;
     // compile-time for the training instantiations so the streaming paths (and their registers) vanish
+    constexpr bool W0REG = (NCH == -2);
     const bool w0_resident = (NCH > 0) ? (NCH == 1) : (nch == 1);
     const bool ws_resident = (LCAP == 1) || (L == 1);
     const float* W0g = a.w0p ? a.w0p : a.params + off.W0;  // streamed W0 chunks (see MlpArgs::w0p); the LDS-resident form reads params
@@ -692,9 +726,17 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     Tile16 px, pw;
     Tile16 pn;  // NCH == 1 training kernels: the NEXT tile's X, requested mid-tile (px is busy holding this tile's X for dW0)
     constexpr bool EARLY_NEXT = TRAIN && NCH == 1;
+    float w0ra[W0REG ? 32 : 1], w0rb[W0REG ? 32 : 1];  // W0REG: this wave's 32 output columns of W0, both input chunks, for the whole launch
+    if constexpr (W0REG) {
+        w0_regs_load(w0ra, a.params + off.W0, 32 * wn, H, din, 0, din);
+        w0_regs_load(w0rb, a.params + off.W0, 32 * wn, H, din, KC, din);
+    }
     if ((long)blockIdx.x < ntiles) {
         tile_load<(VEC != 0)>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
-        if (!w0_resident) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
+        if (!w0_resident && !W0REG) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
+        // W0REG: the W0 staging registers carry the tile's SECOND X chunk instead -- both chunks of a tile are requested a whole tile
+        // ahead (one chunk ahead, the second chunk's HBM round trip was exposed behind 2 k cycles of MFMAs)
+        if (W0REG) tile_load<(VEC != 0)>(pw, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, KC, din - KC);
     }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -723,8 +765,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         const bool rvalid = grow < (int)a.rows;
         for (int c = 0; c < nch; ++c) {
             __syncthreads();  // previous readers of Xs / W0s are done
-            tile_store<(VEC != 0), BF>(Xs, px);
-            if (!w0_resident) tile_store<(VEC == 1), BF>(W0s, pw);
+            if (W0REG && c == 1) tile_store<(VEC != 0), BF>(Xs, pw); else tile_store<(VEC != 0), BF>(Xs, px);
+            if (!w0_resident && !W0REG) tile_store<(VEC == 1), BF>(W0s, pw);
             if (c == 0) {
                 // per-row head inputs: issued here, BEFORE the tile prefetch below (the compiler turns them into booleans right
                 // after the layer-0 loop; vmcnt waits are in issue order, so behind the prefetch they would drag it along)
@@ -755,13 +797,18 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 const bool again = TRAIN && NCH > 0 && (NCH > 1 || L >= 1);  // backward re-reads X of THIS tile
                 const long r0n = last ? (again ? row0 : next_row0) : row0;
                 const int wn_ = min(KC, din - cn * KC);
+                if (W0REG) {  // chunk c of the NEXT tile into the buffer that was just emptied
+                    if (c == 0) tile_load<(VEC != 0)>(px, a.x, next_row0, a.rows, a.x_stride, 0, KC);
+                    else tile_load<(VEC != 0)>(pw, a.x, next_row0, a.rows, a.x_stride, KC, din - KC);
+                } else
                 tile_load<(VEC != 0)>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
-                if (!w0_resident && !(last && TRAIN && NCH > 0)) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, cn * KC, wn_);
+                if (!w0_resident && !W0REG && !(last && TRAIN && NCH > 0)) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, cn * KC, wn_);
             }
             __syncthreads();
             PH(0);
             const int w = min(KC, din - c * KC);
-            if (BF) rowpar_nt_bf<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);  // BF instantiations: HAND = single-pass bf16
+            if constexpr (W0REG) { if (c == 0) rowpar_regb(acc, Xs + 32 * wm * LDT, w0ra, (w + 7) >> 3); else rowpar_regb(acc, Xs + 32 * wm * LDT, w0rb, (w + 7) >> 3); }
+            else if (BF) rowpar_nt_bf<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);  // BF instantiations: HAND = single-pass bf16
             else rowpar_nt_sel<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 7) >> 3);
         }
         {
@@ -1320,7 +1367,7 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
     // hand-ordered LDS reads (see rowpar_nt): the single-chunk actor pass of a batch too large to share the GPU with the critic's
     // epochs (learner.overlap_critic's 2^21-row limit), and every forward pass (the value pass follows the rollout and the join with
     // the critic stream: nothing runs beside it).  cm_set_option("mlp_forms", "hand"|"loop") forces one form wherever both are compiled (A/B runs, tests).
-    if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH == 0)) {
+    if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH <= 0)) {
         const int f = cm_option(CM_OPTION_MLP_FORMS);  // 0 auto, 1 hand, 2 loop
         const bool big = MODE == M_FWD || a.rows > (1L << 21);
         const bool hand = f ? (f == 1) : big;
@@ -1337,7 +1384,9 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
 
 template <int MODE>
 inline int launch_infer(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
-    launch_variant<0, MODE>(a, grid, lds_bytes, s);
+    // exactly two input chunks: W0 in registers (155 .. 242 registers per lane, two workgroups per CU either way)
+    if ((a.din + KC - 1) / KC == 2) launch_variant<-2, MODE>(a, grid, lds_bytes, s);
+    else launch_variant<0, MODE>(a, grid, lds_bytes, s);
     return 0;
 }
 
