@@ -482,7 +482,13 @@ class PPOLearner:
         overlap = 0 if keep_grads else self.overlap_critic(b)
         # one [actor grads | 8 | critic grads | 8] row per epoch: the statistics survive the next epoch without per-epoch copies,
         # the norms are written by the Adam kernel straight into `rec`; row 0 is self.gbuf (what single passes and tests read)
-        rec = torch.zeros(nE0, 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device)
+        # [actor stats | critic stats | actor norm | critic norm] per epoch.  Two persistent buffers used alternately (every field is
+        # written by each update: no fill launch; the previous update's asynchronous copy to the host may still be reading the other one)
+        self._rec_i = getattr(self, "_rec_i", 0) ^ 1
+        recs_ = getattr(self, "_recs", None)
+        if recs_ is None or recs_[0].shape[0] != nE0:
+            recs_ = self._recs = [torch.zeros(nE0, 2 * N.NUM_STATS + 2, dtype=torch.float32, device=self.device) for _ in range(2)]
+        rec = recs_[self._rec_i]
         kept_a, kept_c = [], []
         timed = self.events is not None
         self.critic_span = None
@@ -543,7 +549,6 @@ class PPOLearner:
             if self._critic_stream is None:
                 self._critic_stream = N.low_priority_stream(self.device)
             side = self._critic_stream
-            rec.record_stream(side)
 
             def actor_epoch(ep):
                 g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
@@ -581,9 +586,9 @@ class PPOLearner:
                 side.wait_stream(main)
                 for ep in range(nE0):
                     critic_epoch(ep)
-            rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
             side.wait_stream(main)  # the statistics need both halves; they leave on the critic stream, `main` never waits for them
             with torch.cuda.stream(side):
+                rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]  # on the side stream too: nothing trails the actor's last step on `main`
                 host, ev, attach = _to_host_async(self._ring, rec)
                 self._critic_done = torch.cuda.Event()
                 self._critic_done.record(side)

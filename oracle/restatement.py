@@ -309,6 +309,23 @@ def gru_update(actor_params, critic_params, batch, hp, algo, actor_opt=None, cri
     return ret, adv, recs
 
 
+def gru_chunk_sums(actor_params, batch, adv, h_in, t0, t1, ppo_clip, entropy_coef):
+    """UN-NORMALISED gradient of one TBPTT chunk's loss  sum_{t in [t0, t1)} (-pg_t - c ent_t)  from the detached hidden state
+    h_in [B*A, H] (the quantity the chunk kernels accumulate before the division by N_chunk * T_chunk of
+    mappo_lstm_multienvs.py:605-607) and the chunk's valid (env, t) count.  batch: obs / actions / log_probs / avail / mask in the
+    reference layout [B, T, A, ...]; adv [B, T, A]."""
+    B, T, A, Do = batch["obs"].shape
+    ap = [p.detach().clone().requires_grad_(True) for p in actor_params]
+    hh = h_in
+    loss, count = 0.0, 0
+    for t in range(t0, t1):
+        lg, hh = gru_actor_logits(ap, batch["obs"][:, t].reshape(B * A, Do), hh, batch["avail"][:, t].reshape(B * A, -1))
+        sub = dict(mask=batch["mask"][:, t:t + 1], actions=batch["actions"][:, t:t + 1], log_probs=batch["log_probs"][:, t:t + 1])
+        loss = loss + actor_terms(lg.reshape(B, 1, A, -1), sub, adv[:, t:t + 1], ppo_clip, entropy_coef)["loss"]
+        count += int(batch["mask"][:, t].sum())
+    return [g.clone() for g in torch.autograd.grad(loss, ap)], dict(count=count)
+
+
 # ---------------------------------------------------------------- fixture helpers
 def load_golden(path):
     """Read a tests/golden/*.npz into (batch dict, actor params, critic params, hp, golden dict)."""

@@ -109,3 +109,63 @@ def test_recurrent_scripts_run_on_wide_shapes(script, extra, tmp_path, monkeypat
                        "--critic_hidden_dim=64", "--tbptt=5", "--greedy_eval"] + extra)
     assert out["training_step"] >= 3 and all(math.isfinite(v) for _, v, _ in out["history"])
     assert "eval/ep_reward" in {t for t, _, _ in out["history"]}
+
+
+def test_config5_full_size_chunk_pass_is_additive_over_env_shards_and_deterministic():
+    """BASELINE config 5 at its full size (1024 envs x 5 agents x 128 steps, GRU hidden 64, tbptt 10), where no CPU oracle finishes in
+    seconds: the TBPTT chunk pass (cm_gru_actor_chunk_fwd_bwd, second-generation 32-row sweeps) is a SUM over sequences, so the
+    un-normalised gradient + statistics buffer of the full batch equals the sum over uneven, tile-unaligned env shards (the property the
+    env-sharded run relies on), h_out rows are those of the shards, two runs give identical bits, everything is finite -- and one shard
+    (24 envs) is small enough for the oracle: its chunk gradient matches the CPU restatement, which pins the full-size pass through the
+    additivity."""
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import DeviceBatch, NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    E, A, T, K, H, tb = 1024, 5, 128, 5, 64, 10
+    Do, Ds = 7 * A, 6 * A * A
+    g = torch.Generator().manual_seed(0)
+    b = DeviceBatch(E, A, T, Do, Ds, K, dev)
+    b.obs.copy_(torch.randn(E, A, T, Do, generator=g)); b.avail.fill_(1)
+    b.action.copy_(torch.randint(0, K, (E, A, T), generator=g).int()); b.logp.copy_(-1.6 + 0.1 * torch.randn(E, A, T, generator=g))
+    b.adv.copy_(torch.randn(E, A, T, generator=g)); b.ep_len.copy_(torch.randint(T // 2, T + 1, (E,), generator=g).int())
+    torch.manual_seed(1)
+    spec = NetSpec(Do, H, 0, K, "gru")
+    plist = init_params_like_torch(spec)
+    p = flatten_params(plist, dev)
+    P = p.numel()
+    ws = torch.empty(lib.cm_gru_workspace_bytes(E, A, Do, H, K, tb), dtype=torch.uint8, device=dev)
+    t0, t1 = 60, 70  # a chunk that straddles the shortest episodes' ends
+    h_in = torch.randn(E * A, H, generator=g).to(dev) * 0.3
+
+    def chunk(lo, hi):
+        n = hi - lo
+        gbuf = torch.zeros(P + N.NUM_STATS, device=dev)
+        h_out = torch.zeros(n * A, H, device=dev)
+        N.check(lib.cm_gru_actor_chunk_fwd_bwd(N.ptr(b.obs[lo:hi]), N.ptr(b.avail[lo:hi]), N.ptr(b.action[lo:hi]), N.ptr(b.logp[lo:hi]),
+                                               N.ptr(b.adv[lo:hi]), N.ptr(b.ep_len[lo:hi]), n, A, T, t0, t1, Do, H, K, N.ptr(p),
+                                               N.ptr(h_in[lo * A:hi * A]), N.ptr(h_out), 0.2, 1e-3, N.ptr(gbuf), N.ptr(ws), ws.numel(),
+                                               N.stream_ptr()), "cm_gru_actor_chunk_fwd_bwd")
+        torch.cuda.synchronize()
+        return gbuf, h_out
+    full, h_full = chunk(0, E)
+    again, _ = chunk(0, E)
+    assert torch.equal(full, again) and torch.isfinite(full).all() and torch.isfinite(h_full).all()
+    parts, first = torch.zeros_like(full), None
+    for lo, hi in ((0, 24), (24, 333), (333, E)):
+        gp, hp_ = chunk(lo, hi)
+        parts += gp
+        assert (hp_ - h_full[lo * A:hi * A]).abs().max().item() <= 1e-5
+        if first is None:
+            first = gp.clone()
+    assert (full - parts).abs().max().item() <= 1e-4 * full.abs().max().item()
+    valid = ((torch.arange(t0, t1)[None, :] < b.ep_len.cpu()[:, None]).sum()).item()
+    assert full[P + N.STAT_COUNT].item() == valid
+    # ---- the 24-env shard against the oracle's chunk gradient
+    sb_len = b.ep_len[:24].cpu()
+    mask = torch.arange(T)[None, :] < sb_len[:, None]
+    batch = dict(obs=b.obs[:24].permute(0, 2, 1, 3).cpu(), actions=b.action[:24].permute(0, 2, 1).long().cpu(),
+                 log_probs=b.logp[:24].permute(0, 2, 1).cpu(), avail=b.avail[:24].permute(0, 2, 1, 3).bool().cpu(), mask=mask)
+    og, ostats = R.gru_chunk_sums(plist, batch, b.adv[:24].permute(0, 2, 1).cpu(), h_in[:24 * A].cpu(), t0, t1, 0.2, 1e-3)
+    assert _err(first[:P].cpu().numpy(), R.flat(og).numpy()) <= TOL * max(1.0, float(first[:P].abs().max()))
+    assert abs(float(first[P + N.STAT_COUNT]) - ostats["count"]) == 0
