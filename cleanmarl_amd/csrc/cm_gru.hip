@@ -906,8 +906,19 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #define CM_GRU2_F(WV_, KP_) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf); \
         hipLaunchKernelGGL((k_gru2_fwd<WV_, KP_>), dim3(grid32), dim3(NTHREADS), lf, (hipStream_t)stream, a); } while (0)
-        if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
-        else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
+        // forward: eight waves per tile (stores + head on helper waves, behind the chain); gru_tile = 32 keeps the four-wave kernel
+        const size_t lf8 = gru2_fwd8_lds_bytes(KP);
+#define CM_GRU2_F8(WV_, KP_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd8<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf8); \
+        hipLaunchKernelGGL((k_gru2_fwd8<WV_, KP_>), dim3(grid32), dim3(NT8), lf8, (hipStream_t)stream, a); } while (0)
+        if (cm_option(CM_OPTION_GRU_TILE) == 32) {
+            if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
+            else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
+        } else {
+            if (KP == 16) { if (wv) CM_GRU2_F8(true, 16); else CM_GRU2_F8(false, 16); }
+            else          { if (wv) CM_GRU2_F8(true, 32); else CM_GRU2_F8(false, 32); }
+        }
+#undef CM_GRU2_F8
 #undef CM_GRU2_F
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);

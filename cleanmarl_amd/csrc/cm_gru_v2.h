@@ -354,6 +354,343 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_fwd(const GruArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_gru2_fwd8: the forward sweep with EIGHT waves per 32-row tile.  Waves 0-3 run the recurrence of k_gru2_fwd and nothing else;
+// waves 4-7 ("helpers") take everything that only CONSUMES a finished step, one and two steps behind the chain:
+//   * the six row-major workspace tiles of step s - 1 leave during step s (they were 2.2 k of the 17 k cycles of a step);
+//   * the head (logits -> PPO loss -> dlogits -> fc2 gradient -> dh_head), which k_gru2_fwd runs AFTER its step loop (8.6 k cycles per
+//     pair of steps with the recurrence waves idle), runs DURING the loop: relu(h') of two steps is collected straight from the LDS
+//     tiles into HB[pass & 1] (no reload from the workspace), the four phases of a pass are spread over the intervals between the
+//     recurrence's own three barriers per step, and dh_head leaves from the MFMA accumulators (128-byte runs per half wave).
+// Every wave executes the same barrier sequence (3 per step, two drain steps at the end of the chunk); x1 is double-buffered so that
+// its tile survives until the helpers have stored it.  Interval map of step s (sp = s - 1, pass p = steps 2p, 2p + 1):
+//     I0 (top .. "x1 complete"):   r, z, n, W_hn h tiles of sp -> workspace;  relu(h'_sp) -> HB[(sp >> 1) & 1];  s = 2p + 3: PPO math of pass p
+//     I1 ("x1 complete" .. "h'"):  x1, h' tiles of sp -> workspace;  s = 2p + 2: logits of pass p;  s = 2p + 3: fc2 gradient + dh_head of pass p
+// Same arithmetic in the same order as k_gru2_fwd (same thread mapping inside the helper group): both leave bit-identical results.
+constexpr int NT8 = 2 * NTHREADS;
+constexpr int g2f8_lds_floats(int KP) { return 9 * T32 * LDT + 2 * TM * LDT + KP * WLD + 2 * TM * KP + KMAX + 2 * NTHREADS + 8 * TM; }
+inline size_t gru2_fwd8_lds_bytes(int KP) { return (size_t)g2f8_lds_floats(KP) * sizeof(float); }
+#ifdef CM_PHASE_PROF
+#define PH8_FLUSH() do { if (a.prof && (threadIdx.x == 0 || threadIdx.x == NTHREADS)) { const int b_ = threadIdx.x ? 8 : 0; _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) a.prof[(size_t)blockIdx.x * 16 + b_ + i_] = ph_[b_ + i_]; } } while (0)
+#else
+#define PH8_FLUSH()
+#endif
+
+template <bool WV, int KP>
+__global__ __launch_bounds__(NT8) void k_gru2_fwd8(const GruArgs a) {
+    constexpr int KJ = KP / 4, NCT = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* X0 = p; p += T32 * LDT;    // obs tile of the step
+    float* X1a = p; p += T32 * LDT;   // x1 = relu(fc1(obs)), even steps
+    float* X1b = p; p += T32 * LDT;   //                     odd steps
+    float* hp = p; p += T32 * LDT;    // h_{t-1}
+    float* hn = p; p += T32 * LDT;    // h_t
+    float* SR = p; p += T32 * LDT;
+    float* SZ = p; p += T32 * LDT;
+    float* SN = p; p += T32 * LDT;
+    float* SG = p; p += T32 * LDT;    // W_hn h + b_hn
+    float* HBa = p; p += TM * LDT;    // relu(h') of the two steps of an even pass (64 items)
+    float* HBb = p; p += TM * LDT;    //                               odd pass
+    float* wouts = p; p += KP * WLD;
+    float* ls = p; p += TM * KP;      // logits of the 64 items
+    float* ls2 = p; p += TM * KP;     // dlogits of the 64 items
+    float* b2 = p; p += KMAX;
+    float* red = p; p += 2 * NTHREADS;
+    float* itf = p;                   // per-item inputs of a pass, staged by the recurrence waves: [64 items][act, logp_old, adv, -] ...
+    unsigned* itav = reinterpret_cast<unsigned*>(p + 4 * TM);  // ... and [64 items][4 lanes] availability bits (bit j: action 4 j + lane)
+    // the role is wave-uniform and the compiler must know it (a scalar branch): a divergent one keeps the helpers' registers live
+    // through the recurrence
+    const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    const int tid = threadIdx.x & (NTHREADS - 1), lane = tid & 63, wave = tid >> 6;   // inside the role's group of four waves
+    const int wn = wave & 1, g = wave >> 1, h = lane >> 5, lc = lane & 31;            // head: wave (g, wn) = items 32 g .., columns 32 wn ..
+    const int col = 32 * wn + lc;
+    const int H = a.H, K = a.K, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const int NP = (CL + 1) >> 1, SV = 2 * NP + 2;   // passes of the head; steps including the drain
+    const long R = (long)a.E * a.A;
+    for (int i = threadIdx.x; i < KP * WLD; i += NT8) {
+        const int k = i / WLD, c = i % WLD;
+        wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < KMAX; i += NT8) b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+
+    PH_DECL
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
+    f32x4 accWo[NCT];  // helpers: dW2[k = 16 ct + 4 (lane >> 4) + q][hidden column 16 wave + (lane & 15)]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accWo[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbo = 0.f;
+    const long ntiles = (R + T32 - 1) / T32;
+    if (!helper) {
+        // ================================================================ waves 0-3: the recurrence, 3 barriers per step (gru2_step)
+        G2W w;
+        g2_load_weights<WV>(w, a.params, off, din, H);
+        for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long row0 = tile * T32;
+            __syncthreads();
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+            }
+            X32 xr;
+            x32_load(xr, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
+            x32_store(X0, xr);
+            if (CL > 1) x32_load(xr, a.obs + (long)(a.t0 + 1) * din, row0, R, (long)T * din, din);
+            // per-item inputs of the head (4 lanes per (row, step) item): requested at the end of step 2p, in LDS at the end of step 2p + 1,
+            // read by the helpers in step 2p + 3.  These waves issue no stores, so waiting for a load here waits for loads only -- on the
+            // helper waves every such wait also drained their queue of workspace stores (in-order vmcnt)
+            const int hrow = tid >> 2, hq = tid & 3;
+            const long grow = row0 + (hrow & 31);
+            const bool rvalid = grow < R;
+            unsigned avbits = 0;
+            int it_act = 0;
+            float it_lpo = 0.f, it_adv = 0.f;
+            for (int s = 0; s < SV; ++s) {
+                lds_barrier();  // X0 = obs(t), hp = h_{t-1}
+                PH(0);
+                if (s < CL) {
+                    gru2_step<true>(w, X0, (s & 1) ? X1b : X1a, hp, hn, SR, SZ, SN, SG, din, H);
+                    PH(1);
+                    if (s + 1 < CL) x32_store(X0, xr);
+                    if (s + 2 < CL) x32_load(xr, a.obs + (long)(a.t0 + s + 2) * din, row0, R, (long)T * din, din);
+                    float* tmp = hp; hp = hn; hn = tmp;
+                    PH(2);
+                } else {
+                    if (s == CL && a.h_out)
+                        for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                            const int r = i >> 6, c = i & 63;
+                            if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+                        }
+                    lds_barrier();
+                    lds_barrier();
+                    PH(3);
+                }
+                if (s & 1) {
+                    if ((s >> 1) < NP) {
+                        itav[hrow * 4 + hq] = avbits;
+                        if (hq == 0) *reinterpret_cast<float4*>(itf + 4 * hrow) = make_float4(__int_as_float(it_act), it_lpo, it_adv, 0.f);
+                    }
+                } else if ((s >> 1) < NP) {
+                    const int s_i = s + (hrow >> 5), t_i = a.t0 + s_i;
+                    const bool ok = rvalid && s_i < CL;
+                    avbits = 0;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) {
+                        unsigned v = 1;
+                        if (ok && 4 * j + hq < K) v = a.avail[(grow * T + t_i) * K + 4 * j + hq] ? 1u : 0u;
+                        avbits |= v << j;
+                    }
+                    const long o = grow * T + t_i;
+                    it_act = (ok && hq == 0) ? a.action[o] : 0;
+                    it_lpo = (ok && hq == 0) ? a.logp_old[o] : 0.f;
+                    it_adv = (ok && hq == 0) ? a.adv[o] : 0.f;
+                }
+            }
+        }
+    } else {
+        // ================================================================ waves 4-7: workspace stores + the head, behind the chain
+        for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long row0 = tile * T32;
+            __syncthreads();
+            const int hrow = tid >> 2, hq = tid & 3;   // PPO math: 4 lanes per (row, step) item
+            const int irow = hrow & 31;                // tile row of the item
+            const long grow = row0 + irow;
+            const bool rvalid = grow < R;
+            const int e_row = rvalid ? (int)(grow / a.A) : 0;
+            const int ag = (int)(grow - (long)e_row * a.A);
+            const int eplen = rvalid ? a.ep_len[e_row] : 0;
+            const float invA = 1.0f / (float)a.A;
+            for (int s = 0; s < SV; ++s) {
+                const int sp = s - 1;
+                float* HBw = ((sp >> 1) & 1) ? HBb : HBa;           // the pass step sp belongs to
+                float* HBp = (((s - 2) >> 1) & 1) ? HBb : HBa;      // the pass whose phases run in this step: (s - 2) >> 1 for s = 2p + 2, 2p + 3
+                const int s0 = ((s - 2) >> 1) * 2;                  // its first step
+                lds_barrier();
+                PH(8);
+                // ---------------------------------------------------------------- I0
+                if (sp >= 0 && sp < 2 * NP) {
+                    const bool live = sp < CL;
+                    float* wsS = a.ws_act + ((long)sp * R + row0) * WS2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        const int o = r * LDT + c4;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (live && row0 + r < R) {
+                            float* wp = wsS + (long)r * WS2 + c4;
+#ifndef CM_X_NOST4
+                            *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(SR + o);
+                            *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(SZ + o);
+                            *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(SN + o);
+                            *reinterpret_cast<float4*>(wp + 4 * HP) = *reinterpret_cast<const float4*>(SG + o);
+#endif
+                            v = *reinterpret_cast<const float4*>(hp + o);
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        *reinterpret_cast<float4*>(HBw + (32 * (sp & 1) + r) * LDT + c4) = v;
+                    }
+                }
+                PH(9);
+                if ((s & 1) && s >= 3) {
+                    // PPO clipped-surrogate head (arithmetic of k_gru_chunk_fwd): statistics + dlogits -> ls2
+                    const int s_it = s0 + (hrow >> 5), t_it = a.t0 + s_it;
+                    const bool ivalid = rvalid && s_it < CL;
+                    const unsigned avbits = itav[hrow * 4 + hq];
+                    const float4 itv = *reinterpret_cast<const float4*>(itf + 4 * hrow);
+                    const int act = __float_as_int(itv.x);
+                    const float lpo = itv.y, advv = itv.z;
+                    float zreg[KJ];
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) zreg[j] = (4 * j + hq < K && ((avbits >> j) & 1u)) ? ls[hrow * KP + 4 * j + hq] : -1e9f;
+                    const bool valid = ivalid && t_it < eplen;
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) m = fmaxf(m, zreg[j]);
+                    m = quad_max(m);
+                    float ssum = 0.0f, pj[KJ];
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) { pj[j] = 0.f; if (4 * j + hq < K) { pj[j] = expf(zreg[j] - m); ssum += pj[j]; } }
+                    ssum = quad_sum(ssum);
+                    const float lse = m + logf(ssum), rs = 1.0f / ssum;
+                    float ent = 0.f, lpa = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) if (4 * j + hq < K) {
+                        const float lp = zreg[j] - lse;
+                        pj[j] *= rs; ent -= pj[j] * lp;
+                        if (4 * j + hq == act) lpa = lp;
+                    }
+                    ent = quad_sum(ent); lpa = quad_sum(lpa);
+                    const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
+                    const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                    const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                    float gsel;
+                    if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
+                    if (valid && hq == 0) {
+                        st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
+                        st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
+                        if (ag == 0) st_cnt += 1.f;
+                    }
+                    const float gr = gsel * ratio;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) {
+                        const int k = 4 * j + hq;
+                        float d = 0.f;
+                        if (k < K && valid && zreg[j] > -5e8f) {
+                            const float lp = zreg[j] - lse;
+                            d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
+                        }
+                        ls2[hrow * KP + k] = d;
+                    }
+                }
+                PH(13);
+                lds_barrier();
+                PH(10);
+                // ---------------------------------------------------------------- I1
+                if (sp >= 0 && sp < CL) {
+                    const float* X1 = (sp & 1) ? X1b : X1a;
+                    float* wsS = a.ws_act + ((long)sp * R + row0) * WS2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < R) {
+                            float* wp = wsS + (long)r * WS2 + c4;
+                            const int o = r * LDT + c4;
+#ifndef CM_X_NOST2
+                            *reinterpret_cast<float4*>(wp) = *reinterpret_cast<const float4*>(X1 + o);
+                            *reinterpret_cast<float4*>(wp + 5 * HP) = *reinterpret_cast<const float4*>(hp + o);
+#endif
+                        }
+                    }
+                }
+                PH(11);
+                if (!(s & 1) && s >= 2) {
+                    // logits on the 16x16x4 MFMA: wave w = items 16w..16w+15, one call per 16 head outputs
+                    const int n = lane & 15, g4 = lane >> 4;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const f32x4 lg = head_logits_mfma(HBp + 16 * wave * LDT, wouts + 16 * ct * WLD);
+                        const float bias = b2[16 * ct + n];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ls[(16 * wave + 4 * g4 + q) * KP + 16 * ct + n] = lg[q] + bias;
+                    }
+                } else if ((s & 1) && s >= 3) {
+                    // fc2 gradient: dW2 += dlogits^T relu(h') over the 64 items (wave = 16 hidden columns), db2 += column sums
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) colred_head16<KP>(accWo[ct], ls2, 16 * ct, HBp + 16 * wave);
+                    {
+                        constexpr int PARTS = NTHREADS / KP, RPP = TM / PARTS;
+                        const int k = tid % KP, part = tid / KP;
+                        float sb = 0.f;
+#pragma unroll
+                        for (int r = 0; r < RPP; ++r) sb += ls2[(part * RPP + r) * KP + k];
+                        dbo += sb;
+                    }
+                    // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .. (step s0 + g), columns 32 wn ..; straight to the workspace
+                    f32x16 dh;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dh[i] = 0.0f;
+                    head_bwd_mfma<KP>(dh, ls2 + 32 * g * KP, wouts + 32 * wn);
+                    const int ss = s0 + g;
+                    if (ss < CL) {
+                        float* wsD = a.ws_act + ((long)ss * R + row0) * WS2 + 6 * HP + col;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+#ifndef CM_X_NODH
+                            if (row0 + r < R) wsD[(long)r * WS2] = (HBp[(32 * g + r) * LDT + col] > 0.0f) ? dh[i] : 0.0f;
+#else
+                            if (dh[i] == 123.456f) wsD[(long)r * WS2] = dh[i];
+#endif
+                        }
+                    }
+                }
+                PH(14);
+                lds_barrier();
+                PH(12);
+                if (s < CL) { float* tmp = hp; hp = hn; hn = tmp; }
+            }
+        }
+    }
+    PH8_FLUSH();
+    // ================================ this workgroup's partial row: fc2 gradient + statistics (the rest comes from k_gru2_bwd)
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+    if (helper) {
+        const int n = lane & 15, g4 = lane >> 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * ct + 4 * g4 + r, c = 16 * wave + n;
+                if (k < K && c < H) out[off.W2 + k * H + c] = accWo[ct][r];
+            }
+    }
+    __syncthreads();
+    if (helper) red[tid] = dbo;  // [NTHREADS / KP parts][KP]
+    __syncthreads();
+    if (helper && tid < K) {
+        float sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < NTHREADS / KP; ++q) sb += red[q * KP + tid];
+        out[off.b2 + tid] = sb;
+    }
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+    if (helper) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float v = cm_wave_sum(sv6[q]);
+            if (lane == 0) red[q * 4 + wave] = v;
+        }
+    }
+    __syncthreads();
+    if (helper && tid < CM_NUM_STATS) {
+        float v = 0.f;
+        if (tid < 6) v = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+        out[off.P + tid] = v;
+    }
+}
+
 // transposed tiles [64 columns][32 rows] with row stride LTT: the operands of the weight-gradient MFMAs (contraction over the tile's
 // rows) come out of them as 16-byte reads, four MFMAs per pair of reads, instead of two 4-byte reads per MFMA
 constexpr int LTT = 36;

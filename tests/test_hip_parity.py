@@ -506,11 +506,11 @@ def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H):
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
 
-@pytest.mark.parametrize("tile", ["auto", "64"])
+@pytest.mark.parametrize("tile", ["auto", "32", "64"])
 @pytest.mark.parametrize("name,algo", GRU_CASES)
 def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile, monkeypatch):
-    # "auto" takes the 32-row forward / backward sweeps at this batch size; CM_GRU_TILE=64 (read per call) forces the 64-row
-    # streaming kernels that large batches and K > 8 heads use, so both tilings are pinned to the reference goldens
+    # "auto" takes the 32-row sweeps at this batch size (forward: eight waves per tile, k_gru2_fwd8; CM_GRU_TILE=32 its four-wave
+    # predecessor); CM_GRU_TILE=64 forces the 64-row streaming kernels that large batches use: all three are pinned to the goldens
     if tile != "auto":
         monkeypatch.setenv("CM_GRU_TILE", tile)
     else:
@@ -553,7 +553,7 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
     assert k == len(z["actor_grads"])
 
 
-@pytest.mark.parametrize("tile", ["auto", "64"])
+@pytest.mark.parametrize("tile", ["auto", "32", "64"])
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,tb", [("ippo", 11, 4, 13, 37, 50, 17, 64, 5), ("mappo", 9, 3, 10, 21, 54, 5, 48, 4),
                                                       ("mappo", 40, 5, 12, 35, 150, 5, 64, 10)])
 def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile, monkeypatch):
@@ -588,6 +588,44 @@ def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile,
             assert _err(g.cpu().numpy(), R.flat(ost["grads"]).numpy()) <= TOL
             assert _err(after.cpu().numpy(), R.flat(ost["after"]).numpy()) <= TOL
         assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
+
+
+@pytest.mark.parametrize("E,A,T,Do,K,H,t0,t1", [(40, 5, 23, 35, 5, 64, 0, 10), (40, 5, 23, 35, 5, 64, 20, 23), (11, 4, 13, 37, 17, 64, 5, 10),
+                                                  (9, 3, 10, 21, 5, 48, 3, 4), (70, 3, 12, 18, 5, 64, 0, 7), (33, 2, 9, 64, 30, 40, 1, 9)])
+def test_gru_forward_sweeps_are_bit_identical(E, A, T, Do, K, H, t0, t1):
+    """The eight-wave forward sweep (k_gru2_fwd8: workspace stores and the head on helper waves, behind the chain) against the
+    four-wave one (gru_tile = 32): same arithmetic in the same order, so gradient, statistics and h_out must be EQUAL -- chunks of
+    even and odd length (a half-filled head pass), one step, ragged episodes, several tiles, K > 16 (the 32-wide head)."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    torch.manual_seed(4)
+    batch = _random_case(5, E, A, T, Do, 8, K)
+    spec = NetSpec(Do, H, 0, K, "gru")
+    params = flatten_params(init_params_like_torch(spec), dev)
+    obs = batch["obs"].permute(0, 2, 1, 3).contiguous().float().to(dev)       # [E,A,T,Do]
+    avail = batch["avail"].permute(0, 2, 1, 3).contiguous().to(torch.uint8).to(dev)
+    act = batch["actions"].permute(0, 2, 1).contiguous().to(torch.int32).to(dev)
+    lpo = batch["log_probs"].permute(0, 2, 1).contiguous().float().to(dev)
+    adv = torch.randn(E, A, T, device=dev)
+    eplen = batch["mask"].sum(1).to(torch.int32).to(dev)
+    h0 = torch.randn(E * A, H, device=dev) * 0.3
+    P = params.numel()
+    wsb = lib.cm_gru_workspace_bytes(E, A, Do, H, K, t1 - t0)
+    out = {}
+    for tile in ("auto", "32"):
+        N.set_option("gru_tile", tile)
+        g = torch.zeros(P + N.NUM_STATS, device=dev)
+        h1 = torch.zeros(E * A, H, device=dev)
+        ws = torch.zeros(wsb // 4 + 16, device=dev)
+        N.check(lib.cm_gru_actor_chunk_fwd_bwd(N.ptr(obs), N.ptr(avail), N.ptr(act), N.ptr(lpo), N.ptr(adv), N.ptr(eplen), E, A, T, t0, t1, Do,
+                                               H, K, N.ptr(params), N.ptr(h0), N.ptr(h1), 0.2, 0.01, N.ptr(g), N.ptr(ws), wsb, N.stream_ptr()),
+                "gru chunk")
+        torch.cuda.synchronize()
+        out[tile] = (g.clone(), h1.clone())
+    N.set_option("gru_tile", "auto")
+    assert torch.isfinite(out["auto"][0]).all()
+    assert torch.equal(out["auto"][0], out["32"][0]) and torch.equal(out["auto"][1], out["32"][1])
 
 
 def test_gru_policy_act_matches_oracle():

@@ -92,12 +92,20 @@ ph = prof.double().mean(0).cpu()
 tot = float(ph.sum())
 if which == "gru":
     CL = 10
-    for name, base, per, names in (("k_gru2_fwd", 0, CL, ["barrier_top", "gru2_step (fc1, 6 products, gates)", "-", "-", "-", "workspace stores",
-                                                         "head: barrier", "head: load h'", "head: logits", "head: ppo math", "head: dW2 + dh_head + store"]),
+    fwd4 = ["barrier_top", "gru2_step (fc1, 6 products, gates)", "-", "-", "-", "workspace stores",
+            "head: barrier", "head: load h'", "head: logits", "head: ppo math", "head: dW2 + dh_head + store"]
+    # eight-wave forward: thread 0 (recurrence) in slots 0..3, thread 256 (helpers) in slots 8..12; all per real step
+    fwd8 = ["r: wait top", "r: gru2_step (fc1, 6 products, gates)", "r: obs tile", "r: two drain steps", "-", "-", "-", "-",
+            "h: wait top", "h: I0 4 tile stores, relu h'", "h: wait x1", "h: I1 item loads, 2 tile stores", "h: wait h'", "h: I0 ppo math (odd steps)",
+            "h: I1 logits (even) | dW2 + dh_head (odd)"]
+    eight = os.environ.get("CM_GRU_TILE", "auto") != "32"
+    for name, base, per, names in (("k_gru2_fwd8" if eight else "k_gru2_fwd", 0, CL, fwd8 if eight else fwd4),
                                    ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives (s, registers) | weight gradients (s + 1)", "tile writes", "data path (3 blocks, reg B)", "dx1 / dh write"])):
         rows = prof[base:base + 512]
         used = rows[rows.sum(1) > 0].double()
         ph = used.mean(0).cpu(); tot = float(ph.sum())
+        if names is fwd8:
+            tot = float(ph[:8].sum())
         print(f"{name}: {used.shape[0]} workgroups, cycles per step (head phases: per 2-step pass) -- fwd+bwd launch pair {ms:.3f} ms")
         for i, n in enumerate(names):
             div = per if not n.startswith("head") else per / 2
