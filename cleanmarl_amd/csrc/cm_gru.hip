@@ -15,6 +15,7 @@
 // accumulators (W_ih, W_hh: 6 blocks, fc1, fc2) stay in registers for the whole chunk and are written once
 // per workgroup, then folded by k_reduce_partials.  Time is inherently sequential here; parallelism is over
 // sequences only (SURVEY.md §7 "hard parts" (e)).
+#include <atomic>
 #include "cm_mlp_train.h"
 #ifdef CM_PHASE_PROF
 extern unsigned long long* g_prof;
@@ -348,19 +349,21 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_fwd(const GruArgs a) {
 // 32-row tiles (cm_gru_v2.h, the fused rollout below): tile height and the register-staged obs tile
 constexpr int T32 = 32;
 
-// obs tile of 32 rows x din (<= 64) columns: 8 lanes per row, 8 columns each, register-staged one step ahead
+// obs tile of 32 rows x din (<= 64) columns, register-staged one step ahead by the four recurrence waves: wave w takes rows
+// 8w .. 8w+7, one row per load with lane = column, so an instruction touches the two or three cache lines of ONE row.  (The first
+// mapping -- 8 lanes per row, 8 columns each -- spread every instruction over ~24 lines of 8 rows and cost ~1.3 k cycles per step at
+// issue: profiles/r03_phase_gru.txt.)
 struct X32 { float v[8]; };
 __device__ __forceinline__ void x32_load(X32& x, const float* src, long row0, long nrows, long stride, int ncols) {
-    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
-    const bool rok = row0 + r < nrows;
-    const float* p = src + (row0 + r) * stride + c0;
+    const int lane = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+    const float* p = src + (row0 + r0) * stride + lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x.v[i] = (rok && c0 + i < ncols) ? p[i] : 0.0f;
+    for (int i = 0; i < 8; ++i) x.v[i] = (row0 + r0 + i < nrows && lane < ncols) ? p[i * stride] : 0.0f;
 }
 __device__ __forceinline__ void x32_store(float* XA, const X32& x) {
-    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
-    *reinterpret_cast<float4*>(XA + r * LDT + c0) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    *reinterpret_cast<float4*>(XA + r * LDT + c0 + 4) = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    const int lane = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) XA[(r0 + i) * LDT + lane] = x.v[i];
 }
 
 // ============================================================================================ fused GRU rollout
@@ -854,8 +857,20 @@ extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int 
     const size_t R = (size_t)E * A;
     if (gru_wide(din, hidden)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
     // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
-    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float);
+    // + the step flags of the pipelined forward sweep (k_gru2_fwdx: four 8-byte words per 32-row tile)
+    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8;
 }
+
+static int gru_device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 1;
+    }
+    return cus;
+}
+static std::atomic<unsigned> g_gru_tag{1};
 
 static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t* action,
                           const float* logp_old, const float* adv, const int32_t* ep_len,
@@ -911,14 +926,32 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #define CM_GRU2_F8(WV_, KP_) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwd8<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf8); \
         hipLaunchKernelGGL((k_gru2_fwd8<WV_, KP_>), dim3(grid32), dim3(NT8), lf8, (hipStream_t)stream, a); } while (0)
-        if (cm_option(CM_OPTION_GRU_TILE) == 32) {
+        // ... and, while the tiles leave a third of the CUs idle, the head on those CUs (k_gru2_fwdx: one head workgroup per two tiles)
+        const int tile_opt = cm_option(CM_OPTION_GRU_TILE);
+        const int nh = (int)((nt32 + 1) / 2);
+        GruXArgs xa = {};
+        xa.nt = (int)nt32; xa.nh = nh;
+        {
+            uintptr_t fp = reinterpret_cast<uintptr_t>(a.partial + (size_t)MAX_GRID * a.PS);
+            xa.flags = reinterpret_cast<unsigned long long*>((fp + 7) & ~(uintptr_t)7);
+        }
+        const size_t lfx = gru2_fwdx_lds_bytes(KP);
+#define CM_GRU2_FX(WV_, KP_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
+        hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
+        if (tile_opt == 32) {
             if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
             else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
+        } else if (tile_opt != 8 && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus()) {
+            xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
+            if (KP == 16) { if (wv) CM_GRU2_FX(true, 16); else CM_GRU2_FX(false, 16); }
+            else          { if (wv) CM_GRU2_FX(true, 32); else CM_GRU2_FX(false, 32); }
         } else {
             if (KP == 16) { if (wv) CM_GRU2_F8(true, 16); else CM_GRU2_F8(false, 16); }
             else          { if (wv) CM_GRU2_F8(true, 32); else CM_GRU2_F8(false, 32); }
         }
 #undef CM_GRU2_F8
+#undef CM_GRU2_FX
 #undef CM_GRU2_F
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);

@@ -691,6 +691,402 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwd8(const GruArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_gru2_fwdx: the forward sweep with the head on OTHER compute units.  Two waves of one SIMD share its matrix pipe and its VALU issue
+// slots, so inside a workgroup the head only trades places with the recurrence (k_gru2_fwd8 gains 3-6 %); but at the batch sizes these
+// sweeps serve the tiles do not fill the chip (config 5: 160 tiles on 256 CUs).  Here the launch has two kinds of workgroups:
+//   * blockIdx <  nt  "chain" workgroups, one tile each: waves 0-3 run the recurrence, waves 4-7 store the six workspace tiles of step
+//     s - 1 during step s and PUBLISH the step: h' leaves as agent-scope (sc1) stores, the wave waits for its own stores (vmcnt, off the
+//     chain) and sets its word of flags[tile][4] to {launch tag, steps published}.  No fence: an agent-scope release would write back the
+//     whole L2 (cm_optim.hip has the measurements); the data the consumer needs is written through by the stores themselves.
+//   * blockIdx >= nt  "head" workgroups on the CUs the tiles leave idle: each half (4 waves) follows one tile per round, waits for the
+//     flags of the two steps of a pass, reads their h' rows with agent-scope loads and runs the pass of k_gru2_fwd (logits -> PPO loss ->
+//     dlogits -> fc2 gradient -> dh_head) -- dh_head goes to the workspace for the backward sweep (next launch), the fc2 gradient and
+//     the statistics to the partial row of the head workgroup (the chain workgroups zero theirs).
+// Chain workgroups never wait for head workgroups and are dispatched first (lower blockIdx), so the launch cannot deadlock whatever
+// shares the device; a head workgroup gives up after a bounded number of polls and poisons its statistics with NaN.
+// Numerics: the arithmetic of k_gru2_fwd per item; the fc2 gradient / statistics are summed per head workgroup instead of per tile
+// (a different association of the same terms; everything else bit-identical).
+struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; };
+constexpr int GX_RED = 4 * 64 * 8 + 256;   // head workgroup's reduction scratch: half 1's fc2 accumulators (4 waves x 64 lanes x 8), b2 parts, statistics
+constexpr int g2fx_lds_floats(int KP) {
+    // chain workgroup: 9 tiles; head workgroup: per half HB + ls + ls2, shared wouts + b2 + red
+    return (9 * T32 * LDT > 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED) ? 9 * T32 * LDT : 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED;
+}
+inline size_t gru2_fwdx_lds_bytes(int KP) {
+    const size_t b = (size_t)g2fx_lds_floats(KP) * sizeof(float);
+    return b > 84 * 1024 ? b : 84 * 1024;   // > half of the CU's LDS: one workgroup per CU whatever the register count
+}
+__device__ __forceinline__ void st_agent64(float* p, float x, float y) {
+    unsigned long long v = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent64(const float* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+constexpr int GX_POLLS = 1 << 18;   // ~0.3 s of polling before a head workgroup gives up (a chunk sweep takes ~0.1 ms)
+
+template <int KP>
+__device__ __forceinline__ void gru2_head_wg(const GruArgs& a, const GruXArgs& x, float* smem) {
+    constexpr int KJ = KP / 4, NCT = KP / 16;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    const int hg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // half of the workgroup: its own tile, its own LDS buffers
+    const int tid = threadIdx.x & (NTHREADS - 1), lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, g = wave >> 1, h = lane >> 5, lc = lane & 31;
+    const int col = 32 * wn + lc;
+    float* p = smem + hg * (TM * LDT + 2 * TM * KP);
+    float* HB = p; p += TM * LDT;
+    float* ls = p; p += TM * KP;
+    float* ls2 = p;
+    p = smem + 2 * (TM * LDT + 2 * TM * KP);
+    float* wouts = p; p += KP * WLD;
+    float* b2 = p; p += KMAX;
+    float* red = p;   // GX_RED
+    const int H = a.H, K = a.K, T = a.T, CL = a.t1 - a.t0, NP = (CL + 1) >> 1;
+    const long R = (long)a.E * a.A;
+    for (int i = threadIdx.x; i < KP * WLD; i += NT8) {
+        const int k = i / WLD, c = i % WLD;
+        wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < KMAX; i += NT8) b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+    PH_DECL
+    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_cnt = 0.f;
+    f32x4 accWo[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accWo[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbo = 0.f;
+    bool dead = false;   // a poll ran out: stop waiting, poison the statistics
+    const int j = (int)blockIdx.x - x.nt;
+    const int rounds = (x.nt + 2 * x.nh - 1) / (2 * x.nh);
+    const int hrow = tid >> 2, hq = tid & 3;
+    const int irow = hrow & 31;
+    const float invA = 1.0f / (float)a.A;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int q = (rd * x.nh + j) * 2 + hg;          // this half's tile of the round
+        const bool tvalid = q < x.nt;
+        const long row0 = (long)q * T32;
+        const long grow = row0 + irow;
+        const bool rvalid = tvalid && grow < R;
+        const int e_row = rvalid ? (int)(grow / a.A) : 0;
+        const int ag = (int)(grow - (long)e_row * a.A);
+        const int eplen = rvalid ? a.ep_len[e_row] : 0;
+        const unsigned long long* fl = x.flags + (size_t)(tvalid ? q : 0) * 4;
+        for (int pss = 0; pss < NP; ++pss) {
+            const int s0 = 2 * pss;
+            // per-item inputs (4 lanes per (row, step) item)
+            const int s_it = s0 + (hrow >> 5), t_it = a.t0 + s_it;
+            const bool ivalid = rvalid && s_it < CL;
+            unsigned char avb[KJ];
+#pragma unroll
+            for (int jj = 0; jj < KJ; ++jj) {
+                avb[jj] = 1;
+                if (ivalid && 4 * jj + hq < K) avb[jj] = a.avail[(grow * T + t_it) * K + 4 * jj + hq];
+            }
+            const long o = grow * T + t_it;
+            const int act = ivalid ? a.action[o] : 0;
+            const float lpo = ivalid ? a.logp_old[o] : 0.f, advv = ivalid ? a.adv[o] : 0.f;
+            // wait until the chain workgroup has published both steps of the pass (each wave polls the four words itself)
+            if (tvalid && !dead) {
+                const unsigned want = (unsigned)(s0 + 2 < CL ? s0 + 2 : CL);
+                int it = 0;
+                for (;; ++it) {
+                    bool ok = true;
+                    if (lane < 4) {
+                        const unsigned long long v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(v >> 32) == x.tag && (unsigned)v >= want;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (it >= GX_POLLS) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            PH(0);
+            lds_barrier();  // HB / ls / ls2 of the previous pass are dead
+            // relu(h') of the two steps -> HB (agent-scope loads: the rows were written by another workgroup in this launch)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int idx = tid + NTHREADS * qq, it = idx >> 4, c4 = (idx & 15) * 4;
+                const int ss = s0 + (it >> 5), r = it & 31;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tvalid && !dead && ss < CL && row0 + r < R) {
+                    const float* src = a.ws_act + ((long)ss * R + row0 + r) * WS2 + 5 * HP + c4;
+                    const float2 lo = ld_agent64(src), hi = ld_agent64(src + 2);
+                    v = make_float4(fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f));
+                }
+                *reinterpret_cast<float4*>(HB + it * LDT + c4) = v;
+            }
+            PH(1);
+            lds_barrier();
+            {   // logits on the 16x16x4 MFMA: wave w = items 16w..16w+15, one call per 16 head outputs
+                const int n = lane & 15, g4 = lane >> 4;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const f32x4 lg = head_logits_mfma(HB + 16 * wave * LDT, wouts + 16 * ct * WLD);
+                    const float bias = b2[16 * ct + n];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ls[(16 * wave + 4 * g4 + qq) * KP + 16 * ct + n] = lg[qq] + bias;
+                }
+            }
+            PH(2);
+            lds_barrier();
+            {   // PPO clipped-surrogate head (arithmetic of k_gru_chunk_fwd): statistics + dlogits -> ls2
+                float zreg[KJ];
+#pragma unroll
+                for (int jj = 0; jj < KJ; ++jj) zreg[jj] = (4 * jj + hq < K && avb[jj]) ? ls[hrow * KP + 4 * jj + hq] : -1e9f;
+                const bool valid = ivalid && t_it < eplen;
+                float m = -INFINITY;
+#pragma unroll
+                for (int jj = 0; jj < KJ; ++jj) if (4 * jj + hq < K) m = fmaxf(m, zreg[jj]);
+                m = quad_max(m);
+                float ssum = 0.0f, pj[KJ];
+#pragma unroll
+                for (int jj = 0; jj < KJ; ++jj) { pj[jj] = 0.f; if (4 * jj + hq < K) { pj[jj] = expf(zreg[jj] - m); ssum += pj[jj]; } }
+                ssum = quad_sum(ssum);
+                const float lse = m + logf(ssum), rs = 1.0f / ssum;
+                float ent = 0.f, lpa = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < KJ; ++jj) if (4 * jj + hq < K) {
+                    const float lp = zreg[jj] - lse;
+                    pj[jj] *= rs; ent -= pj[jj] * lp;
+                    if (4 * jj + hq == act) lpa = lp;
+                }
+                ent = quad_sum(ent); lpa = quad_sum(lpa);
+                const float log_ratio = lpa - lpo, ratio = expf(log_ratio);
+                const float pg1 = advv * ratio, pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
+                const bool inr = (ratio >= a.clip_lo) && (ratio <= a.clip_hi);
+                float gsel;
+                if (pg1 < pg2) gsel = advv; else if (pg1 > pg2) gsel = inr ? advv : 0.f; else gsel = 0.5f * advv + (inr ? 0.5f * advv : 0.f);
+                if (valid && hq == 0) {
+                    st_pg += invA * fminf(pg1, pg2); st_ent += invA * ent; st_kl += invA * ((ratio - 1.f) - log_ratio);
+                    st_clip += (fabsf(ratio - 1.f) > a.clip_eps) ? invA : 0.f;
+                    if (ag == 0) st_cnt += 1.f;
+                }
+                const float gr = gsel * ratio;
+#pragma unroll
+                for (int jj = 0; jj < KJ; ++jj) {
+                    const int k = 4 * jj + hq;
+                    float d = 0.f;
+                    if (k < K && valid && zreg[jj] > -5e8f) {
+                        const float lp = zreg[jj] - lse;
+                        d = invA * (-gr * ((k == act ? 1.f : 0.f) - pj[jj]) + a.ent_coef * pj[jj] * (lp + ent));
+                    }
+                    ls2[hrow * KP + k] = d;
+                }
+            }
+            PH(3);
+            lds_barrier();
+            // fc2 gradient: dW2 += dlogits^T relu(h') over the 64 items (wave = 16 hidden columns), db2 += column sums
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) colred_head16<KP>(accWo[ct], ls2, 16 * ct, HB + 16 * wave);
+            {
+                constexpr int PARTS = NTHREADS / KP, RPP = TM / PARTS;
+                const int k = tid % KP, part = tid / KP;
+                float sb = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) sb += ls2[(part * RPP + r) * KP + k];
+                dbo += sb;
+            }
+            // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .. (step s0 + g), columns 32 wn ..; straight to the workspace
+            f32x16 dh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dh[i] = 0.0f;
+            head_bwd_mfma<KP>(dh, ls2 + 32 * g * KP, wouts + 32 * wn);
+            const int ss = s0 + g;
+            if (tvalid && ss < CL) {
+                float* wsD = a.ws_act + ((long)ss * R + row0) * WS2 + 6 * HP + col;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row0 + r < R) wsD[(long)r * WS2] = (HB[(32 * g + r) * LDT + col] > 0.0f) ? dh[i] : 0.0f;
+                }
+            }
+            PH(4);
+        }
+    }
+#ifdef CM_PHASE_PROF
+    if (a.prof && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) a.prof[(size_t)blockIdx.x * 16 + i_] = ph_[i_]; }
+#endif
+    // ================================ partial row of this head workgroup: fc2 gradient + statistics of the tiles its two halves followed
+    float* out = a.partial + (size_t)j * a.PS;
+    __syncthreads();
+    {
+        const int n = lane & 15, g4 = lane >> 4;
+        float* rw = red + (size_t)wave * 64 * 4 * NCT;   // half 1 hands its accumulators to half 0
+        if (hg == 1) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[(ct * 4 + r) * 64 + lane] = accWo[ct][r];
+        }
+        __syncthreads();
+        if (hg == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * ct + 4 * g4 + r, c = 16 * wave + n;
+                    if (k < K && c < H) out[off.W2 + k * H + c] = accWo[ct][r] + rw[(ct * 4 + r) * 64 + lane];
+                }
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = dbo;  // [2 halves][NTHREADS / KP parts][KP]
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float sb = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < NT8 / KP; ++qq) sb += red[qq * KP + threadIdx.x];
+        out[off.b2 + threadIdx.x] = sb;
+    }
+    float sv6[6] = {st_pg, st_ent, st_kl, st_clip, 0.f, st_cnt};
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 6; ++qq) {
+        const float v = cm_wave_sum(sv6[qq]);
+        if (lane == 0) red[qq * 8 + (threadIdx.x >> 6)] = v;
+    }
+    if (threadIdx.x == 0) red[64] = 0.f;   // (statistics occupy red[0 .. 47])
+    __syncthreads();
+    if (dead && lane == 0) red[64] = 1.f;
+    __syncthreads();
+    if (threadIdx.x < CM_NUM_STATS) {
+        float v = 0.f;
+        if (threadIdx.x < 6) {
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) v += red[threadIdx.x * 8 + w8];
+        }
+        if (red[64] != 0.f) v = __builtin_nanf("");
+        out[off.P + threadIdx.x] = v;
+    }
+}
+
+template <bool WV, int KP>
+__global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXArgs x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef CM_X_NOHEAD
+    if ((int)blockIdx.x >= x.nt) return;
+#endif
+    if ((int)blockIdx.x >= x.nt) { gru2_head_wg<KP>(a, x, smem); return; }
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* X0 = p; p += T32 * LDT;    // obs tile of the step
+    float* X1a = p; p += T32 * LDT;   // x1 = relu(fc1(obs)), even steps
+    float* X1b = p; p += T32 * LDT;   //                     odd steps
+    float* hp = p; p += T32 * LDT;    // h_{t-1}
+    float* hn = p; p += T32 * LDT;    // h_t
+    float* SR = p; p += T32 * LDT;
+    float* SZ = p; p += T32 * LDT;
+    float* SN = p; p += T32 * LDT;
+    float* SG = p;                    // W_hn h + b_hn
+    const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // wave-uniform, and the compiler must know it
+    const int tid = threadIdx.x & (NTHREADS - 1), lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const long row0 = (long)blockIdx.x * T32;
+    PH_DECL
+    if (!helper) {
+        // ================================================================ waves 0-3: the recurrence, 3 barriers per step (gru2_step)
+        G2W w;
+        g2_load_weights<WV>(w, a.params, off, din, H);
+        for (int i = tid; i < T32 * HP; i += NTHREADS) {
+            const int r = i >> 6, c = i & 63;
+            hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+        }
+        X32 xr;
+        x32_load(xr, a.obs + (long)a.t0 * din, row0, R, (long)T * din, din);
+        x32_store(X0, xr);
+        if (CL > 1) x32_load(xr, a.obs + (long)(a.t0 + 1) * din, row0, R, (long)T * din, din);
+        for (int s = 0; s <= CL; ++s) {
+            lds_barrier();  // X0 = obs(t), hp = h_{t-1}
+            PH(0);
+            if (s < CL) {
+                gru2_step<true>(w, X0, (s & 1) ? X1b : X1a, hp, hn, SR, SZ, SN, SG, din, H);
+                PH(1);
+#ifndef CM_X_NOOBS
+#ifndef CM_X_NOOBSST
+                if (s + 1 < CL) x32_store(X0, xr);
+#endif
+#ifndef CM_X_NOOBSLD
+                if (s + 2 < CL) x32_load(xr, a.obs + (long)(a.t0 + s + 2) * din, row0, R, (long)T * din, din);
+#endif
+#endif
+                float* tmp = hp; hp = hn; hn = tmp;
+                PH(2);
+            } else {
+                if (a.h_out)
+                    for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                        const int r = i >> 6, c = i & 63;
+                        if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+                    }
+                lds_barrier();
+                lds_barrier();
+                PH(3);
+            }
+        }
+    } else {
+        // ================================================================ waves 4-7: the tiles of step s - 1 leave during step s; publish
+        unsigned long long* fl = x.flags + (size_t)blockIdx.x * 4 + wave;
+        for (int s = 0; s <= CL; ++s) {
+            const int sp = s - 1;
+            float* wsS = a.ws_act + ((long)sp * R + row0) * WS2;
+            lds_barrier();
+            PH(8);
+#ifdef CM_X_NOHEAD
+            if (false) {
+#else
+            if (sp >= 0) {
+#endif
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                    if (row0 + r < R) {
+                        float* wp = wsS + (long)r * WS2 + c4;
+                        const int o = r * LDT + c4;
+                        const float4 hv = *reinterpret_cast<const float4*>(hp + o);   // h' first: it is what the head workgroups wait for
+                        st_agent64(wp + 5 * HP, hv.x, hv.y);
+                        st_agent64(wp + 5 * HP + 2, hv.z, hv.w);
+                        *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(SR + o);
+                        *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(SZ + o);
+                        *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(SN + o);
+                        *reinterpret_cast<float4*>(wp + 4 * HP) = *reinterpret_cast<const float4*>(SG + o);
+                    }
+                }
+            }
+            PH(9);
+            lds_barrier();
+            PH(10);
+#ifdef CM_X_NOHEAD
+            if (false) {
+#else
+            if (sp >= 0) {
+#endif
+                const float* X1 = (sp & 1) ? X1b : X1a;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                    if (row0 + r < R) *reinterpret_cast<float4*>(wsS + (long)r * WS2 + c4) = *reinterpret_cast<const float4*>(X1 + r * LDT + c4);
+                }
+                // this wave's stores of the step are acknowledged (the h' rows were issued an interval ago): publish it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(fl, ((unsigned long long)x.tag << 32) | (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            PH(11);
+            lds_barrier();
+            PH(12);
+            if (s < CL) { float* tmp = hp; hp = hn; hn = tmp; }
+        }
+    }
+    PH8_FLUSH();
+    // the fc2 gradient / statistics columns of this row are summed by the head workgroups (rows 0 .. nh - 1): zero them from nh on
+    if ((int)blockIdx.x >= x.nh) {
+        float* out = a.partial + (size_t)blockIdx.x * a.PS;
+        for (int i = threadIdx.x; i < a.K * H; i += NT8) out[off.W2 + i] = 0.0f;
+        if (threadIdx.x < a.K) out[off.b2 + threadIdx.x] = 0.0f;
+        if (threadIdx.x < CM_NUM_STATS) out[off.P + threadIdx.x] = 0.0f;
+    }
+}
+
 // transposed tiles [64 columns][32 rows] with row stride LTT: the operands of the weight-gradient MFMAs (contraction over the tile's
 // rows) come out of them as 16-byte reads, four MFMAs per pair of reads, instead of two 4-byte reads per MFMA
 constexpr int LTT = 36;

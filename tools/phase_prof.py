@@ -98,8 +98,20 @@ if which == "gru":
     fwd8 = ["r: wait top", "r: gru2_step (fc1, 6 products, gates)", "r: obs tile", "r: two drain steps", "-", "-", "-", "-",
             "h: wait top", "h: I0 4 tile stores, relu h'", "h: wait x1", "h: I1 item loads, 2 tile stores", "h: wait h'", "h: I0 ppo math (odd steps)",
             "h: I1 logits (even) | dW2 + dh_head (odd)"]
-    eight = os.environ.get("CM_GRU_TILE", "auto") != "32"
-    for name, base, per, names in (("k_gru2_fwd8" if eight else "k_gru2_fwd", 0, CL, fwd8 if eight else fwd4),
+    tile_opt = os.environ.get("CM_GRU_TILE", "auto")
+    eight = tile_opt != "32"
+    nt = (E * A + 31) // 32
+    if tile_opt == "auto" and nt + (nt + 1) // 2 <= 256:  # k_gru2_fwdx: chain workgroups in rows [0, nt), head workgroups behind them
+        fwd8 = ["r: wait top", "r: gru2_step (fc1, 6 products, gates)", "r: obs tile", "r: drain step", "-", "-", "-", "-",
+                "h: wait top", "h: I0 h' (agent scope) + 4 tile stores", "h: wait x1", "h: I1 x1 store, vmcnt(0), publish", "h: wait h'"]
+        rows = prof[nt:nt + (nt + 1) // 2].double()
+        ph = rows.mean(0).cpu()
+        print(f"k_gru2_fwdx head workgroups: {rows.shape[0]}, cycles per 2-step pass")
+        for i, n in enumerate(["items + wait for the flags", "barrier, h' (agent scope) -> HB", "barrier, logits", "barrier, ppo math", "barrier, dW2 + dh_head"]):
+            print(f"  {n:34s} {float(ph[i]) / (CL / 2):10.1f}")
+        print(f"  total cycles/WG {float(ph[:8].sum()):.0f}")
+        prof[nt:512] = 0
+    for name, base, per, names in (("k_gru2_fwd8/x" if eight else "k_gru2_fwd", 0, CL, fwd8 if eight else fwd4),
                                    ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives (s, registers) | weight gradients (s + 1)", "tile writes", "data path (3 blocks, reg B)", "dx1 / dh write"])):
         rows = prof[base:base + 512]
         used = rows[rows.sum(1) > 0].double()
