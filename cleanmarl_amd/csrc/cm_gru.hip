@@ -857,8 +857,8 @@ extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int 
     const size_t R = (size_t)E * A;
     if (gru_wide(din, hidden)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
     // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
-    // + the step flags of the pipelined forward sweep (k_gru2_fwdx: four 8-byte words per 32-row tile)
-    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8;
+    // + the pipelined sweeps' hand-over areas: step flags of k_gru2_fwdx (four 8-byte words per 32-row tile), {dh_t, tag} words of k_gru2_bwd<true>
+    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8 + (size_t)chunk_len * R * HP * 8;
 }
 
 static int gru_device_cus() {
@@ -929,6 +929,7 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         // ... and, while the tiles leave a third of the CUs idle, the head on those CUs (k_gru2_fwdx: one head workgroup per two tiles)
         const int tile_opt = cm_option(CM_OPTION_GRU_TILE);
         const int nh = (int)((nt32 + 1) / 2);
+        const bool pipelined = tile_opt == 0 && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
         GruXArgs xa = {};
         xa.nt = (int)nt32; xa.nh = nh;
         {
@@ -942,7 +943,7 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         if (tile_opt == 32) {
             if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
             else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
-        } else if (tile_opt != 8 && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus()) {
+        } else if (pipelined) {
             xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
             if (KP == 16) { if (wv) CM_GRU2_FX(true, 16); else CM_GRU2_FX(false, 16); }
             else          { if (wv) CM_GRU2_FX(true, 32); else CM_GRU2_FX(false, 32); }
@@ -953,10 +954,26 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #undef CM_GRU2_F8
 #undef CM_GRU2_FX
 #undef CM_GRU2_F
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-        hipLaunchKernelGGL(k_gru2_bwd, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a);
+        // backward: likewise, five of the seven weight-gradient products of a step on the idle CUs (k_gru2_bwd<true> / gru2_grad_wg: as many
+        // workgroups as CUs are left, at most one per tile; their partial rows follow those of the tiles)
+        int ng = 0;
+        if (pipelined) {
+            ng = gru_device_cus() - (int)nt32;
+            if (ng > (int)nt32) ng = (int)nt32;
+            if ((long)nt32 + ng > MAX_GRID) ng = MAX_GRID - (int)nt32;
+        }
+        if (ng > 0) {
+            GruXArgs xb = xa;
+            xb.dhq = xa.flags + (size_t)MAX_GRID * 4;
+            xb.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL(k_gru2_bwd<true>, dim3(grid32 + ng), dim3(NTHREADS), lb, (hipStream_t)stream, a, xb);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL(k_gru2_bwd<false>, dim3(grid32), dim3(NTHREADS), lb, (hipStream_t)stream, a, xa);
+        }
         CM_CHECK_LAUNCH("cm_gru_actor_chunk_fwd_bwd");
-        return finish_train(m, grid32, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
+        return finish_train(m, grid32 + ng, P, grad_and_stats, (hipStream_t)stream, "cm_gru_actor_chunk_fwd_bwd", 0, opt);
     }
     if (n_actions <= 8) { if (wv) CM_GRU_LAUNCH2(2, true); else CM_GRU_LAUNCH2(2, false); }
     else { if (wv) CM_GRU_LAUNCH2(8, true); else CM_GRU_LAUNCH2(8, false); }

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwd8(const GruArgs a) {
 // slots, so inside a workgroup the head only trades places with the recurrence (k_gru2_fwd8 gains 3-6 %); but at the batch sizes these
 // sweeps serve the tiles do not fill the chip (config 5: 160 tiles on 256 CUs).  Here the launch has two kinds of workgroups:
 //   * blockIdx <  nt  "chain" workgroups, one tile each: waves 0-3 run the recurrence, waves 4-7 store the six workspace tiles of step
-//     s - 1 during step s and PUBLISH the step: h' leaves as agent-scope (sc1) stores, the wave waits for its own stores (vmcnt, off the
+//     s - 1 during step s and PUBLISH the step: h' leaves first, as agent-scope (sc1) stores, the wave waits for them (vmcnt, off the
 //     chain) and sets its word of flags[tile][4] to {launch tag, steps published}.  No fence: an agent-scope release would write back the
 //     whole L2 (cm_optim.hip has the measurements); the data the consumer needs is written through by the stores themselves.
 //   * blockIdx >= nt  "head" workgroups on the CUs the tiles leave idle: each half (4 waves) follows one tile per round, waits for the
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwd8(const GruArgs a) {
 // shares the device; a head workgroup gives up after a bounded number of polls and poisons its statistics with NaN.
 // Numerics: the arithmetic of k_gru2_fwd per item; the fc2 gradient / statistics are summed per head workgroup instead of per tile
 // (a different association of the same terms; everything else bit-identical).
-struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; };
+struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; unsigned long long* dhq; };  // dhq: [CL][R][64] {dh_t, tag} words (backward)
 constexpr int GX_RED = 4 * 64 * 8 + 256;   // head workgroup's reduction scratch: half 1's fc2 accumulators (4 waves x 64 lanes x 8), b2 parts, statistics
 constexpr int g2fx_lds_floats(int KP) {
     // chain workgroup: 9 tiles; head workgroup: per half HB + ls + ls2, shared wouts + b2 + red
@@ -786,35 +786,43 @@ __device__ __forceinline__ void gru2_head_wg(const GruArgs& a, const GruXArgs& x
             const long o = grow * T + t_it;
             const int act = ivalid ? a.action[o] : 0;
             const float lpo = ivalid ? a.logp_old[o] : 0.f, advv = ivalid ? a.adv[o] : 0.f;
-            // wait until the chain workgroup has published both steps of the pass (each wave polls the four words itself)
-            if (tvalid && !dead) {
-                const unsigned want = (unsigned)(s0 + 2 < CL ? s0 + 2 : CL);
-                int it = 0;
-                for (;; ++it) {
-                    bool ok = true;
-                    if (lane < 4) {
-                        const unsigned long long v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (unsigned)(v >> 32) == x.tag && (unsigned)v >= want;
+            // the two steps of the pass as the chain workgroup publishes them (each wave polls the four words itself): the rows of the
+            // first step are on their way while the second is still being computed.  Agent-scope loads: the rows were written by
+            // another workgroup in this launch
+            float4 hv[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned want = (unsigned)(s0 + half + 1 < CL ? s0 + half + 1 : CL);
+                if (tvalid && !dead) {
+                    for (int it = 0;; ++it) {
+                        bool ok = true;
+                        if (lane < 4) {
+                            const unsigned long long v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (unsigned)(v >> 32) == x.tag && (unsigned)v >= want;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (it >= GX_POLLS) { dead = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                    if (it >= GX_POLLS) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(4);
+                }
+#pragma unroll
+                for (int qq = 2 * half; qq < 2 * half + 2; ++qq) {
+                    const int idx = tid + NTHREADS * qq, it = idx >> 4, c4 = (idx & 15) * 4;
+                    const int ss = s0 + (it >> 5), r = it & 31;   // it >> 5 == half
+                    hv[qq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tvalid && !dead && ss < CL && row0 + r < R) {
+                        const float* src = a.ws_act + ((long)ss * R + row0 + r) * WS2 + 5 * HP + c4;
+                        const float2 lo = ld_agent64(src), hi = ld_agent64(src + 2);
+                        hv[qq] = make_float4(fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f));
+                    }
                 }
             }
             PH(0);
             lds_barrier();  // HB / ls / ls2 of the previous pass are dead
-            // relu(h') of the two steps -> HB (agent-scope loads: the rows were written by another workgroup in this launch)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int idx = tid + NTHREADS * qq, it = idx >> 4, c4 = (idx & 15) * 4;
-                const int ss = s0 + (it >> 5), r = it & 31;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tvalid && !dead && ss < CL && row0 + r < R) {
-                    const float* src = a.ws_act + ((long)ss * R + row0 + r) * WS2 + 5 * HP + c4;
-                    const float2 lo = ld_agent64(src), hi = ld_agent64(src + 2);
-                    v = make_float4(fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f));
-                }
-                *reinterpret_cast<float4*>(HB + it * LDT + c4) = v;
+                *reinterpret_cast<float4*>(HB + it * LDT + c4) = hv[qq];
             }
             PH(1);
             lds_barrier();
@@ -887,19 +895,24 @@ __device__ __forceinline__ void gru2_head_wg(const GruArgs& a, const GruXArgs& x
                 for (int r = 0; r < RPP; ++r) sb += ls2[(part * RPP + r) * KP + k];
                 dbo += sb;
             }
-            // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .. (step s0 + g), columns 32 wn ..; straight to the workspace
+            // dh_head = (dlogits W2) .* (h' > 0): wave (g, wn) = items 32 g .. (step s0 + g), columns 32 wn ..
             f32x16 dh;
 #pragma unroll
             for (int i = 0; i < 16; ++i) dh[i] = 0.0f;
             head_bwd_mfma<KP>(dh, ls2 + 32 * g * KP, wouts + 32 * wn);
-            const int ss = s0 + g;
-            if (tvalid && ss < CL) {
-                float* wsD = a.ws_act + ((long)ss * R + row0) * WS2 + 6 * HP + col;
+            lds_barrier();  // every read of HB (fc2 gradient) is done: it becomes the dh_head tile
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (row0 + r < R) wsD[(long)r * WS2] = (HB[(32 * g + r) * LDT + col] > 0.0f) ? dh[i] : 0.0f;
-                }
+            for (int i = 0; i < 16; ++i) {
+                float* qd = HB + (32 * g + (i & 3) + 8 * (i >> 2) + 4 * h) * LDT + col;
+                *qd = (*qd > 0.0f) ? dh[i] : 0.0f;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int idx = tid + NTHREADS * qq, it = idx >> 4, c4 = (idx & 15) * 4;
+                const int ss = s0 + (it >> 5), r = it & 31;
+                if (tvalid && ss < CL && row0 + r < R)
+                    *reinterpret_cast<float4*>(a.ws_act + ((long)ss * R + row0 + r) * WS2 + 6 * HP + c4) = *reinterpret_cast<const float4*>(HB + it * LDT + c4);
             }
             PH(4);
         }
@@ -1037,15 +1050,26 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXAr
 #else
             if (sp >= 0) {
 #endif
+                // h' first, alone: it is what the head workgroups wait for.  The wave waits for its own stores (the older ones are a
+                // step old) and publishes the step; everything else follows
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                    if (row0 + r < R) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hp + r * LDT + c4);
+                        float* wp = wsS + (long)r * WS2 + 5 * HP + c4;
+                        st_agent64(wp, hv.x, hv.y);
+                        st_agent64(wp + 2, hv.z, hv.w);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(fl, ((unsigned long long)x.tag << 32) | (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
                     if (row0 + r < R) {
                         float* wp = wsS + (long)r * WS2 + c4;
                         const int o = r * LDT + c4;
-                        const float4 hv = *reinterpret_cast<const float4*>(hp + o);   // h' first: it is what the head workgroups wait for
-                        st_agent64(wp + 5 * HP, hv.x, hv.y);
-                        st_agent64(wp + 5 * HP + 2, hv.z, hv.w);
                         *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(SR + o);
                         *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(SZ + o);
                         *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(SN + o);
@@ -1067,9 +1091,6 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXAr
                     const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
                     if (row0 + r < R) *reinterpret_cast<float4*>(wsS + (long)r * WS2 + c4) = *reinterpret_cast<const float4*>(X1 + r * LDT + c4);
                 }
-                // this wave's stores of the step are acknowledged (the h' rows were issued an interval ago): publish it
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(fl, ((unsigned long long)x.tag << 32) | (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             PH(11);
             lds_barrier();
@@ -1121,14 +1142,149 @@ __device__ __forceinline__ void rowpar_rb_t(f32x16& acc, const float* GT, const 
 constexpr int G2B_TILES = 8;  // per set: G0T G1T G2T G3T X1T HPT OBT D1T
 inline size_t gru2_bwd_lds_bytes() { return (size_t)(5 * T32 * LDT + G2B_TILES * HP * LTT + 2 * NTHREADS) * sizeof(float); }
 
+// Weight-gradient workgroups of the pipelined backward sweep (k_gru2_bwd<true>): on the CUs the tiles leave idle.  The chain workgroups
+// publish dh_t (the carried gradient plus the head's share) of every step but the last one processed as self-certifying 64-bit words
+// {value, launch tag} (agent-scope stores, no flag, no wait on the chain); a unit of work here is one (tile, step):
+// reload the step's activations (written by the forward launch), redo the element-wise gate derivatives from dh_t, lay the operands
+// out as transposed tiles and run five of the seven weight-gradient products (W_ih x 3, W_hr, W_hz) -- the chain keeps dW_1 and dW_hn,
+// which fit under its own element-wise phase.  Units are dealt round-robin in publication order (u = step-from-the-end * tiles + tile,
+// workgroup u mod ng), so every workgroup lags the chain by the same amount whatever the tile count.
+
+__device__ __forceinline__ void gru2_grad_wg(const GruArgs& a, const GruXArgs& x, float* smem) {
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* S = smem;   // 5 transposed tiles [64][LTT]
+    float *G0T = S, *G1T = S + HP * LTT, *G2T = S + 2 * HP * LTT, *X1T = S + 3 * HP * LTT, *HPT = S + 4 * HP * LTT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, role = wave >> 1, h = lane >> 5, lc = lane & 31;
+    const int H = a.H, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const int col = 32 * wn + lc;
+    const int ec = tid & 63, er0 = 8 * (tid >> 6);
+    f32x16 accWih[3], accWhh[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) accWih[q][i] = 0.f;
+        accWhh[0][i] = 0.f; accWhh[1][i] = 0.f;
+    }
+    PH_DECL
+#ifdef CM_PHASE_PROF
+    const unsigned long long ph_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
+#endif
+    const int g = (int)blockIdx.x - x.nt, ng = (int)gridDim.x - x.nt;
+    const long U = (long)x.nt * (CL - 1);
+    bool dead = false;
+    struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8]; } P;
+    auto load_stable = [&](long u) {   // everything of the unit that the forward launch wrote
+        const int q = (int)(u % x.nt), s = CL - 1 - (int)(u / x.nt);
+        const long row0 = (long)q * T32;
+        const float* wsS = a.ws_act + ((long)s * R + row0) * WS2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = er0 + e;
+            const float* w = wsS + (long)r * WS2;
+            P.x1[e] = P.rr[e] = P.zz[e] = P.nn[e] = P.ghn[e] = P.hprev[e] = 0.0f;
+            if (row0 + r < R && ec < H) {
+                P.x1[e] = w[ec]; P.rr[e] = w[HP + ec]; P.zz[e] = w[2 * HP + ec]; P.nn[e] = w[3 * HP + ec]; P.ghn[e] = w[4 * HP + ec];
+                P.hprev[e] = a.ws_act[((long)(s - 1) * R + row0 + r) * WS2 + 5 * HP + ec];   // s >= 1 here
+            }
+        }
+    };
+    // dh_t of a unit: 64-bit words {value, launch tag} that the chain workgroup stores with agent scope.  A word certifies itself, so
+    // the loads can be issued long before the unit is due (under the products of the unit before) and simply repeated if a tag is still
+    // missing -- one round trip to memory (~2 us under this load) per unit, hidden, where a flag followed by the data costs two in a row
+    unsigned long long dq[8];
+    auto load_dh = [&](long u) {
+        const int q = (int)(u % x.nt), s = CL - 1 - (int)(u / x.nt);
+        const long row0 = (long)q * T32;
+        const unsigned long long* wd = x.dhq + ((long)s * R + row0) * HP + ec;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dq[e] = (unsigned long long)x.tag << 32;   // rows / columns outside the tile: valid, zero
+            if (row0 + er0 + e < R && ec < H) dq[e] = __hip_atomic_load(wd + (long)(er0 + e) * HP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto have_dh = [&]() -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ok = ok && (unsigned)(dq[e] >> 32) == x.tag;
+        return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+    };
+    if (g < U) { load_stable(g); load_dh(g); }
+    for (long u = g; u < U; u += ng) {
+        const long un = u + ng;
+        const bool has_next = un < U;
+        if (!dead) {
+            for (int it = 0; !have_dh(); ++it) {
+                if (it >= GX_POLLS) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+                load_dh(u);
+            }
+        }
+        PH(0);
+        float v0[8], v1[8], v2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // the element-wise arithmetic of the chain (k_gru2_bwd), same order
+            const float rr = P.rr[e], zz = P.zz[e], nn = P.nn[e], ghn = P.ghn[e], hprev = P.hprev[e];
+            const float dh = dead ? 0.0f : __uint_as_float((unsigned)dq[e]);
+            const float dn = dh * (1.0f - zz), dzg = dh * (hprev - nn);
+            const float dn_pre = dn * (1.0f - nn * nn);
+            v0[e] = dn_pre * ghn * rr * (1.0f - rr); v1[e] = dzg * zz * (1.0f - zz); v2[e] = dn_pre;
+        }
+        lds_barrier();  // the products of the previous unit have read the tiles
+        {
+            const int ot = ec * LTT + er0;
+#define CM_ST8(dst, v) do { *reinterpret_cast<float4*>(dst + ot) = make_float4(v[0], v[1], v[2], v[3]); \
+                            *reinterpret_cast<float4*>(dst + ot + 4) = make_float4(v[4], v[5], v[6], v[7]); } while (0)
+            CM_ST8(G0T, v0); CM_ST8(G1T, v1); CM_ST8(G2T, v2); CM_ST8(X1T, P.x1); CM_ST8(HPT, P.hprev);
+#undef CM_ST8
+        }
+        if (has_next) { load_dh(un); load_stable(un); }   // under the products
+        PH(1);
+        lds_barrier();
+        PH(2);
+        colred32t(accWih[0], G0T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWih[1], G1T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWih[2], G2T + 32 * role * LTT, X1T + 32 * wn * LTT);
+        colred32t(accWhh[0], G0T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accWhh[1], G1T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        PH(3);
+    }
+#ifdef CM_PHASE_PROF
+    ph_[7] = __builtin_amdgcn_s_memrealtime(); ph_[6] = ph_start;
+    if (a.prof && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) a.prof[(size_t)(512 + blockIdx.x) * 16 + i_] = ph_[i_]; }
+#endif
+    // ================================ this workgroup's partial row (behind the rows of the chain workgroups): its five blocks, zero elsewhere
+    float* out = a.partial + (size_t)blockIdx.x * a.PS;
+    const float poison = dead ? __builtin_nanf("") : 0.0f;
+    for (int i = tid; i < a.PS; i += NTHREADS) {
+        const bool mine = (i >= off.Wih && i < off.Whh + 2 * H * H);   // W_ih (3 blocks), W_hr, W_hz
+        if (!mine) out[i] = (i >= off.P && i < off.P + CM_NUM_STATS) ? poison : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = 32 * role + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (n < H && col < H) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) out[off.Wih + (q * H + n) * H + col] = accWih[q][i];
+            out[off.Whh + n * H + col] = accWhh[0][i];
+            out[off.Whh + (H + n) * H + col] = accWhh[1][i];
+        }
+    }
+}
+
 // Backward sweep.  The recurrence of a step is: gate derivatives (element-wise, needs dh) -> data path (dx1 / dh_prev = dG W, 96 MFMAs
 // per wave) -> dh.  The weight gradients of the step (112 MFMAs per wave) are NOT on that chain: they are issued one step LATER, in the
 // barrier interval in which the NEXT step's gate derivatives are computed -- into registers, so that the tiles the MFMAs read stay
 // intact -- and the matrix pipe works through them while the VALU produces the derivatives; the tiles of the new step are written
 // after the next barrier.  Three barriers per step (twelve in the first generation).  Weight-gradient operands come from transposed
 // [column][row] tiles (16-byte reads along the contracted rows), the data path reads row-major tiles and register weights.
-__global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
+// XG (pipelined): five of the seven weight-gradient products of every step but the last one processed run on other CUs (gru2_grad_wg
+// above: workgroups blockIdx >= x.nt); the chain workgroups publish dh_t for them and keep dW_1 and dW_hn.  x is unused without XG.
+template <bool XG>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a, const GruXArgs x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (XG && (int)blockIdx.x >= x.nt) { gru2_grad_wg(a, x, smem); return; }
     const GruOff off = gru_offsets(a.din, a.H, a.K);
     float* DH = smem;                                   // row-major [32][LDT]: dh carried backwards
     float* G0 = DH + T32 * LDT;                         // row-major pre-activation gradients of the step (data path)
@@ -1159,6 +1315,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
         for (int q = 0; q < 3; ++q) { accWih[q][i] = 0.f; accWhh[q][i] = 0.f; }
     }
     PH_DECL
+#ifdef CM_PHASE_PROF
+    const unsigned long long ph_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the whole device
+#endif
     const long ntiles = (R + T32 - 1) / T32;
     struct Pre { float x1[8], rr[8], zz[8], nn[8], ghn[8], hprev[8], dhh[8], ob[8]; } P;
     // weight gradients of the step whose tiles are in LDS
@@ -1168,6 +1327,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
         colred32t(accWih[2], G2T + 32 * role * LTT, X1T + 32 * wn * LTT);
         colred32t(accWhh[0], G0T + 32 * role * LTT, HPT + 32 * wn * LTT);
         colred32t(accWhh[1], G1T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accWhh[2], G3T + 32 * role * LTT, HPT + 32 * wn * LTT);
+        colred32t(accW1, D1T + 32 * role * LTT, OBT + 32 * wn * LTT);
+        const float4 u = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0), w4 = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0 + 4);
+        db1 += ((u.x + u.y) + (u.z + u.w)) + ((w4.x + w4.y) + (w4.z + w4.w));
+    };
+    auto wgrad2 = [&]() {   // XG: what the chain keeps of a published step
         colred32t(accWhh[2], G3T + 32 * role * LTT, HPT + 32 * wn * LTT);
         colred32t(accW1, D1T + 32 * role * LTT, OBT + 32 * wn * LTT);
         const float4 u = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0), w4 = *reinterpret_cast<const float4*>(D1T + ec * LTT + er0 + 4);
@@ -1211,9 +1376,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
                 const float dn_pre = dn * (1.0f - nn * nn);
                 v0[e] = dn_pre * ghn * rr * (1.0f - rr); v1[e] = dzg * zz * (1.0f - zz); v2[e] = dn_pre; v3[e] = dn_pre * rr;
                 DH[o] = dh * zz;
+                if (XG && s > 0 && row0 + er0 + e < R && ec < H)   // {dh_t, launch tag} for the weight-gradient workgroups: fire and forget
+                    __hip_atomic_store(x.dhq + ((long)s * R + row0 + er0 + e) * HP + ec, ((unsigned long long)x.tag << 32) | __float_as_uint(dh),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // ---- ... while the matrix pipe works through the weight gradients of step s + 1 (independent of the lines above)
-            if (s + 1 < CL) wgrad();
+            if (s + 1 < CL) { if (XG) wgrad2(); else wgrad(); }
             lds_barrier();  // every read of the tiles of step s + 1 is done
             PH(1);
             {   // tiles of step s: row-major for the data path, transposed for the weight gradients
@@ -1225,8 +1393,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
                 const int ot = ec * LTT + er0;
 #define CM_ST8(dst, v) do { *reinterpret_cast<float4*>(dst + ot) = make_float4(v[0], v[1], v[2], v[3]); \
                             *reinterpret_cast<float4*>(dst + ot + 4) = make_float4(v[4], v[5], v[6], v[7]); } while (0)
-                CM_ST8(G0T, v0); CM_ST8(G1T, v1); CM_ST8(G2T, v2); CM_ST8(G3T, v3);
-                CM_ST8(X1T, P.x1); CM_ST8(HPT, P.hprev); CM_ST8(OBT, P.ob);
+                if (!XG || s == 0) { CM_ST8(G0T, v0); CM_ST8(G1T, v1); CM_ST8(G2T, v2); }  // published steps: their products run elsewhere
+                CM_ST8(G3T, v3); CM_ST8(X1T, P.x1); CM_ST8(HPT, P.hprev); CM_ST8(OBT, P.ob);
 #undef CM_ST8
                 dbg[0] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
                 dbg[1] += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
@@ -1261,6 +1429,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru2_bwd(const GruArgs a) {
         lds_barrier();
         wgrad();  // step 0
     }
+#ifdef CM_PHASE_PROF
+    ph_[7] = __builtin_amdgcn_s_memrealtime(); ph_[6] = ph_start;
+#endif
     PH2_FLUSH(512);
     // ================================ partial gradient of this workgroup (fc2 + statistics were written by k_gru2_fwd)
     float* out = a.partial + (size_t)blockIdx.x * a.PS;

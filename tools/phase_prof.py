@@ -103,14 +103,29 @@ if which == "gru":
     nt = (E * A + 31) // 32
     if tile_opt == "auto" and nt + (nt + 1) // 2 <= 256:  # k_gru2_fwdx: chain workgroups in rows [0, nt), head workgroups behind them
         fwd8 = ["r: wait top", "r: gru2_step (fc1, 6 products, gates)", "r: obs tile", "r: drain step", "-", "-", "-", "-",
-                "h: wait top", "h: I0 h' (agent scope) + 4 tile stores", "h: wait x1", "h: I1 x1 store, vmcnt(0), publish", "h: wait h'"]
+                "h: wait top", "h: I0 h' (agent scope), vmcnt(0), publish, 4 tile stores", "h: wait x1", "h: I1 x1 store", "h: wait h'"]
         rows = prof[nt:nt + (nt + 1) // 2].double()
         ph = rows.mean(0).cpu()
         print(f"k_gru2_fwdx head workgroups: {rows.shape[0]}, cycles per 2-step pass")
-        for i, n in enumerate(["items + wait for the flags", "barrier, h' (agent scope) -> HB", "barrier, logits", "barrier, ppo math", "barrier, dW2 + dh_head"]):
+        for i, n in enumerate(["items, flags + h' rows (agent scope) of both steps", "barrier, HB", "barrier, logits", "barrier, ppo math", "barrier, dW2 + dh_head (2 barriers)"]):
             print(f"  {n:34s} {float(ph[i]) / (CL / 2):10.1f}")
         print(f"  total cycles/WG {float(ph[:8].sum()):.0f}")
         prof[nt:512] = 0
+    if tile_opt == "auto" and nt + (nt + 1) // 2 <= 256:  # k_gru2_bwd<true>: weight-gradient workgroups behind the chain workgroups
+        ng = min(256 - nt, nt)
+        rows = prof[512 + nt:512 + nt + ng].double()
+        ph = rows.mean(0).cpu()
+        units = nt * (CL - 1) / ng
+        print(f"k_gru2_bwd<true> weight-gradient workgroups: {rows.shape[0]}, cycles per (tile, step) unit, {units:.2f} units each")
+        for i, n in enumerate(["wait for the unit's {dh_t, tag} words", "gate derivatives, barrier, tiles, next loads", "barrier", "five products"]):
+            print(f"  {n:34s} {float(ph[i]) / units:10.1f}")
+        print(f"  total cycles/WG {float(ph[:8].sum()):.0f}")
+        allr = prof[512:512 + nt + ng].double().cpu()   # slots 6, 7: s_memrealtime (100 MHz, device-wide) at the start / end of the workgroup
+        t0 = allr[:, 6].min()
+        for nm, rr_ in (("chain", allr[:nt]), ("weight-gradient", allr[nt:])):
+            print(f"  {nm:16s} start {float((rr_[:, 6] - t0).min()) / 100:7.2f} .. {float((rr_[:, 6] - t0).max()) / 100:7.2f} us   end {float((rr_[:, 7] - t0).min()) / 100:7.2f} .. {float((rr_[:, 7] - t0).max()) / 100:7.2f} us")
+        prof[512:, 6:8] = 0
+        prof[512 + nt:1024] = 0
     for name, base, per, names in (("k_gru2_fwd8/x" if eight else "k_gru2_fwd", 0, CL, fwd8 if eight else fwd4),
                                    ("k_gru2_bwd", 512, CL, ["barrier_top", "gate derivatives (s, registers) | weight gradients (s + 1)", "tile writes", "data path (3 blocks, reg B)", "dx1 / dh write"])):
         rows = prof[base:base + 512]
