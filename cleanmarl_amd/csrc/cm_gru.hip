@@ -377,6 +377,7 @@ struct GruRollArgs {
     unsigned long long seed, act_seed; long env_offset, episode;
     const float* params; int din, H, K;
     float* obs; float* state; int* action; float* logp; float* reward;
+    unsigned long long* prof;  // CM_PHASE_PROF builds only
 };
 constexpr float GR_DAMP = 0.25f, GR_DT = 0.1f, GR_ACCEL = 5.0f, GR_COLLIDE = 0.3f;  // cm_env.hip / cm_rollout.hip constants
 constexpr int G32R_LDS_FLOATS = 4 * T32 * LDT + 8 * HP + KMAX + 64 + T32 * 8 + 3 * T32 * 2 + 2 * T32 + 4 * T32 + 16;  // 4 tiles, head weights, ls, pos/vel/landmarks, reward partials, 2 x long[32]
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
     }
     for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
 
+    PH_DECL
     const int ntiles = (a.E + EPT - 1) / EPT;
     const float inv_din = 1.0f / (float)din, inv_sw = 1.0f / (float)(6 * A);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
         };
         for (int t = 0; t < T; ++t) {
             __syncthreads();
+            PH(0);
             if (t > 0) reward_partials();  // reward of step t-1 from the positions after its physics update
             // ---- observations of step t -> XA: 4 lanes per row (threads 0..127), lane hq handles entities j = hq, hq+4, ...
             if (hrow < T32) {
@@ -482,7 +485,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
                     for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
                 }
             }
+            PH(1);
             __syncthreads();
+            PH(2);
             // ---- rollout-buffer writes: flat (row, column) enumeration, consecutive threads -> consecutive addresses
             for (int idx = tid; idx < RT * din; idx += NTHREADS) {
                 const int r = (int)(((float)idx + 0.5f) * inv_din), c = idx - r * din;
@@ -508,8 +513,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
                                                 (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
                 u_row = cm_u01(rnd.x);
             }
+            PH(3);
             // ---- GRU step: the obs tile is complete since the barrier above, h_{t-1} since the end of the previous step
             gru2_step<false>(w, XA, X1, hp, hn, nullptr, nullptr, nullptr, nullptr, din, H);
+            PH(4);
             if (hrow < T32) {
                 unsigned char avb[KJ] = {1, 1};
                 float zreg[KJ];
@@ -518,7 +525,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
                 for (int j = 0; j < KJ; ++j)
                     if (4 * j + hq < K) ls[hrow * 8 + 4 * j + hq] = zreg[j];
             }
+            PH(5);
             __syncthreads();
+            PH(6);
             if (tid < RT) {
                 const int el = tid / A, i = tid - el * A;
                 const long e = e0 + el;
@@ -537,6 +546,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
                 }
             }
             float* tmp = hp; hp = hn; hn = tmp;
+            PH(7);
         }
         __syncthreads();
         reward_partials();
@@ -558,6 +568,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
             }
         }
     }
+    PH_FLUSH;
 }
 
 template <int KJ, bool WV>
@@ -1057,6 +1068,9 @@ extern "C" int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int 
     a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed;
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0); a.H = hidden; a.K = 5;
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+#ifdef CM_PHASE_PROF
+    a.prof = g_prof;
+#endif
     const int EPT = T32 / A;
     const int ntiles = (E + EPT - 1) / EPT;
     const size_t lds = (size_t)G32R_LDS_FLOATS * sizeof(float);

@@ -66,6 +66,16 @@ elif which == "act":  # the whole-episode act pass of config 4 (cm_policy_act_ep
     w0 = torch.empty(max(16, w0b), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_policy_act_episode_ld(N.ptr(obs), ld, N.ptr(avail), E * A, T, Do, 64, 1, K, N.ptr(p), 7, 0, N.ptr(act), N.ptr(lp),
                                                       N.ptr(w0), w0b, s), "act")
+elif which == "grurollout":  # the fused GRU rollout of config 5 (k_gru32_rollout)
+    from cleanmarl_amd.gru import GRUSyntheticRollout
+    E, A, T, K = 1024, 5, 128, 5
+    Do = 6 * A + A
+    prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
+    lib.cm_prof_set_buffer(C.c_void_p(prof.data_ptr()))
+    spec = NetSpec(Do, 64, 0, K, "gru")
+    p = flatten_params(init_params_like_torch(spec), dev)
+    roll = GRUSyntheticRollout(E, A, T, seed=1, device=dev, agent_ids=True)
+    run = lambda: roll.collect(p, spec, fused=True)
 elif which == "rollout":
     from cleanmarl_amd.rollout import SyntheticSpreadRollout
     prof = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
@@ -138,6 +148,14 @@ if which == "gru":
             div = per if not n.startswith("head") else per / 2
             print(f"  {n:34s} {float(ph[i]) / div:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
         print(f"  total cycles/WG {tot:.0f}")
+    sys.exit(0)
+if which == "grurollout":
+    used = prof[(prof.sum(1) > 0)]
+    ph = used.double().mean(0).cpu(); tot = float(ph.sum())
+    print(f"gru rollout: {ms:.3f} ms; cycles per (tile, step) per phase ({used.shape[0]} WGs):")
+    for i, n in enumerate(["barrier top", "reward partials + obs build", "barrier", "buffer writes + philox", "gru2_step", "head logits", "barrier", "sample + physics"]):
+        print(f"  {n:30s} {float(ph[i]) / T:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+    print(f"  total cycles/WG {tot:.0f}")
     sys.exit(0)
 if which == "rollout":
     used = prof[(prof.sum(1) > 0)]
