@@ -179,15 +179,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_linear_nt(const float* __restri
 // z0_add[(e,a,t)][h] = S[e,t][h] + sum_{j != a} W0a[h][slot(j,a) K + u_j].  One wave per (e,t), lane = hidden unit: the A
 // actions of the step are fetched once (lane j holds u_j, broadcast by readlane), S once, then the A rows are produced from
 // the transposed action block of W0 in LDS ([(A-1)K][64], conflict-free across lanes).
+// VW = hidden units per lane (1: one 64-unit slab per launch; 2: 128 units in ONE pass, float2 per lane -- the fused 128-wide critic)
+template <int VW>
 __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S, const int* __restrict__ action,
                                                      const float* __restrict__ W0, int E, int A, int T, int H, int Dc, int Ds, int Do,
                                                      int K, float* __restrict__ out, int h0, long ldS, long ldo) {
-    // h0 / ldS / ldo: this launch covers hidden units h0..h0+63 of S and out rows with strides ldS / ldo (fused path: 0, HP, HP;
+    // h0 / ldS / ldo: this launch covers hidden units h0..h0+64 VW-1 of S and out rows with strides ldS / ldo (fused path: 0, HP, HP;
     // the layered schedule of wide critics runs one launch per 64-unit slab)
+    constexpr int HW = 64 * VW;
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int Da = (A - 1) * K;
-    for (int i = threadIdx.x; i < Da * HP; i += 256) {
-        const int c = i / HP, hh = i - c * HP;
+    for (int i = threadIdx.x; i < Da * HW; i += 256) {
+        const int c = i / HW, hh = i - c * HW;
         tab[i] = h0 + hh < H ? W0[(long)(h0 + hh) * Dc + Ds + Do + c] : 0.0f;
     }
     __syncthreads();
@@ -197,14 +200,22 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
         const long e = et / T;
         const int t = (int)(et - e * T);
         const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
-        const float sv = S[et * ldS + h0 + lane];
+        float sv[VW];
+        if constexpr (VW == 2) { const float2 q = *reinterpret_cast<const float2*>(S + et * ldS + h0 + 2 * lane); sv[0] = q.x; sv[1] = q.y; }
+        else sv[0] = S[et * ldS + h0 + lane];
         for (int a = 0; a < A; ++a) {
-            float v = sv;
+            float v[VW];
+#pragma unroll
+            for (int q = 0; q < VW; ++q) v[q] = sv[q];
             for (int slot = 0; slot < A - 1; ++slot) {
                 const int j = slot < a ? slot : slot + 1;
-                v += tab[(slot * K + __shfl(u, j, 64)) * HP + lane];
+                const float* tp = tab + (slot * K + __shfl(u, j, 64)) * HW + VW * lane;
+#pragma unroll
+                for (int q = 0; q < VW; ++q) v[q] += tp[q];
             }
-            out[((e * A + a) * T + t) * ldo + h0 + lane] = v;
+            float* op = out + ((e * A + a) * T + t) * ldo + h0 + VW * lane;
+            if constexpr (VW == 2) *reinterpret_cast<float2*>(op) = make_float2(v[0], v[1]);
+            else op[0] = v[0];
         }
     }
 }
@@ -218,16 +229,18 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
 //   per-wave partials [nwaves][Da][HP] and reduced in a fixed order by k_reduce_partials.
 constexpr int OH_MAXA = 32;
 constexpr int OH_NWAVES = 8192;  // upper bound of gather waves (= partial tables)
+template <int VW>
 __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict__ dz0, const int* __restrict__ action, int E, int A, int T,
                                                          int K, int waves_per_block, float* __restrict__ dS, float* __restrict__ part,
                                                          int h0, long ldz, long ldS) {
+    constexpr int HW = 64 * VW;  // hidden units per pass (VW per lane, see k_coma_z0_add)
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int Da = (A - 1) * K;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool active = w < waves_per_block;
-    float* mine = tab + (size_t)(active ? w : 0) * Da * HP;
+    float* mine = tab + (size_t)(active ? w : 0) * Da * HW;
     if (active)
-        for (int i = lane; i < Da * HP; i += 64) mine[i] = 0.0f;
+        for (int i = lane; i < Da * HW; i += 64) mine[i] = 0.0f;
     const long net = (long)E * T;
     const long nw = (long)gridDim.x * waves_per_block;
     if (active) {
@@ -235,36 +248,52 @@ __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict
             const long e = et / T;
             const int t = (int)(et - e * T);
             const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
-            float z[OH_MAXA];
-            float tot = 0.0f;
+            float z[OH_MAXA][VW];
+            float tot[VW];
+#pragma unroll
+            for (int q = 0; q < VW; ++q) tot[q] = 0.0f;
 #pragma unroll
             for (int a = 0; a < OH_MAXA; ++a) {
-                z[a] = 0.0f;
-                if (a < A) { z[a] = dz0[((e * A + a) * T + t) * ldz + h0 + lane]; tot += z[a]; }
+#pragma unroll
+                for (int q = 0; q < VW; ++q) z[a][q] = 0.0f;
+                if (a < A) {
+                    const float* zp = dz0 + ((e * A + a) * T + t) * ldz + h0 + VW * lane;
+                    if constexpr (VW == 2) { const float2 q2 = *reinterpret_cast<const float2*>(zp); z[a][0] = q2.x; z[a][1] = q2.y; }
+                    else z[a][0] = zp[0];
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) tot[q] += z[a][q];
+                }
             }
-            dS[et * ldS + h0 + lane] = tot;
-            float pre = 0.0f;  // sum_{a<j}
+            float* sp = dS + et * ldS + h0 + VW * lane;
+            if constexpr (VW == 2) *reinterpret_cast<float2*>(sp) = make_float2(tot[0], tot[1]);
+            else sp[0] = tot[0];
+            float pre[VW];  // sum_{a<j}
+#pragma unroll
+            for (int q = 0; q < VW; ++q) pre[q] = 0.0f;
 #pragma unroll
             for (int j = 0; j < OH_MAXA; ++j) {
                 if (j < A) {
                     const int uj = __shfl(u, j, 64);
-                    if (j > 0) mine[((j - 1) * K + uj) * HP + lane] += pre;
-                    const float suf = tot - pre - z[j];  // sum_{a>j}
-                    if (j < A - 1) mine[(j * K + uj) * HP + lane] += suf;
-                    pre += z[j];
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) {
+                        if (j > 0) mine[((j - 1) * K + uj) * HW + VW * lane + q] += pre[q];
+                        const float suf = tot[q] - pre[q] - z[j][q];  // sum_{a>j}
+                        if (j < A - 1) mine[(j * K + uj) * HW + VW * lane + q] += suf;
+                        pre[q] += z[j][q];
+                    }
                 }
             }
         }
-        float* o = part + ((size_t)blockIdx.x * waves_per_block + w) * Da * HP;
-        for (int i = lane; i < Da * HP; i += 64) o[i] = mine[i];
+        float* o = part + ((size_t)blockIdx.x * waves_per_block + w) * Da * HW;
+        for (int i = lane; i < Da * HW; i += 64) o[i] = mine[i];
     }
 }
 
 // ga[h][c] = reduced[c][h] (H x Da, torch order) from the [Da][HP] layout of the gather kernel
-__global__ __launch_bounds__(256) void k_transpose_ga(const float* __restrict__ red, int H, int Da, float* __restrict__ ga) {
+__global__ __launch_bounds__(256) void k_transpose_ga(const float* __restrict__ red, int H, int Da, float* __restrict__ ga, int ldr) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H * Da; i += gridDim.x * 256) {
         const int hh = i / Da, c = i - hh * Da;
-        ga[i] = red[c * HP + hh];
+        ga[i] = red[c * ldr + hh];
     }
 }
 
@@ -327,7 +356,7 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
     CM_REQUIRE(A <= 64, "%s: n_agents=%d > 64 is not supported by the factored critic input", who, A);
     const long g = (et + 3) / 4;
-    hipLaunchKernelGGL(k_coma_z0_add, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E, A, T, H,
+    hipLaunchKernelGGL(k_coma_z0_add<1>, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E, A, T, H,
                        Dc, Ds, Do, K, wsf + w.z0, 0, (long)HP, (long)HP);
     CM_CHECK_LAUNCH(who);
     return 0;
@@ -351,7 +380,7 @@ inline ComaWideWs coma_wide_ws(int E, int A, int T, int Ds, int Do, int K, int H
         w.gc = p; p += al64(Pc + CM_NUM_STATS);
         w.gs = p; p += al64((size_t)H * Ds);
         w.ga = p; p += al64((size_t)H * DaP);
-        const size_t a1 = (size_t)DW0_GRID * 64 * Ds, a2 = (size_t)(OH_NWAVES + 1) * DaP * HP;
+        const size_t a1 = (size_t)DW0_GRID * 64 * Ds, a2 = (size_t)(OH_NWAVES + 2) * DaP * HP;
         w.part = p; p += al64(a1 > a2 ? a1 : a2);
     }
     w.train = p; p += al64(wide_ws_bytes(rows, Do, H, L, K, train) / sizeof(float) + 1);
@@ -372,8 +401,14 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
     CM_REQUIRE(A <= OH_MAXA, "%s: n_agents=%d > %d is not supported by the factored critic input", who, A, OH_MAXA);
     const long g = (et + 3) / 4;
+    if (w.Hs == 2 * HP && 2 * tab_bytes <= 64 * 1024) {  // 65..128 units: both slabs in one pass, float2 per lane
+        hipLaunchKernelGGL(k_coma_z0_add<2>, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? 2 * tab_bytes : 8, s, wsf + w.S, action, params, E,
+                           A, T, H, Dc, Ds, Do, K, wsf + w.z0, 0, (long)w.Hs, (long)w.Hs);
+        CM_CHECK_LAUNCH(who);
+        return 0;
+    }
     for (int h0 = 0; h0 < H; h0 += 64) {
-        hipLaunchKernelGGL(k_coma_z0_add, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E,
+        hipLaunchKernelGGL(k_coma_z0_add<1>, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E,
                            A, T, H, Dc, Ds, Do, K, wsf + w.z0, h0, (long)w.Hs, (long)w.Hs);
         CM_CHECK_LAUNCH(who);
     }
@@ -420,15 +455,33 @@ inline int coma_wide_critic_fwd_bwd(const float* state, const float* obs, const 
     if (blocks > cap) blocks = cap;
     float* gpart = wsf + w.part;
     float* gred = gpart + (size_t)blocks * wpb * DaP * HP;
-    for (int h0 = 0; h0 < H; h0 += 64) {
+    const bool one_pass = w.Hs == 2 * HP && 2 * per_wave <= 64 * 1024;  // 65..128 units: both slabs per lane (float2)
+    if (one_pass) {
+        int wpb2 = (int)((64 * 1024) / (2 * per_wave));
+        wpb2 = wpb2 > 4 ? 4 : wpb2;
+        long blocks2 = (et + wpb2 - 1) / wpb2;
+        const long cap2 = (OH_NWAVES / 2) / wpb2;
+        if (blocks2 > cap2) blocks2 = cap2;
+        float* gred2 = gpart + (size_t)blocks2 * wpb2 * DaP * 2 * HP;
+        hipLaunchKernelGGL(k_coma_bwd_gather<2>, dim3((int)blocks2), dim3(256), 2 * per_wave * wpb2, s, dz0, action, E, A, T, K, wpb2, wsf + w.dS, gpart, 0,
+                           (long)w.Hs, (long)w.Hs);
+        CM_CHECK_LAUNCH(who);
+        if (Da > 0) {
+            const int n = Da * 2 * HP;
+            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks2 * wpb2), n, 0, n, gred2);
+            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred2, H, Da, wsf + w.ga, 2 * HP);
+            CM_CHECK_LAUNCH(who);
+        }
+    }
+    for (int h0 = 0; h0 < H && !one_pass; h0 += 64) {
         const int hn = min(64, H - h0);
-        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, h0,
+        hipLaunchKernelGGL(k_coma_bwd_gather<1>, dim3((int)blocks), dim3(256), per_wave * wpb, s, dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, h0,
                            (long)w.Hs, (long)w.Hs);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * HP;
             hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks * wpb), n, 0, n, gred);
-            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, hn, Da, wsf + w.ga + (size_t)h0 * Da);
+            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, hn, Da, wsf + w.ga + (size_t)h0 * Da, HP);
             CM_CHECK_LAUNCH(who);
         }
     }
@@ -606,13 +659,13 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
         if (blocks > cap) blocks = cap;
         float* gpart = wsf + w.part;                       // [blocks * wpb][Da][HP]
         float* gred = gpart + (size_t)blocks * wpb * DaP * HP;  // [Da][HP]
-        hipLaunchKernelGGL(k_coma_bwd_gather, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, 0, (long)HP, (long)HP);
+        hipLaunchKernelGGL(k_coma_bwd_gather<1>, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, 0, (long)HP, (long)HP);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * HP;
             hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks * wpb), n, 0, n, gred);
             CM_CHECK_LAUNCH(who);
-            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, H, Da, wsf + w.ga);
+            hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, H, Da, wsf + w.ga, HP);
             CM_CHECK_LAUNCH(who);
         }
     }

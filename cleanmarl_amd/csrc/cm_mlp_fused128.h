@@ -1,0 +1,424 @@
+// cm_mlp_fused128.h -- ONE-launch forward / training pass of a 65..128-unit MLP with one hidden->hidden layer: the reference's COMA
+// critic default (cleanmarl/coma_multienvs.py:35, critic_hidden_dim = 128) and every --actor_hidden_dim / --critic_hidden_dim up to
+// 128 of the MAPPO / IPPO scripts (cleanmarl/mappo_multienvs.py:127-160).  Included by cm_mlp_wide.h, which falls back to its layered
+// schedule for everything else (wider, deeper, no hidden->hidden layer).
+//
+// One workgroup of EIGHT waves per CU (two per SIMD, <= 256 registers each), 64-row tiles, v_mfma_f32_16x16x4_f32 (exact fp32 products,
+// fp32 accumulation).  Wave w owns hidden units 16w .. 16w+15 of BOTH hidden layers for all 64 rows of a tile:
+//   * its slices of W1 (forward B operand) and W1^T (backward B operand) live in REGISTERS for the whole launch; W0 and Wout are
+//     zero-padded LDS images written once per launch -- no weight traffic per tile, the rest of LDS holds activations only (X double
+//     buffered, H0, H1 -> dH1, logits -> dlogits);
+//   * the C layout of a 16x16x4 product (lane (c, g) holds rows 4g .. 4g+3 of column c) IS the A layout of the transposed operand, so
+//     the three weight-gradient products take dZ straight from the registers the backward products left it in (dW1 = dH1^T H0,
+//     dW0 = dH0^T X, dWout = dOut^T H1 with H1 as the register-resident B operand) -- no transposed tiles, no extra LDS round trip;
+//   * rows are contracted in the order {16j + 4g + i}: the scalar operand reads of those products walk DOWN a column of rows with the
+//     four lane groups 16 banks apart (row strides 132 / 68 / 36 floats = 4 mod 64): conflict-free, as are the b128 row reads;
+//   * weight-gradient accumulators (32 + 16 + 8 registers per lane) persist across the tiles of a workgroup and leave as ONE partial row
+//     per workgroup, folded in a fixed order by k_reduce_partials (deterministic, same pattern as the 64-wide kernels).
+// Five barriers per tile (layer 0 | layer 1 | head | loss | dH1).  The per-row loss heads are wide_loss_row<MODE> (cm_mlp_wide.h), one
+// thread per row.  Inputs wider than 64 columns (MAPPO's central state) keep layer 0 OUTSIDE: z0 = X W0^T by k_wide_gemm, dW0 = dZ0^T X
+// by k_dw0_stream -- the fused kernel then starts from z0 and ends at dZ0 (EXT0).  COMA's factored critic input (cm_coma.hip) enters as
+// the z0 addend and leaves as dZ0 in the same way.
+#pragma once
+
+namespace {
+
+constexpr int F_NT = 512;    // threads per workgroup (8 waves)
+constexpr int F_TM = 64;     // rows per tile
+constexpr int F_HP = 128;    // padded hidden width
+constexpr int F_LDH = 132;   // LDS row stride of H0 / H1 / the head weight image
+constexpr int F_LDX = 68;    // ... of the X tiles
+constexpr int F_LDO = 36;    // ... of the logits / dlogits tile
+constexpr int F_GRID = 256;  // persistent workgroups: one per CU
+// scheduling fence between product groups: without it the compiler hoists every LDS operand read of a phase above its first MFMA
+// (128 live registers in the dW1 phase alone) and spills the register-resident weights
+#define F_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+struct F128X {
+    const float* z0; long ldz0;  // optional layer-0 pre-activation addend [rows][ldz0] (EXT0: the whole X W0^T product)
+    float* dz0; long lddz0;      // optional output: layer-0 pre-activation gradient
+    float* y; long ldy; int ncols;  // M_FWD: head output (columns dout .. ncols-1 written as zeros)
+    int vecx;                    // X rows are 16-byte aligned
+};
+
+__host__ __device__ inline int f128_lds_floats(bool ext0) {
+    return (ext0 ? 0 : 2 * F_TM * F_LDX + F_HP * F_LDX) + 2 * F_TM * F_LDH + KMAX * F_LDH + F_TM * F_LDO;  // 163 328 bytes of the 160 KB with layer 0 inside
+}
+
+__device__ __forceinline__ float f128_kq_sum(float v) {  // sum over the four lane groups of a column (fixed order)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int MODE, bool EXT0, int KCAP>
+__global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e) {
+    constexpr bool TRAIN = (MODE >= M_ACTOR);
+    constexpr bool MASKED = (MODE == M_FWD || MODE == M_ACTOR || MODE == M_COMA_ACTOR);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* W0s = smem + 2 * F_TM * F_LDX;  // [128][68] zero-padded image of W0 (!EXT0)
+    float* H0s = smem + (EXT0 ? 0 : 2 * F_TM * F_LDX + F_HP * F_LDX);
+    float* H1s = H0s + F_TM * F_LDH;
+    float* Wos = H1s + F_TM * F_LDH;
+    float* outs = Wos + KMAX * F_LDH;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lc = lane & 15, kq = lane >> 4;
+    const int H = a.H, din = a.din, K = a.dout;
+    const Offsets off = make_offsets(din, H, 1, K);
+    const float* __restrict__ P = a.params;
+    const int n = 16 * w + lc;  // the hidden unit of this lane (both layers)
+    const bool nok = n < H;
+    const long ntiles = (a.rows + F_TM - 1) / F_TM;
+
+    // ---- register-resident weights
+    float w1f[32], w1b[32];
+    if constexpr (!EXT0) {
+        for (int i = tid; i < F_HP * 64; i += F_NT) {
+            const int m = i >> 6, k = i & 63;
+            W0s[m * F_LDX + k] = (m < H && k < din) ? P[off.W0 + m * din + k] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {  // unconditional loads from clamped indices, then a select: the 32 requests are in flight together
+        const int k = 32 * kq + s;
+        const float v = P[off.Wl(0) + min(n, H - 1) * H + min(k, H - 1)];
+        w1f[s] = (nok && k < H) ? v : 0.0f;
+    }
+    if constexpr (TRAIN) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int m = 32 * kq + s;
+            const float v = P[off.Wl(0) + min(m, H - 1) * H + min(n, H - 1)];
+            w1b[s] = (nok && m < H) ? v : 0.0f;
+        }
+    }
+    const float b0v = nok ? P[off.b0 + n] : 0.0f, b1v = nok ? P[off.bl(0) + n] : 0.0f;
+    for (int i = tid; i < KMAX * F_HP; i += F_NT) {
+        const int j = i >> 7, k = i & 127;
+        Wos[j * F_LDH + k] = (j < K && k < H) ? P[off.Wout + j * H + k] : 0.0f;
+    }
+    const int hrb = w & 3, hcb = w >> 2;          // head: row block / column block of this wave
+    const int hj = 16 * hcb + lc;                 // head output of this lane
+    const float boutv = hj < K ? P[off.bout + hj] : 0.0f;
+
+    // ---- X tile loader: thread -> (row tid / 8, columns 8 (tid % 8) .. + 7)
+    const int xr = tid >> 3, xc = (tid & 7) * 8;
+    float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+    auto load_x = [&](long tile) {
+        xa = make_float4(0.f, 0.f, 0.f, 0.f); xb = xa;
+        const long row = tile * F_TM + xr;
+        if (tile < ntiles && row < a.rows) {
+            const float* p = a.x + row * a.x_stride + xc;
+            if (e.vecx) {
+                if (xc < din) xa = *reinterpret_cast<const float4*>(p);
+                if (xc + 4 < din) xb = *reinterpret_cast<const float4*>(p + 4);
+            } else {
+                if (xc < din) xa.x = p[0];
+                if (xc + 1 < din) xa.y = p[1];
+                if (xc + 2 < din) xa.z = p[2];
+                if (xc + 3 < din) xa.w = p[3];
+                if (xc + 4 < din) xb.x = p[4];
+                if (xc + 5 < din) xb.y = p[5];
+                if (xc + 6 < din) xb.z = p[6];
+                if (xc + 7 < din) xb.w = p[7];
+            }
+            if (xc + 1 >= din) xa.y = 0.f;
+            if (xc + 2 >= din) xa.z = 0.f;
+            if (xc + 3 >= din) xa.w = 0.f;
+            if (xc + 5 >= din) xb.y = 0.f;
+            if (xc + 6 >= din) xb.z = 0.f;
+            if (xc + 7 >= din) xb.w = 0.f;
+        }
+    };
+    auto store_x = [&](int buf) {
+        float* d = Xs + buf * (F_TM * F_LDX) + xr * F_LDX + xc;
+        *reinterpret_cast<float4*>(d) = xa;
+        *reinterpret_cast<float4*>(d + 4) = xb;
+    };
+
+    // ---- persistent accumulators (training)
+    f32x4 accW1[8], accW0[4], accWo[2];
+    float db0 = 0.f, db1 = 0.f, dbo[2] = {0.f, 0.f};
+    float st[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (TRAIN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accW0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accWo[0] = accWo[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if constexpr (!EXT0) { load_x(blockIdx.x); store_x(0); }
+    __syncthreads();
+
+    int buf = 0;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const long row0 = tile * F_TM;
+        if constexpr (!EXT0 && !TRAIN) load_x(tile + gridDim.x);  // in flight under the forward products
+        const float* Xc = Xs + buf * (F_TM * F_LDX);
+
+        // ---- layer 0: H0 = relu(X W0^T + b0 + z0)
+        f32x4 acc[4];
+        unsigned mask0 = 0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // the accumulators start at b0 + z0
+                const long row = row0 + 16 * rb + 4 * kq + i;
+                acc[rb][i] = b0v + ((e.z0 && nok && row < a.rows) ? e.z0[row * e.ldz0 + n] : 0.0f);
+            }
+        if constexpr (!EXT0) {
+            float4 bw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw[q] = *reinterpret_cast<const float4*>(W0s + n * F_LDX + 16 * kq + 4 * q);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float* ap = Xc + (16 * rb + lc) * F_LDX + 16 * kq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
+                    acc[rb] = mfma16(av.x, bw[q].x, acc[rb]);
+                    acc[rb] = mfma16(av.y, bw[q].y, acc[rb]);
+                    acc[rb] = mfma16(av.z, bw[q].z, acc[rb]);
+                    acc[rb] = mfma16(av.w, bw[q].w, acc[rb]);
+                }
+                F_FENCE();
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = fmaxf(acc[rb][i], 0.0f);
+                if (h > 0.0f) mask0 |= 1u << (4 * rb + i);
+                H0s[(16 * rb + 4 * kq + i) * F_LDH + n] = h;
+            }
+        __syncthreads();  // B1: H0 complete
+
+        // ---- layer 1: H1 = relu(H0 W1^T + b1)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* ap = H0s + (16 * rb + lc) * F_LDH + 32 * kq;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
+                acc[rb] = mfma16(av.x, w1f[4 * q], acc[rb]);
+                acc[rb] = mfma16(av.y, w1f[4 * q + 1], acc[rb]);
+                acc[rb] = mfma16(av.z, w1f[4 * q + 2], acc[rb]);
+                acc[rb] = mfma16(av.w, w1f[4 * q + 3], acc[rb]);
+            }
+            F_FENCE();
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                H1s[(16 * rb + 4 * kq + i) * F_LDH + n] = fmaxf(acc[rb][i] + b1v, 0.0f);
+            }
+        if constexpr (!EXT0 && !TRAIN) store_x(buf ^ 1);  // the next tile's X (its previous readers finished before B1)
+        __syncthreads();  // B2: H1 complete
+
+        if constexpr (!EXT0 && TRAIN) load_x(tile + gridDim.x);  // training: requested here, parked in LDS after the loss barrier (8 registers less in the forward products)
+        // ---- head: wave (hrb, hcb) -> 16 rows x 16 outputs
+        {
+            f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (16 * hcb < K) {
+                const float* ap = H1s + (16 * hrb + lc) * F_LDH + 32 * kq;
+                const float* bp = Wos + (16 * hcb + lc) * F_LDH + 32 * kq;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * q);
+                    hacc = mfma16(av.x, bv.x, hacc);
+                    hacc = mfma16(av.y, bv.y, hacc);
+                    hacc = mfma16(av.z, bv.z, hacc);
+                    hacc = mfma16(av.w, bv.w, hacc);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = 16 * hrb + 4 * kq + i;
+                const long row = row0 + rl;
+                float v = 0.0f;
+                if (hj < K) {
+                    v = hacc[i] + boutv;
+                    if (MASKED && a.avail && row < a.rows && !a.avail[row * a.avail_stride + hj]) v = -1e9f;  // masked_fill(~avail, -1e9)
+                }
+                if constexpr (TRAIN) outs[rl * F_LDO + hj] = v;
+                else if (row < a.rows && hj < e.ncols) e.y[row * e.ldy + hj] = v;
+            }
+        }
+        if constexpr (!TRAIN) continue;  // forward only: the next tile's barriers order every LDS reuse
+        __syncthreads();  // B3: logits complete
+
+        // ---- loss heads: one thread per row, logits -> dlogits in place
+        if (tid < F_TM) {
+            const long row = row0 + tid;
+            float* z = outs + tid * F_LDO;
+            if (row < a.rows) wide_loss_row<MODE, KCAP>(a, row, z, st);
+            else for (int k = 0; k < K; ++k) z[k] = 0.0f;
+        }
+        __syncthreads();  // B4: dlogits complete
+        if constexpr (!EXT0) store_x(buf ^ 1);  // visible after B5; the buffer's last readers (dW0 of the previous tile) passed B1
+
+        // ---- dWout += dOut^T H1 (B = this wave's own H1 columns, read back down the rows), dbout (wave 0)
+        float h1[4][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h1[rb][i] = H1s[(16 * rb + 4 * kq + i) * F_LDH + n];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (16 * cb < K) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float av = outs[(16 * rb + 4 * kq + i) * F_LDO + 16 * cb + lc];
+                        accWo[cb] = mfma16(av, h1[rb][i], accWo[cb]);
+                        dbo[cb] += av;
+                    }
+            }
+        }
+        // ---- dH1 = (dOut Wout) .* relu'(H1) -> this wave's columns of the H1 tile
+        float dh[4][4];
+        {
+            float woutb[8];  // Wout[8 g + s][n] down a column of the head weight image
+#pragma unroll
+            for (int s = 0; s < 8; ++s) woutb[s] = Wos[(8 * kq + s) * F_LDH + n];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* ap = outs + (16 * rb + lc) * F_LDO + 8 * kq;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
+                    acc[rb] = mfma16(av.x, woutb[4 * q], acc[rb]);
+                    acc[rb] = mfma16(av.y, woutb[4 * q + 1], acc[rb]);
+                    acc[rb] = mfma16(av.z, woutb[4 * q + 2], acc[rb]);
+                    acc[rb] = mfma16(av.w, woutb[4 * q + 3], acc[rb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dh[rb][i] = h1[rb][i] > 0.0f ? acc[rb][i] : 0.0f;
+                db1 += dh[rb][i];
+                H1s[(16 * rb + 4 * kq + i) * F_LDH + n] = dh[rb][i];
+            }
+        // ---- dW1 += dH1^T H0 (A = the registers above)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            if (16 * kb < H) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        accW1[kb] = mfma16(dh[rb][i], H0s[(16 * rb + 4 * kq + i) * F_LDH + 16 * kb + lc], accW1[kb]);
+                F_FENCE();
+            }
+        }
+        __syncthreads();  // B5: dH1 complete
+
+        // ---- dH0 = (dH1 W1) .* relu'(H0)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* ap = H1s + (16 * rb + lc) * F_LDH + 32 * kq;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
+                acc[rb] = mfma16(av.x, w1b[4 * q], acc[rb]);
+                acc[rb] = mfma16(av.y, w1b[4 * q + 1], acc[rb]);
+                acc[rb] = mfma16(av.z, w1b[4 * q + 2], acc[rb]);
+                acc[rb] = mfma16(av.w, w1b[4 * q + 3], acc[rb]);
+            }
+            F_FENCE();
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dh[rb][i] = ((mask0 >> (4 * rb + i)) & 1u) ? acc[rb][i] : 0.0f;
+                db0 += dh[rb][i];
+                const long row = row0 + 16 * rb + 4 * kq + i;
+                if (e.dz0 && nok && row < a.rows) e.dz0[row * e.lddz0 + n] = dh[rb][i];
+            }
+        // ---- dW0 += dH0^T X
+        if constexpr (!EXT0) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if (16 * kb < din) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            accW0[kb] = mfma16(dh[rb][i], Xc[(16 * rb + 4 * kq + i) * F_LDX + 16 * kb + lc], accW0[kb]);
+                    F_FENCE();
+                }
+            }
+        }
+    }
+
+    if constexpr (TRAIN) {
+        // ---- this workgroup's partial row: accumulator (i', lane (c, g)) = d W[16 w + 4 g + i'][16 kb + c]
+        float* part = a.partial + (size_t)blockIdx.x * a.PS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int no = 16 * w + 4 * kq + i;
+            if (no < H) {
+                if constexpr (!EXT0) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) { const int k = 16 * kb + lc; if (k < din) part[off.W0 + no * din + k] = accW0[kb][i]; }
+                }
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) { const int k = 16 * kb + lc; if (k < H) part[off.Wl(0) + no * H + k] = accW1[kb][i]; }
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { const int j = 16 * cb + 4 * kq + i; if (j < K && nok) part[off.Wout + j * H + n] = accWo[cb][i]; }
+        }
+        db0 = f128_kq_sum(db0); db1 = f128_kq_sum(db1);
+        dbo[0] = f128_kq_sum(dbo[0]); dbo[1] = f128_kq_sum(dbo[1]);
+        if (kq == 0 && nok) { part[off.b0 + n] = db0; part[off.bl(0) + n] = db1; }
+        if (w == 0 && kq == 0) {
+            if (lc < K) part[off.bout + lc] = dbo[0];
+            if (16 + lc < K) part[off.bout + 16 + lc] = dbo[1];
+        }
+        if (w == 0) {  // statistics: rows were handled by the threads of wave 0
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st[i] = cm_wave_sum(st[i]);
+            if (lane < CM_NUM_STATS) {
+                float v = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (lane == i) v = st[i];
+                part[off.P + lane] = v;
+            }
+        }
+    }
+}
+
+// the shapes this kernel serves (cm_set_option("wide_schedule", "layered") keeps everything on the layered schedule: A/B runs, tests)
+inline bool fused128_shape(int H, int L) { return H > HP && H <= F_HP && L == 1 && cm_option(CM_OPTION_WIDE_SCHEDULE) != 2; }
+inline int fused128_grid(long rows) { const long nt = (rows + F_TM - 1) / F_TM; return (int)(nt < F_GRID ? nt : F_GRID); }
+inline size_t fused128_part_floats(long rows, int din, int H, int dout) {
+    const size_t PS = (size_t)((cm_mlp_param_count(din, H, 1, dout) + CM_NUM_STATS + 63) / 64 * 64);
+    return (size_t)fused128_grid(rows) * PS;
+}
+
+template <int MODE, bool EXT0, int KCAP>
+inline void fused128_launch_k(const MlpArgs& a, const F128X& e, hipStream_t s) {
+    const size_t lds = (size_t)f128_lds_floats(EXT0) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp128<MODE, EXT0, KCAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mlp128<MODE, EXT0, KCAP>), dim3(fused128_grid(a.rows)), dim3(F_NT), lds, s, a, e);
+}
+template <int MODE, bool EXT0>
+inline void fused128_launch(const MlpArgs& a, const F128X& e, hipStream_t s) {
+    // the actor heads exist in a K <= 8 form (the softmax / gradient loops of wide_loss_row over 8 instead of 32 outputs)
+    if constexpr (MODE == M_ACTOR || MODE == M_COMA_ACTOR) { if (a.dout <= 8) { fused128_launch_k<MODE, EXT0, 8>(a, e, s); return; } }
+    fused128_launch_k<MODE, EXT0, KMAX>(a, e, s);
+}
+
+}  // namespace

@@ -28,7 +28,7 @@ constexpr int WT_TPR = WT_K / 4;   // loader threads per row (one float4 each)
 constexpr int WT_RPP = NTHREADS / WT_TPR;  // rows per loader pass
 constexpr int WT_XP = WT_M / WT_RPP;       // loader passes over the X tile
 constexpr int WIDE_HMAX = 256;
-enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend
+enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_ADD = 4 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend; ADD: product + gate, nothing else
 
 #define WIDE_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                             const float4 t = *reinterpret_cast<const float4*>(stg + rl * SLD + 4 * c4);
                             float v[4] = {t.x, t.y, t.z, t.w};
                             float gt[4] = {0.f, 0.f, 0.f, 0.f};
-                            const bool has_g = (EPI == EPI_GATE) || (EPI == EPI_BIAS_RELU && gate != nullptr);
+                            const bool has_g = (EPI == EPI_GATE) || ((EPI == EPI_BIAS_RELU || EPI == EPI_ADD) && gate != nullptr);
                             if (has_g) {
                                 const float* gp = gate + row * ldg + 4 * c4;
                                 if (vecg && 4 * c4 + 3 < N) { const float4 q4 = *reinterpret_cast<const float4*>(gp); gt[0] = q4.x; gt[1] = q4.y; gt[2] = q4.z; gt[3] = q4.w; }
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                                 const bool cv = col < N;
                                 float x = v[q] + bv4[q];
                                 if (EPI == EPI_BIAS_RELU) x = fmaxf(x + gt[q], 0.0f);  // gt = COMA's factored layer-0 addend (or 0)
+                                if (EPI == EPI_ADD) x += gt[q];
                                 if (EPI == EPI_BIAS && avail && cv && !avail[row * lda + col]) x = -1e9f;  // masked_fill(~avail, -1e9)
                                 if (EPI == EPI_GATE) { x = gt[q] > 0.0f ? x : 0.0f; cs4[q] += cv ? x : 0.0f; }
                                 v[q] = cv ? x : 0.0f;
@@ -286,20 +287,19 @@ inline int wide_colsum(const float* Z, long ldz, long rows, int N, float* partia
 // per-workgroup partials [grid][8] = {pg, entropy, kl, clipfrac, value loss, count, 0, 0}.  Formulas: the fused epilogue's
 // (cm_mlp_kernel.h; cleanmarl/mappo_multienvs.py:527-576, cleanmarl/coma_multienvs.py:620-631, :649-676).
 constexpr int LOSS_GRID = 2048;
-template <int MODE>
-__global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* __restrict__ out, float* __restrict__ partial) {
-    __shared__ float red[6][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// one row's head: z = the row's (masked) logits / values, overwritten with d(loss)/dz; st = {pg, entropy, kl, clipfrac, value loss, count}
+// KCAP: compile-time bound of the head width (8 keeps a K <= 8 head in a few registers)
+template <int MODE, int KCAP = KMAX>
+__device__ __forceinline__ void wide_loss_row(const MlpArgs& a, long row, float* z, float (&st)[6]) {
     const int dout = a.dout;
     const int Aseq = (MODE == M_CRITIC && !a.per_agent) ? 1 : a.A;
     const float invA = 1.0f / (float)a.A;
-    float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_vl = 0.f, st_cnt = 0.f;
-    for (long row = (long)blockIdx.x * NTHREADS + tid; row < a.rows; row += (long)gridDim.x * NTHREADS) {
+    float &st_pg = st[0], &st_ent = st[1], &st_kl = st[2], &st_clip = st[3], &st_vl = st[4], &st_cnt = st[5];
+    {
         const long seq = row / a.T;
         const int t = (int)(row - seq * a.T);
         const int e = (int)(seq / Aseq), ag = (int)(seq - (long)e * Aseq);
         const bool valid = t < a.ep_len[e];
-        float* z = out + row * KMAX;
         if (MODE == M_CRITIC) {
             float d = 0.0f;
             if (valid) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
                 }
             }
             z[0] = d;
-            continue;
+            return;
         }
         const int act = a.action[row];
         if (MODE == M_QCRITIC) {
@@ -331,23 +331,23 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
                 if (ag == 0) st_cnt += 1.0f;
             }
             for (int k = 0; k < dout; ++k) z[k] = (valid && k == act) ? 2.0f * invA * df : 0.0f;
-            continue;
+            return;
         }
         // actors: logits were masked (-1e9) by the head GEMM's epilogue
-        float zr[KMAX], p[KMAX];
+        float zr[KCAP], p[KCAP];
         float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { zr[k] = k < dout ? z[k] : -INFINITY; m = fmaxf(m, zr[k]); }
+        for (int k = 0; k < KCAP; ++k) { zr[k] = k < dout ? z[k] : -INFINITY; m = fmaxf(m, zr[k]); }
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { p[k] = k < dout ? expf(zr[k] - m) : 0.0f; s += p[k]; }
+        for (int k = 0; k < KCAP; ++k) { p[k] = k < dout ? expf(zr[k] - m) : 0.0f; s += p[k]; }
         const float rs = 1.0f / s;
         const float advv = a.adv[row];
         if (MODE == M_ACTOR) {
             const float lse = m + logf(s);
             float ent = 0.0f, lpa = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
+            for (int k = 0; k < KCAP; ++k)
                 if (k < dout) {
                     const float lp = zr[k] - lse;
                     p[k] *= rs;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
             }
             const float gr = g * ratio;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
+            for (int k = 0; k < KCAP; ++k)
                 if (k < dout) {
                     const float lp = zr[k] - lse;
                     float d = invA * (-gr * ((k == act ? 1.0f : 0.0f) - p[k]) + a.ent_coef * p[k] * (lp + ent));
@@ -381,10 +381,10 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
                 }
         } else {  // M_COMA_ACTOR
             const float invK = 1.0f / (float)dout;
-            float lq[KMAX];
+            float lq[KCAP];
             float ent = 0.0f, lpa = 0.0f, pa = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
+            for (int k = 0; k < KCAP; ++k) {
                 lq[k] = 0.0f;
                 if (k < dout) {
                     p[k] *= rs;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
             }
             float gbar = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
+            for (int k = 0; k < KCAP; ++k)
                 if (k < dout) {
                     float gk = a.ent_coef * invK * (lq[k] + p[k] / (p[k] + 1e-8f));
                     if (k == act) gk -= advv / (pa + 1e-8f);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
                     gbar += gk * p[k];
                 }
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
+            for (int k = 0; k < KCAP; ++k)
                 if (k < dout) {
                     float d = p[k] * (lq[k] - gbar);
                     if (!valid || zr[k] <= -5e8f) d = 0.0f;
@@ -417,7 +417,15 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
                 }
         }
     }
-    float sv[6] = {st_pg, st_ent, st_kl, st_clip, st_vl, st_cnt};
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* __restrict__ out, float* __restrict__ partial) {
+    __shared__ float red[6][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * NTHREADS + tid; row < a.rows; row += (long)gridDim.x * NTHREADS)
+        wide_loss_row<MODE>(a, row, out + row * KMAX, sv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const float v = cm_wave_sum(sv[i]);
@@ -426,6 +434,10 @@ __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* 
     __syncthreads();
     if (tid < CM_NUM_STATS) partial[(long)blockIdx.x * CM_NUM_STATS + tid] = tid < 6 ? red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3] : 0.0f;
 }
+
+}  // namespace
+#include "cm_mlp_fused128.h"
+namespace {
 
 // ---- workspace carve (floats)
 struct WideWs { size_t act, dz, out, wt, part, total; int Hs; };
@@ -439,7 +451,8 @@ inline WideWs wide_ws(long rows, int din, int H, int L, int dout, bool train, bo
     w.wt = p; if (train) p += (size_t)WIDE_HMAX * WIDE_HMAX;
     const int kmax = max(din, w.Hs);
     w.part = p;
-    if (train) p += max((size_t)DW0_GRID * 64 * kmax, max((size_t)CS_GRID * WIDE_HMAX, (size_t)LOSS_GRID * CM_NUM_STATS));
+    if (train) p += max(max((size_t)DW0_GRID * 64 * kmax, (H > HP && H <= F_HP && L == 1) ? fused128_part_floats(rows, din, H, dout) : (size_t)0),
+                        max((size_t)CS_GRID * WIDE_HMAX, (size_t)LOSS_GRID * CM_NUM_STATS));
     w.total = p;
     return w;
 }
@@ -458,6 +471,18 @@ inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bo
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
     const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
     auto act = [&](int l) { return wsf + w.act + (size_t)(train ? l : (l & 1)) * plane; };
+    if (fused128_shape(a.H, a.L)) {  // one launch (cm_mlp_fused128.h); inputs wider than 64 columns: layer 0's product first
+        F128X e = {};
+        e.z0 = a.z0_add; e.ldz0 = w.Hs; e.y = y; e.ldy = ldy; e.ncols = ncols; e.vecx = x_rows_vec(a) ? 1 : 0;
+        if (a.din > KC) {
+            if (a.z0_add) wide_gemm<EPI_ADD>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, nullptr, nullptr, 0, a.z0_add, w.Hs, act(0), w.Hs, w.Hs, s);
+            else wide_gemm<EPI_NONE>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, nullptr, nullptr, 0, nullptr, 0, act(0), w.Hs, w.Hs, s);
+            e.z0 = act(0);
+            fused128_launch<M_FWD, true>(a, e, s);
+        } else fused128_launch<M_FWD, false>(a, e, s);
+        CM_CHECK_LAUNCH(who);
+        return 0;
+    }
     wide_gemm<EPI_BIAS_RELU>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, a.H, a.params + off.b0, nullptr, 0, a.z0_add, w.Hs,
                              act(0), w.Hs, w.Hs, s);
     for (int l = 1; l <= a.L; ++l)
@@ -523,6 +548,34 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
     float* part = wsf + w.part;
     float* wt = wsf + w.wt;
     const int H = a.H, Hs = w.Hs;
+    if (fused128_shape(a.H, a.L)) {  // forward + loss + backward in one launch (cm_mlp_fused128.h)
+        MlpArgs b = a;
+        const int64_t P = off.P;
+        b.partial = part; b.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
+        const bool ext0 = a.din > KC;
+        float* z0 = act(0);
+        float* dz = wsf + w.dz;
+        F128X e = {};
+        e.z0 = a.z0_add; e.ldz0 = Hs; e.vecx = x_rows_vec(a) ? 1 : 0;
+        e.dz0 = (ext0 || dz0_out) ? dz : nullptr; e.lddz0 = Hs;
+        const int grid = fused128_grid(a.rows);
+        if (ext0) {
+            if (a.z0_add) wide_gemm<EPI_ADD>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, H, nullptr, nullptr, 0, a.z0_add, Hs, z0, Hs, Hs, s);
+            else wide_gemm<EPI_NONE>(a.x, a.x_stride, a.rows, a.din, a.params + off.W0, a.din, H, nullptr, nullptr, 0, nullptr, 0, z0, Hs, Hs, s);
+            e.z0 = z0;
+            fused128_launch<MODE, true>(b, e, s);
+        } else fused128_launch<MODE, false>(b, e, s);
+        CM_CHECK_LAUNCH(who);
+        const int n = (int)(P + CM_NUM_STATS), i0 = ext0 ? H * a.din : 0;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((n - i0 + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, part, grid, b.PS, i0, n, grad_and_stats);
+        CM_CHECK_LAUNCH(who);
+        if (ext0)  // layer 0's weight gradient: dW0 = dZ0^T X, one 64-unit slab at a time (the partial rows above are folded by now)
+            for (int n0 = 0; n0 < H; n0 += 64)
+                if (int rc = stream_dw<true>(dz + n0, a.x, a.rows, a.din, min(64, H - n0), part, grad_and_stats + off.W0 + (size_t)n0 * a.din, s, who,
+                                             Hs, a.x_stride)) return rc;
+        if (dz0_out) *dz0_out = dz;
+        return 0;
+    }
     if (int rc = wide_forward_layers(a, wsf, w, true, out, KMAX, KMAX, s, who)) return rc;
     // ---- loss heads: logits -> dlogits in place, statistics
     {

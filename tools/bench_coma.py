@@ -27,13 +27,15 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--cpu-envs", type=int, default=16)
+ap.add_argument("--critic-hidden", type=int, default=64, help="critic width (the reference's default is 128: coma_multienvs.py:35)")
 args = ap.parse_args()
 E, A, T = args.envs, args.agents, args.T
 dev = torch.device("cuda:0")
 roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, pad=False)  # COMA's kernels read contiguous rows
 Do, Ds, K = roll.Do, roll.Ds, roll.K
 Dc = coma_critic_input_dim(Do, Ds, A, K)
-aspec, cspec = NetSpec(Do, 64, 1, K), NetSpec(Dc, 64, 1, K)
+Hc = args.critic_hidden
+aspec, cspec = NetSpec(Do, 64, 1, K), NetSpec(Dc, Hc, 1, K)
 torch.manual_seed(1)
 L = COMALearner(aspec, cspec, A, COMAHParams(), dev, init_params_like_torch(aspec), init_params_like_torch(cspec))
 ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -83,23 +85,23 @@ def timed(fn, n=3):
 k = {}
 k["q_forward"] = timed(lambda: L._q(L.target, b.avail, L.q, b, s))
 k["critic_fwd_bwd"] = timed(lambda: N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, Ds, Do, K,
-                                                                        64, 1, N.ptr(L.critic), N.ptr(L.g_critic), N.ptr(L.ws), L.ws.numel(), s), "c"))
+                                                                        Hc, 1, N.ptr(L.critic), N.ptr(L.g_critic), N.ptr(L.ws), L.ws.numel(), s), "c"))
 k["actor_forward"] = timed(lambda: N.check(lib.cm_mlp_forward(N.ptr(b.obs), rows, Do, 64, 1, K, N.ptr(L.actor), N.ptr(b.avail), N.ptr(L.logits), s), "f"))
 k["advantage"] = timed(lambda: N.check(lib.cm_coma_advantage(N.ptr(L.logits), N.ptr(L.q), N.ptr(b.action), N.ptr(b.ep_len), E, A, T, K, N.ptr(b.adv),
                                                               N.ptr(L.tstats), N.ptr(L.ws), L.ws.numel(), s), "a"))
 k["coma_actor_fwd_bwd"] = timed(lambda: N.check(lib.cm_coma_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.adv), N.ptr(b.ep_len), E, A, T,
                                                                            Do, 64, 1, K, N.ptr(L.actor), 1e-3, N.ptr(L.g_actor), N.ptr(L.ws), L.ws.numel(), s), "p"))
-Pc = Dc * 64 + 64 * 64 + 64 * K
-flop_ref = rows * (2 * Pc + 2 * Pc + 2 * (Pc - Dc * 64))  # the reference's (materialised-input) critic: fwd + dW + dX per row
+Pc = Dc * Hc + Hc * Hc + Hc * K
+flop_ref = rows * (2 * Pc + 2 * Pc + 2 * (Pc - Dc * Hc))  # the reference's (materialised-input) critic: fwd + dW + dX per row
 # FLOPs the factored schedule actually needs: obs block per row, state block per (e,t), action block as one-hot GEMM in the backward only
-Pf = Do * 64 + 64 * 64 + 64 * K
-flop = rows * (4 * Pf + 2 * (Pf - Do * 64)) + E * T * 4 * Ds * 64 + rows * 2 * (A - 1) * K * 64
+Pf = Do * Hc + Hc * Hc + Hc * K
+flop = rows * (4 * Pf + 2 * (Pf - Do * Hc)) + E * T * 4 * Ds * Hc + rows * 2 * (A - 1) * K * Hc
 ach = flop / (k["critic_fwd_bwd"] * 1e-3) / 1e12
 out = {"metric": "env-steps/sec (agents x envs x steps), COMA full iteration", "value": E * A * T * args.steps / dt, "unit": "agent-env-steps/s",
        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "dtype": "f32",
-       "data": "synthetic", "config": {"workload": f"COMA synthetic-MPE {E} envs x {A} agents x {T} steps, actor 2x64, critic input {Dc} -> 2x64 -> {K}"},
+       "data": "synthetic", "config": {"workload": f"COMA synthetic-MPE {E} envs x {A} agents x {T} steps, actor 2x64, critic input {Dc} -> 2x{Hc} -> {K}"},
        "phase_ms": {"rollout_eps_mixed": ph[0], "targets": ph[1], "update": ph[2]}, "kernel_ms": k,
-       "roofline": {"kernel": "cm_coma_critic_fwd_bwd (k_linear_nt + k_coma_z0_add + k_mlp<1,M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)", "bound": "mfma", "achieved": ach,
+       "roofline": {"kernel": "cm_coma_critic_fwd_bwd (k_linear_nt + k_coma_z0_add + k_mlp<1,M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)" if Hc <= 64 else "cm_coma_critic_fwd_bwd (k_wide_gemm + k_coma_z0_add + k_mlp128<M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)", "bound": "mfma", "achieved": ach,
                     "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "flop_per_launch": flop, "reference_schedule_flop": flop_ref,
                     "reference_schedule_equiv_tflops": flop_ref / (k["critic_fwd_bwd"] * 1e-3) / 1e12,
                     "algorithmic_bytes_per_launch": rows * (4 * Do + 12) + E * T * 4 * Ds}}

@@ -57,7 +57,7 @@ for ch in (64, 128):
     L = COMALearner(aspec, cspec, A, COMAHParams(), dev, init_params_like_torch(aspec), init_params_like_torch(cspec))
     b = roll.collect(L.actor, aspec, eps=0.3)
     ms = timeit(lambda: L.train_iteration(b))
-    print(f"COMA  {E}x{A}x{T} critic {ch}x2 ({'factored, fused' if ch <= 64 else 'factored, layered'}): targets + critic + actor step "
+    print(f"COMA  {E}x{A}x{T} critic {ch}x2 ({'factored, fused' if ch <= 64 else ('factored, layered' if os.environ.get('CM_WIDE_SCHEDULE') == 'layered' else 'factored, fused 128-wide tile')}): targets + critic + actor step "
           f"{ms:7.2f} ms", flush=True)
     del L, b
     torch.cuda.empty_cache()
