@@ -70,6 +70,9 @@ int cm_version(void);
  *                                              (3 MFMAs per product, ~3e-6 of sum|a b|, inside the 1e-4 parity bar); single-pass bf16
  *                                              (1 MFMA per product, operands rounded to 8 bits: ~4e-3, its own looser parity tier);
  *                                              fp32 accumulate either way -- DESIGN.md section 8
+ *   "wide_schedule"    auto | fused | layered  MLPs of 65 .. 128 hidden units with one hidden->hidden layer (the reference's COMA critic
+ *                                              default, cleanmarl/coma_multienvs.py:35): one-launch fused tile (csrc/cm_mlp_fused128.h, the
+ *                                              default) vs the layer-by-layer schedule every wider / deeper shape runs (csrc/cm_mlp_wide.h)
  * cm_set_option returns 0, or -1 for an unknown key / value; cm_get_option returns the current value's name (NULL: unknown key). */
 int cm_set_option(const char* key, const char* value);
 const char* cm_get_option(const char* key);

@@ -127,6 +127,30 @@ def test_wide_critic_split_schedule_matches_oracle(algo, E, A, T, Do, Ds, K, H, 
     _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
+    ("mappo", 21, 3, 19, 21, 54, 5, 128, 1),    # actor + critic inside one launch each (inputs <= 64 columns, odd widths: scalar tile loads)
+    ("mappo", 16, 8, 32, 56, 384, 5, 128, 1),   # config-3 shapes: critic on the 384-wide state (layer 0 outside: k_wide_gemm + k_dw0_stream)
+    ("ippo", 12, 4, 15, 37, 50, 17, 96, 1),     # 96 units (zero-padded slab), 17 actions (two head column blocks), per-agent critic
+    ("ippo", 6, 3, 20, 140, 10, 32, 65, 1),     # 65 units, 140-wide observations (actor AND critic with layer 0 outside), 32 actions
+    ("mappo", 3, 2, 131, 64, 64, 8, 128, 1),    # 64-column inputs exactly, several row tiles with a ragged tail
+])
+def test_fused_128_wide_tile_matches_oracle_and_the_layered_schedule(algo, E, A, T, Do, Ds, K, H, L, monkeypatch):
+    """csrc/cm_mlp_fused128.h (65..128 hidden units, one hidden->hidden layer: the reference's COMA critic default and any
+    --*_hidden_dim up to 128) against the oracle at the module's bar, and against the layered schedule it replaces (option
+    wide_schedule = layered) -- two different summation orders of the same fp32 products."""
+    from cleanmarl_amd import _native as N
+    monkeypatch.setenv("CM_WIDE_SCHEDULE", "fused")
+    N.sync_env_options()
+    assert N.load().cm_get_option(b"wide_schedule") == b"fused"
+    ef = _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
+    monkeypatch.setenv("CM_WIDE_SCHEDULE", "layered")
+    N.sync_env_options()
+    assert N.load().cm_get_option(b"wide_schedule") == b"layered"
+    el = _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
+    assert ef != el or all(v == 0.0 for v in ef.values())  # the option really switched kernels (bit-different sums)
+
+
 def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
     from oracle import restatement as R
     from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
