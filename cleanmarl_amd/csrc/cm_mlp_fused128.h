@@ -55,6 +55,9 @@ template <int MODE, bool EXT0, int KCAP>
 __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e) {
     constexpr bool TRAIN = (MODE >= M_ACTOR);
     constexpr bool MASKED = (MODE == M_FWD || MODE == M_ACTOR || MODE == M_COMA_ACTOR);
+    // the Q-critic's head (MSE on the taken action, cleanmarl/coma_multienvs.py:620-631) is element-wise in the logits tile: it runs in the
+    // epilogue of the head product (no loss phase, one barrier less); the per-row inputs wait in the padding columns of the logits tile
+    constexpr bool EPI_LOSS = (MODE == M_QCRITIC);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* W0s = smem + 2 * F_TM * F_LDX;  // [128][68] zero-padded image of W0 (!EXT0)
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
     const int n = 16 * w + lc;  // the hidden unit of this lane (both layers)
     const bool nok = n < H;
     const long ntiles = (a.rows + F_TM - 1) / F_TM;
+    const float invA = 1.0f / (float)a.A;
 
     // ---- register-resident weights
     float w1f[32], w1b[32];
@@ -148,10 +152,35 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
         accWo[0] = accWo[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // per-row inputs of the element-wise head (EPI_LOSS): threads 0..63 request the NEXT tile's {action, target, valid | first agent} at
+    // the top of the backward phases and park them in the padding columns 32..34 of the logits tile at the end of the tile -- a whole
+    // backward pass between request and use (requested at the tile top they cost wave 0 a memory round trip per tile)
+    int rin_act = 0, rin_fl = 0;
+    float rin_tg = 0.0f;
+    auto load_rin = [&](long tile) {
+        rin_act = 0; rin_fl = 0; rin_tg = 0.0f;
+        const long row = tile * F_TM + tid;
+        if (tid < F_TM && tile < ntiles && row < a.rows) {
+            const unsigned r32 = (unsigned)row, seq = r32 / (unsigned)a.T;  // rows < 2^31 (check_rows)
+            const int t = (int)(r32 - seq * (unsigned)a.T);
+            const int en = (int)(seq / (unsigned)a.A), ag = (int)(seq - (unsigned)en * (unsigned)a.A);
+            rin_act = a.action[row];
+            rin_tg = a.ret[row];
+            rin_fl = (t < a.ep_len[en] ? 1 : 0) | (ag == 0 ? 2 : 0);
+        }
+    };
+    auto store_rin = [&]() {
+        if (tid < F_TM) {
+            float* rp = outs + tid * F_LDO + KMAX;  // no product reads these columns
+            rp[0] = __int_as_float(rin_act); rp[1] = rin_tg; rp[2] = __int_as_float(rin_fl);
+        }
+    };
+    if constexpr (EPI_LOSS) { load_rin(blockIdx.x); store_rin(); }
     if constexpr (!EXT0) { load_x(blockIdx.x); store_x(0); }
     __syncthreads();
 
     int buf = 0;
+    PH_DECL
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const long row0 = tile * F_TM;
         if constexpr (!EXT0 && !TRAIN) load_x(tile + gridDim.x);  // in flight under the forward products
@@ -159,13 +188,15 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
 
         // ---- layer 0: H0 = relu(X W0^T + b0 + z0)
         f32x4 acc[4];
+        float zv[4][4];
         unsigned mask0 = 0;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // the accumulators start at b0 + z0
+            for (int i = 0; i < 4; ++i) {  // z0 is requested here and added behind the products (its round trip hides under them)
                 const long row = row0 + 16 * rb + 4 * kq + i;
-                acc[rb][i] = b0v + ((e.z0 && nok && row < a.rows) ? e.z0[row * e.ldz0 + n] : 0.0f);
+                zv[rb][i] = (e.z0 && nok && row < a.rows) ? e.z0[row * e.ldz0 + n] : 0.0f;
+                acc[rb][i] = b0v;
             }
         if constexpr (!EXT0) {
             float4 bw[4];
@@ -189,35 +220,37 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float h = fmaxf(acc[rb][i], 0.0f);
+                const float h = fmaxf(acc[rb][i] + zv[rb][i], 0.0f);
                 if (h > 0.0f) mask0 |= 1u << (4 * rb + i);
                 H0s[(16 * rb + 4 * kq + i) * F_LDH + n] = h;
             }
+        PH(0);
         __syncthreads();  // B1: H0 complete
+        PH(1);
 
-        // ---- layer 1: H1 = relu(H0 W1^T + b1)
-#pragma unroll
+        // ---- layer 1: H1 = relu(H0 W1^T + b1).  The row-block loops from here on are ROLLED (runtime rb): an unrolled phase lets the
+        // compiler hoist every operand read of the phase above its first MFMA and spill the persistent accumulators to scratch
+        // (measured: 127 spilled registers, dW1 / dW0 phases 30 % / 100 % slower); one row block per iteration bounds the live set.
+#pragma unroll 2
         for (int rb = 0; rb < 4; ++rb) {
-            acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 c1 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* ap = H0s + (16 * rb + lc) * F_LDH + 32 * kq;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
-                acc[rb] = mfma16(av.x, w1f[4 * q], acc[rb]);
-                acc[rb] = mfma16(av.y, w1f[4 * q + 1], acc[rb]);
-                acc[rb] = mfma16(av.z, w1f[4 * q + 2], acc[rb]);
-                acc[rb] = mfma16(av.w, w1f[4 * q + 3], acc[rb]);
+                c1 = mfma16(av.x, w1f[4 * q], c1);
+                c1 = mfma16(av.y, w1f[4 * q + 1], c1);
+                c1 = mfma16(av.z, w1f[4 * q + 2], c1);
+                c1 = mfma16(av.w, w1f[4 * q + 3], c1);
             }
-            F_FENCE();
+            float* hp = H1s + (16 * rb + 4 * kq) * F_LDH + n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hp[i * F_LDH] = fmaxf(c1[i] + b1v, 0.0f);
         }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                H1s[(16 * rb + 4 * kq + i) * F_LDH + n] = fmaxf(acc[rb][i] + b1v, 0.0f);
-            }
         if constexpr (!EXT0 && !TRAIN) store_x(buf ^ 1);  // the next tile's X (its previous readers finished before B1)
+        PH(2);
         __syncthreads();  // B2: H1 complete
+        PH(3);
 
         if constexpr (!EXT0 && TRAIN) load_x(tile + gridDim.x);  // training: requested here, parked in LDS after the loss barrier (8 registers less in the forward products)
         // ---- head: wave (hrb, hcb) -> 16 rows x 16 outputs
@@ -245,123 +278,148 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
                     v = hacc[i] + boutv;
                     if (MASKED && a.avail && row < a.rows && !a.avail[row * a.avail_stride + hj]) v = -1e9f;  // masked_fill(~avail, -1e9)
                 }
+                if constexpr (EPI_LOSS) {  // d(loss)/dq = 2/A (q_taken - target) on the taken action of a valid row, 0 elsewhere
+                    const float* rp = outs + rl * F_LDO + KMAX;
+                    const int act = __float_as_int(rp[0]), fl = __float_as_int(rp[2]);
+                    const float df = v - rp[1];
+                    const bool hit = (fl & 1) && hj == act && hj < K;
+                    v = hit ? 2.0f * invA * df : 0.0f;
+                    if (hit) st[4] += invA * df * df;
+                    if ((fl & 3) == 3 && hj == 0) st[5] += 1.0f;
+                }
                 if constexpr (TRAIN) outs[rl * F_LDO + hj] = v;
                 else if (row < a.rows && hj < e.ncols) e.y[row * e.ldy + hj] = v;
             }
         }
+        PH(4);
         if constexpr (!TRAIN) continue;  // forward only: the next tile's barriers order every LDS reuse
         __syncthreads();  // B3: logits complete
+        PH(5);
 
-        // ---- loss heads: one thread per row, logits -> dlogits in place
-        if (tid < F_TM) {
-            const long row = row0 + tid;
-            float* z = outs + tid * F_LDO;
-            if (row < a.rows) wide_loss_row<MODE, KCAP>(a, row, z, st);
-            else for (int k = 0; k < K; ++k) z[k] = 0.0f;
-        }
-        __syncthreads();  // B4: dlogits complete
-        if constexpr (!EXT0) store_x(buf ^ 1);  // visible after B5; the buffer's last readers (dW0 of the previous tile) passed B1
-
-        // ---- dWout += dOut^T H1 (B = this wave's own H1 columns, read back down the rows), dbout (wave 0)
-        float h1[4][4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h1[rb][i] = H1s[(16 * rb + 4 * kq + i) * F_LDH + n];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            if (16 * cb < K) {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float av = outs[(16 * rb + 4 * kq + i) * F_LDO + 16 * cb + lc];
-                        accWo[cb] = mfma16(av, h1[rb][i], accWo[cb]);
-                        dbo[cb] += av;
-                    }
+        if constexpr (!EPI_LOSS) {
+            // ---- loss heads: one thread per row, logits -> dlogits in place
+            if (tid < F_TM) {
+                const long row = row0 + tid;
+                float* z = outs + tid * F_LDO;
+                if (row < a.rows) wide_loss_row<MODE, KCAP>(a, row, z, st);
+                else for (int k = 0; k < K; ++k) z[k] = 0.0f;
             }
+            PH(6);
+            __syncthreads();  // B4: dlogits complete
+            PH(7);
         }
-        // ---- dH1 = (dOut Wout) .* relu'(H1) -> this wave's columns of the H1 tile
-        float dh[4][4];
+        if constexpr (!EXT0) store_x(buf ^ 1);  // visible after B5; the buffer's last readers (dW0 of the previous tile) passed B1
+        if constexpr (EPI_LOSS) load_rin(tile + gridDim.x);
+
+        // ---- per row block: dWout += dOut^T H1 (B = this wave's own H1 columns, read back down the rows; dbout in wave 0),
+        //      dH1 = (dOut Wout) .* relu'(H1) -> this wave's columns of the H1 tile, dW1 += dH1^T H0 (A = the registers dH1 was left in)
         {
             float woutb[8];  // Wout[8 g + s][n] down a column of the head weight image
 #pragma unroll
-            for (int s = 0; s < 8; ++s) woutb[s] = Wos[(8 * kq + s) * F_LDH + n];
-#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) woutb[s8] = Wos[(8 * kq + s8) * F_LDH + n];
+#pragma unroll 2
             for (int rb = 0; rb < 4; ++rb) {
-                acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float* hp = H1s + (16 * rb + 4 * kq) * F_LDH + n;
+                const float* op = outs + (16 * rb + 4 * kq) * F_LDO + lc;
+                float h1v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h1v[i] = hp[i * F_LDH];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    if (16 * cb < K) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float av = op[i * F_LDO + 16 * cb];
+                            accWo[cb] = mfma16(av, h1v[i], accWo[cb]);
+                            dbo[cb] += av;
+                        }
+                    }
+                }
+                f32x4 c2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 const float* ap = outs + (16 * rb + lc) * F_LDO + 8 * kq;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
-                    acc[rb] = mfma16(av.x, woutb[4 * q], acc[rb]);
-                    acc[rb] = mfma16(av.y, woutb[4 * q + 1], acc[rb]);
-                    acc[rb] = mfma16(av.z, woutb[4 * q + 2], acc[rb]);
-                    acc[rb] = mfma16(av.w, woutb[4 * q + 3], acc[rb]);
+                    c2 = mfma16(av.x, woutb[4 * q], c2);
+                    c2 = mfma16(av.y, woutb[4 * q + 1], c2);
+                    c2 = mfma16(av.z, woutb[4 * q + 2], c2);
+                    c2 = mfma16(av.w, woutb[4 * q + 3], c2);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = h1v[i] > 0.0f ? c2[i] : 0.0f;
+                    db1 += d;
+                    hp[i * F_LDH] = d;
                 }
             }
         }
+        PH(8);
+        // dW1 in its own loop (dH1 read back from the wave's own columns): 16 steps (row block, row) of 8 MFMAs on eight independent
+        // accumulators, software-pipelined by hand -- the nine operand reads of step s + 1 are issued before the MFMAs of step s and the
+        // fence keeps that order (left to itself the compiler either hoists all 144 reads and spills the accumulators, or -- in a rolled
+        // loop -- issues 7 reads, consumes them, and exposes the LDS latency every 7 MFMAs: 17.1 k cycles per tile for 8.2 k of MFMA)
+        {
+            float bq[2][9];
+            // an opaque zero keeps the 32 per-step LDS addresses from being hoisted out of the tile loop as 32 live registers
+            // (row strides exceed the 8-bit offsets of ds_read2_b32): they are one v_add each, recomputed where they are used
+            int zoff;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
+            const float* H0z = H0s + zoff + lc;
+            const float* H1z = H1s + zoff + n;
+            auto ld = [&](int st_, float (&q)[9]) {
+                const int r = 16 * (st_ >> 2) + (st_ & 3) + 4 * kq;
+                q[8] = H1z[r * F_LDH];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+                for (int kb = 0; kb < 8; ++kb) q[kb] = H0z[r * F_LDH + 16 * kb];  // columns >= H of H0 are zero
+            };
+            ld(0, bq[0]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dh[rb][i] = h1[rb][i] > 0.0f ? acc[rb][i] : 0.0f;
-                db1 += dh[rb][i];
-                H1s[(16 * rb + 4 * kq + i) * F_LDH + n] = dh[rb][i];
-            }
-        // ---- dW1 += dH1^T H0 (A = the registers above)
+            for (int st_ = 0; st_ < 16; ++st_) {
+                if (st_ + 1 < 16) ld(st_ + 1, bq[(st_ + 1) & 1]);
+                F_FENCE();  // ... and the reads may not sink below the MFMAs either
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            if (16 * kb < H) {
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        accW1[kb] = mfma16(dh[rb][i], H0s[(16 * rb + 4 * kq + i) * F_LDH + 16 * kb + lc], accW1[kb]);
+                for (int kb = 0; kb < 8; ++kb) accW1[kb] = mfma16(bq[st_ & 1][8], bq[st_ & 1][kb], accW1[kb]);
                 F_FENCE();
             }
         }
+        PH(9);
         __syncthreads();  // B5: dH1 complete
+        PH(10);
 
-        // ---- dH0 = (dH1 W1) .* relu'(H0)
-#pragma unroll
+        // ---- per row block: dH0 = (dH1 W1) .* relu'(H0) (-> dz0), dW0 += dH0^T X
+#pragma unroll 2
         for (int rb = 0; rb < 4; ++rb) {
-            acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 c3 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* ap = H1s + (16 * rb + lc) * F_LDH + 32 * kq;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 av = *reinterpret_cast<const float4*>(ap + 4 * q);
-                acc[rb] = mfma16(av.x, w1b[4 * q], acc[rb]);
-                acc[rb] = mfma16(av.y, w1b[4 * q + 1], acc[rb]);
-                acc[rb] = mfma16(av.z, w1b[4 * q + 2], acc[rb]);
-                acc[rb] = mfma16(av.w, w1b[4 * q + 3], acc[rb]);
+                c3 = mfma16(av.x, w1b[4 * q], c3);
+                c3 = mfma16(av.y, w1b[4 * q + 1], c3);
+                c3 = mfma16(av.z, w1b[4 * q + 2], c3);
+                c3 = mfma16(av.w, w1b[4 * q + 3], c3);
             }
-            F_FENCE();
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+            float dh[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                dh[rb][i] = ((mask0 >> (4 * rb + i)) & 1u) ? acc[rb][i] : 0.0f;
-                db0 += dh[rb][i];
+                dh[i] = ((mask0 >> (4 * rb + i)) & 1u) ? c3[i] : 0.0f;
+                db0 += dh[i];
                 const long row = row0 + 16 * rb + 4 * kq + i;
-                if (e.dz0 && nok && row < a.rows) e.dz0[row * e.lddz0 + n] = dh[rb][i];
+                if (e.dz0 && nok && row < a.rows) e.dz0[row * e.lddz0 + n] = dh[i];
             }
-        // ---- dW0 += dH0^T X
-        if constexpr (!EXT0) {
+            if constexpr (!EXT0) {
+                const float* bp = Xc + (16 * rb + 4 * kq) * F_LDX + lc;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                if (16 * kb < din) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            accW0[kb] = mfma16(dh[rb][i], Xc[(16 * rb + 4 * kq + i) * F_LDX + 16 * kb + lc], accW0[kb]);
-                    F_FENCE();
-                }
+                    for (int kb = 0; kb < 4; ++kb)
+                        accW0[kb] = mfma16(dh[i], bp[i * F_LDX + 16 * kb], accW0[kb]);  // columns >= din of X are zero
             }
         }
+        if constexpr (EPI_LOSS) store_rin();  // this tile's head read its inputs before B3
+        PH(12);
     }
+    PH_FLUSH;
 
     if constexpr (TRAIN) {
         // ---- this workgroup's partial row: accumulator (i', lane (c, g)) = d W[16 w + 4 g + i'][16 kb + c]
@@ -387,7 +445,21 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
             if (lc < K) part[off.bout + lc] = dbo[0];
             if (16 + lc < K) part[off.bout + 16 + lc] = dbo[1];
         }
-        if (w == 0) {  // statistics: rows were handled by the threads of wave 0
+        if constexpr (EPI_LOSS) {  // statistics: partial sums in the lanes of every head wave -> per-wave sums -> fixed-order fold
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st[i] = cm_wave_sum(st[i]);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) outs[w * 8 + i] = st[i];
+            }
+            __syncthreads();
+            if (tid < CM_NUM_STATS) {
+                float v = 0.0f;
+                if (tid < 6) for (int ww = 0; ww < F_NT / 64; ++ww) v += outs[ww * 8 + tid];
+                part[off.P + tid] = v;
+            }
+        } else if (w == 0) {  // statistics: rows were handled by the threads of wave 0
 #pragma unroll
             for (int i = 0; i < 6; ++i) st[i] = cm_wave_sum(st[i]);
             if (lane < CM_NUM_STATS) {

@@ -552,6 +552,9 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
         MlpArgs b = a;
         const int64_t P = off.P;
         b.partial = part; b.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
+#ifdef CM_PHASE_PROF
+        b.prof = g_prof;
+#endif
         const bool ext0 = a.din > KC;
         float* z0 = act(0);
         float* dz = wsf + w.dz;

@@ -66,6 +66,15 @@ elif which == "act":  # the whole-episode act pass of config 4 (cm_policy_act_ep
     w0 = torch.empty(max(16, w0b), dtype=torch.uint8, device=dev)
     run = lambda: N.check(lib.cm_policy_act_episode_ld(N.ptr(obs), ld, N.ptr(avail), E * A, T, Do, 64, 1, K, N.ptr(p), 7, 0, N.ptr(act), N.ptr(lp),
                                                       N.ptr(w0), w0b, s), "act")
+elif which == "fused128":  # csrc/cm_mlp_fused128.h: the COMA critic's training pass at the reference's default width (obs block + z0 addend left out: cm_qcritic_fwd_bwd)
+    spec = NetSpec(Do, 128, 1, K)
+    p = flatten_params(init_params_like_torch(spec), dev)
+    obs = torch.randn(E, A, T, Do, device=dev)
+    act = torch.randint(0, K, (E, A, T), dtype=torch.int32, device=dev); tgt = torch.randn(E, A, T, device=dev)
+    g = torch.zeros(spec.nparams + 8, device=dev)
+    ws = torch.empty(lib.cm_mlp_split_workspace_bytes(E * A * T, Do, 128, 1, K), dtype=torch.uint8, device=dev)
+    run = lambda: N.check(lib.cm_qcritic_fwd_bwd(N.ptr(obs), N.ptr(act), N.ptr(tgt), N.ptr(ep_len), E, A, T, Do, 128, 1, K, N.ptr(p), N.ptr(g),
+                                                 N.ptr(ws), ws.numel(), s), "qcritic 128")
 elif which == "grurollout":  # the fused GRU rollout of config 5 (k_gru32_rollout)
     from cleanmarl_amd.gru import GRUSyntheticRollout
     E, A, T, K = 1024, 5, 128, 5
@@ -183,6 +192,15 @@ if which == "critic" and os.environ.get("CM_CRITIC_SCHEDULE") != "split" and 128
     print(f"critic (fused): {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks per tile:")
     for i, n in enumerate(names):
         print(f"  {n:30s} {float(ph[i]) / tiles_per_wg:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
+    print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
+    sys.exit(0)
+if which == "fused128":
+    names = ["layer 0 (z0 loads, 64 MFMAs, H0 -> LDS)", "wait B1", "layer 1 (128 MFMAs, H1 -> LDS)", "wait B2", "head (32 MFMAs) + X request", "wait B3",
+             "loss heads (wave 0)", "wait B4", "X -> LDS, dWout, dH1 (64 MFMAs) -> LDS", "dW1 (128 MFMAs)", "wait B5", "dH0 (128 MFMAs), dz0 stores", "dW0 (64 MFMAs)"]
+    tiles_per_wg = E * A * T / 64 / 256
+    print(f"fused 128-wide tile, M_QCRITIC, {E} x {A} x {T} rows: {ms:.3f} ms, {tiles_per_wg:.0f} tiles/WG, s_memtime ticks of thread 0 per tile:")
+    for i, n in enumerate(names):
+        print(f"  {n:44s} {float(ph[i]) / tiles_per_wg:10.1f}  {100 * float(ph[i]) / tot:5.1f}%")
     print(f"  total ticks/WG {tot:.0f}  -> {tot / (ms * 1e-3) / 1e6:.1f} MHz tick rate")
     sys.exit(0)
 names = ["stage_x", "fwd_L0", "fwd_hidden", "head_logits", "softmax_loss", "dWout", "dZ_L", "bwd_hidden(colred+tn)", "inplace", "bwd_L0(colred)"]
