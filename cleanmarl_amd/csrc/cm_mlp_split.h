@@ -19,7 +19,12 @@ constexpr int RB = 8;  // row pairs per software-pipeline batch (16 rows)
 // wave w of the workgroup owns k-tiles {w, w+4, ...} (32 columns each); both 32-row halves of the 64 hidden units.
 // GEN = false: the tuned layer-0 form (dZ0 row stride HP, X row stride din).  GEN = true (cm_mlp_wide.h): explicit row strides,
 // one or two 32-row halves of dZ.
-template <int KTW, bool GEN = false>
+// RBT: row pairs per batch.  The 8-pair form keeps 80 operand registers per lane in flight (234 registers at KTW = 3): a wave of it finds
+// no slot on a SIMD that holds two waves of the six-wave rollout (2 x 144 of 512 registers), so beside the next iteration's rollout -- where
+// the two-stream schedule puts the critic's epochs -- the WHOLE workgroup waited for the rollout's workgroup to retire (kernel trace of the
+// 512-env share: 310 us instead of 70).  The 4-pair form (RBT = 4) fits one wave on every SIMD there; stream_dw() picks it up to 2^16 rows -- the sizes whose rollouts take the six-wave form; anywhere else it is the slower one
+// (half the loads in flight: config 5's critic at 2^17 rows 95 -> 151 us).
+template <int KTW, bool GEN = false, int RBT = RB>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restrict__ dz0, const float* __restrict__ x,
                                                             long rows, int din, int H, long rows_per_wg,
                                                             float* __restrict__ partial, int PS2, int col0,
@@ -41,10 +46,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restr
 #pragma unroll
     for (int j = 0; j < KTW; ++j) { col[j] = col0 + 32 * (w + 4 * j) + r; cok[j] = col[j] < din; }
 
-    float a0[RB], a1[RB], b[RB][KTW], na0[RB], na1[RB], nb[RB][KTW];
-    auto load = [&](long base, float (&A0)[RB], float (&A1)[RB], float (&B)[RB][KTW]) {
+    float a0[RBT], a1[RBT], b[RBT][KTW], na0[RBT], na1[RBT], nb[RBT][KTW];
+    auto load = [&](long base, float (&A0)[RBT], float (&A1)[RBT], float (&B)[RBT][KTW]) {
 #pragma unroll
-        for (int p = 0; p < RB; ++p) {
+        for (int p = 0; p < RBT; ++p) {
             const long row = base + 2 * p + h;
             const bool ok = row < row_hi;
             A0[p] = ok ? dz0[row * ldz + r] : 0.0f;
@@ -54,17 +59,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dw0_stream(const float* __restr
         }
     };
     if (row_lo < row_hi) load(row_lo, a0, a1, b);
-    for (long base = row_lo; base < row_hi; base += 2 * RB) {
-        if (base + 2 * RB < row_hi) load(base + 2 * RB, na0, na1, nb);  // next batch in flight under this batch's MFMAs
+    for (long base = row_lo; base < row_hi; base += 2 * RBT) {
+        if (base + 2 * RBT < row_hi) load(base + 2 * RBT, na0, na1, nb);  // next batch in flight under this batch's MFMAs
 #pragma unroll
-        for (int p = 0; p < RB; ++p)
+        for (int p = 0; p < RBT; ++p)
 #pragma unroll
             for (int j = 0; j < KTW; ++j) {
                 acc[0][j] = mfma32(a0[p], b[p][j], acc[0][j]);
                 acc[1][j] = mfma32(a1[p], b[p][j], acc[1][j]);
             }
 #pragma unroll
-        for (int p = 0; p < RB; ++p) {
+        for (int p = 0; p < RBT; ++p) {
             a0[p] = na0[p]; a1[p] = na1[p];
 #pragma unroll
             for (int j = 0; j < KTW; ++j) b[p][j] = nb[p][j];
@@ -95,14 +100,21 @@ inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H
     rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
     const int grid2 = (int)((rows + rpw - 1) / rpw);
     const int PS2 = H * din;
+    // rows in flight per lane: see k_dw0_stream (same accumulation order either way)
+    const int batch = cm_option(CM_OPTION_DW0_BATCH);
+    const bool light = batch ? batch == 4 : rows <= (1L << 16);
     for (int col0 = 0; col0 < din; col0 += 512) {  // one launch per 512-column window of X (4 waves x 4 tiles x 32 columns)
         const int nkt = (min(512, din - col0) + 31) / 32, ktw = (nkt + 3) / 4;
+#define CM_DW0_LAUNCH(K)                                                                                                                      \
+    if (light) hipLaunchKernelGGL((k_dw0_stream<K, GEN, 4>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); \
+    else hipLaunchKernelGGL((k_dw0_stream<K, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx)
         switch (ktw) {
-            case 1: hipLaunchKernelGGL((k_dw0_stream<1, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
-            case 2: hipLaunchKernelGGL((k_dw0_stream<2, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
-            case 3: hipLaunchKernelGGL((k_dw0_stream<3, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
-            default: hipLaunchKernelGGL((k_dw0_stream<4, GEN>), dim3(grid2), dim3(NTHREADS), 0, s, dz0, x, rows, din, H, rpw, part2, PS2, col0, ldz, ldx); break;
+            case 1: CM_DW0_LAUNCH(1); break;
+            case 2: CM_DW0_LAUNCH(2); break;
+            case 3: CM_DW0_LAUNCH(3); break;
+            default: CM_DW0_LAUNCH(4); break;
         }
+#undef CM_DW0_LAUNCH
     }
     CM_CHECK_LAUNCH(who);
     if (grid2_out) { *grid2_out = grid2; return 0; }

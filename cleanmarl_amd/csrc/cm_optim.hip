@@ -102,10 +102,50 @@ __device__ __forceinline__ float step_wait(const unsigned long long* p, unsigned
     return __uint_as_float((unsigned)w);
 }
 
+// The fused launch runs on 256-thread workgroups: wave w folds row groups 4w .. 4w+3 (same rows, same alternating accumulators, same final
+// order over the 16 groups as step_colsum / k_reduce_partials => bit-identical sums), 4 x 8 loads in flight per thread.  A 1024-thread
+// workgroup needs four wave slots of 40 registers on EVERY SIMD at once: beside the persistent workgroups of the other stream's k_mlp
+// (2 x 200 registers per SIMD, 112 free) it could not be placed until a whole workgroup retired -- in the two-stream schedule the critic's
+// step sat 218 us behind the actor's pass and the actor's 30 - 56 us behind the critic's (kernel trace of the 512-env share, round 3);
+// one 64-register wave per SIMD fits beside every kernel of the path.
+constexpr int STEP_WAVES = 4, STEP_GPW = STEP_GROUPS / STEP_WAVES;
+template <bool PEER = false>
+__device__ __forceinline__ void step_colsum_gpw(const float* __restrict__ p, int np, int PS, int i, int w, float (&out)[STEP_GPW]) {
+    constexpr int STEP_BATCH = 8;
+    float s0[STEP_GPW], s1[STEP_GPW];
+#pragma unroll
+    for (int j = 0; j < STEP_GPW; ++j) s0[j] = s1[j] = 0.f;
+    const unsigned last = (unsigned)(np - 1), col = (unsigned)i;
+    for (int r0 = 0; r0 < np; r0 += STEP_BATCH * STEP_GROUPS) {  // a group whose rows are exhausted adds +0.0f: no change
+        // unconditional loads of clamped rows (no branch per load: 32 requests leave back to back), masked after they arrived;
+        // 32-bit element offsets: one address register per load in flight (cm_launch_reduce_step checks np * PS < 2^30)
+        float v[STEP_GPW][STEP_BATCH];
+#pragma unroll
+        for (int j = 0; j < STEP_GPW; ++j)
+#pragma unroll
+            for (int k = 0; k < STEP_BATCH; ++k) {
+                const unsigned row = (unsigned)(r0 + w * STEP_GPW + j + k * STEP_GROUPS);
+                const unsigned off = min(row, last) * (unsigned)PS + col;
+                v[j][k] = PEER ? __hip_atomic_load(p + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : p[off];
+            }
+#pragma unroll
+        for (int j = 0; j < STEP_GPW; ++j)
+#pragma unroll
+            for (int k = 0; k < STEP_BATCH; ++k)
+                if ((unsigned)(r0 + w * STEP_GPW + j + k * STEP_GROUPS) > last) v[j][k] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < STEP_GPW; ++j)
+#pragma unroll
+            for (int k = 0; k < STEP_BATCH; k += 2) { s0[j] += v[j][k]; s1[j] += v[j][k + 1]; }
+    }
+#pragma unroll
+    for (int j = 0; j < STEP_GPW; ++j) out[j] = s0[j] + s1[j];
+}
+
 template <bool UPDATE, bool PEER = false>
-__global__ __launch_bounds__(STEP_COLS * STEP_GROUPS) void k_reduce_step(const StepArgs a) {
+__global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const StepArgs a) {
     __shared__ float sh[STEP_GROUPS][STEP_COLS];
-    const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;
+    const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;  // g: wave of the workgroup
     if (PEER) {  // the partial rows are mailbox slots: wait until every rank has published this step's (cm_peer.hip)
         if (threadIdx.x < a.np1)
             while (__hip_atomic_load(a.peer_tags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)a.peer_seq)
@@ -115,9 +155,15 @@ __global__ __launch_bounds__(STEP_COLS * STEP_GROUPS) void k_reduce_step(const S
     const int icnt = a.n + CM_STAT_COUNT, slab_n = icnt / STEP_COLS;
     const int slab = blockIdx.x == 0 ? slab_n : ((int)blockIdx.x <= slab_n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
     const int i = slab * STEP_COLS + c;
-    float s = 0.f;
-    if (i < a.ntot) s = (i < a.isplit) ? step_colsum(a.part2, a.np2, a.PS2, i, g) : step_colsum<PEER>(a.part1, a.np1, a.PS1, i, g);
-    sh[g][c] = s;
+    float s[STEP_GPW];
+#pragma unroll
+    for (int j = 0; j < STEP_GPW; ++j) s[j] = 0.f;
+    if (i < a.ntot) {
+        if (i < a.isplit) step_colsum_gpw(a.part2, a.np2, a.PS2, i, g, s);
+        else step_colsum_gpw<PEER>(a.part1, a.np1, a.PS1, i, g, s);
+    }
+#pragma unroll
+    for (int j = 0; j < STEP_GPW; ++j) sh[g * STEP_GPW + j][c] = s[j];
     __syncthreads();
     if (g != 0) return;  // wave 0 finishes its 64 columns
     float t = 0.f;
@@ -306,7 +352,9 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
     const int grid = (int)((ntot + STEP_COLS - 1) / STEP_COLS);
     const double bc1 = 1.0 - pow(o->beta1, (double)o->step), bc2 = 1.0 - pow(o->beta2, (double)o->step);
     CM_REQUIRE(!peer_tags || (grid <= STEP_MAX_WG && o->scratch), "%s: the peer step needs the fused launch (<= %d parameters, a scratch)", who, STEP_MAX_WG * STEP_COLS);
-    if (grid > STEP_MAX_WG || !o->scratch) {
+    const bool small_offsets = (int64_t)np1 * PS1 < (1LL << 30) && (int64_t)np2 * PS2 < (1LL << 30);  // step_colsum_gpw's 32-bit offsets
+    CM_REQUIRE(!peer_tags || small_offsets, "%s: mailbox too large for the fused step", who);
+    if (grid > STEP_MAX_WG || !o->scratch || !small_offsets) {
         // beyond the scratch's sumsq slots (or no scratch): plain reduction + the stand-alone step
         hipLaunchKernelGGL(k_reduce_cols, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, part1, np1, PS1, part2, np2, PS2, isplit, (int)ntot, grad_and_stats);
         CM_CHECK_LAUNCH(who);
@@ -324,14 +372,14 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
     a.tag = next_step_tag();
     a.peer_tags = peer_tags; a.peer_seq = peer_seq;
     if (o->max_norm > 0.0) {
-        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<false, true>), dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
-        else hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<false, true>), dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
+        else hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         const int ugrid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(ugrid), dim3(UPD_THREADS), 0, s, o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq,
                            (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm);
     } else {
-        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<true, true>), dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
-        else hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, a);
+        if (peer_tags) hipLaunchKernelGGL((k_reduce_step<true, true>), dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
+        else hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
     }
     CM_CHECK_LAUNCH(who);
     return 0;

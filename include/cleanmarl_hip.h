@@ -73,6 +73,10 @@ int cm_version(void);
  *   "wide_schedule"    auto | fused | layered  MLPs of 65 .. 128 hidden units with one hidden->hidden layer (the reference's COMA critic
  *                                              default, cleanmarl/coma_multienvs.py:35): one-launch fused tile (csrc/cm_mlp_fused128.h, the
  *                                              default) vs the layer-by-layer schedule every wider / deeper shape runs (csrc/cm_mlp_wide.h)
+ *   "dw0_batch"        auto | 8 | 4            rows in flight per lane of the streaming layer-0 weight-gradient product of the split
+ *                                              critic schedule (csrc/cm_mlp_split.h): 16 rows (234 registers) or 8 rows (fits one wave on
+ *                                              every SIMD beside the six-wave rollout the two-stream schedule runs it under); auto = 8 rows
+ *                                              up to 2^16 rows per launch.  Same summation order, bit-identical results.
  * cm_set_option returns 0, or -1 for an unknown key / value; cm_get_option returns the current value's name (NULL: unknown key). */
 int cm_set_option(const char* key, const char* value);
 const char* cm_get_option(const char* key);
