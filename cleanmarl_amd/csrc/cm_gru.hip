@@ -862,11 +862,11 @@ static size_t gru_ps(int din, int hidden, int K) {
     return (size_t)((cm_gru_param_count(din, hidden, K) + CM_NUM_STATS + 63) / 64 * 64);
 }
 
-static bool gru_wide(int din, int hidden) { return din > KC || hidden > HP; }  // layered schedule (cm_gru_wide.hip)
+static bool gru_wide(int din, int hidden, int K = 1) { return din > KC || hidden > HP || K > KMAX; }  // layered schedule (cm_gru_wide.hip)
 
 extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int n_actions, int chunk_len) {
     const size_t R = (size_t)E * A;
-    if (gru_wide(din, hidden)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
+    if (gru_wide(din, hidden, n_actions)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
     // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
     // + the pipelined sweeps' hand-over areas: step flags of k_gru2_fwdx (four 8-byte words per 32-row tile), {dh_t, tag} words of k_gru2_bwd<true>
     return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8 + (size_t)chunk_len * R * HP * 8;
@@ -890,7 +890,7 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
                           double ppo_clip, double entropy_coef,
                           float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream, const cm_opt_step_t* opt) {
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T, "cm_gru_actor_chunk_fwd_bwd: bad dims E=%d A=%d T=%d t0=%d t1=%d", E, A, T, t0, t1);
-    if (gru_wide(din, hidden))
+    if (gru_wide(din, hidden, n_actions))
         return cm_gru_wide_chunk(obs, avail, action, logp_old, adv, ep_len, E, A, T, t0, t1, din, hidden, n_actions, params, h_in, h_out, ppo_clip,
                                  entropy_coef, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, opt);
     if (int rc = gru_check("cm_gru_actor_chunk_fwd_bwd", din, hidden, n_actions)) return rc;
@@ -1046,7 +1046,7 @@ extern "C" int cm_gru_policy_act_ws(const float* x, int64_t x_row_stride, const 
                                     void* ws, size_t ws_bytes, cm_stream_t stream) {
     CM_REQUIRE(h != nullptr, "cm_gru_policy_act_ws: hidden state pointer is NULL");
     CM_REQUIRE(eps <= 0.0, "cm_gru_policy_act_ws: eps=%g (the recurrent scripts have no epsilon-mixed exploration; eps < 0 = greedy)", eps);
-    if (!gru_wide(din, hidden) && eps == 0.0)  // the fused step kernel
+    if (!gru_wide(din, hidden, n_actions) && eps == 0.0)  // the fused step kernel
         return cm_gru_policy_act(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_actions, params, h, seed, row_offset, t, action, logp,
                                  out_stride, stream);
     return cm_gru_wide_act(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_actions, params, h, seed, row_offset, t, (float)eps, action,

@@ -105,7 +105,8 @@ struct GwLossArgs {
     long R; int A, T, t0, CL, K; float clip_lo, clip_hi, clip_eps, ent_coef;
 };
 // PPO head of the chunk (formulas of k_wide_loss<M_ACTOR> / the fused epilogue; cleanmarl/mappo_lstm_multienvs.py:580-607): one thread
-// per (step, sequence); logits [CL R][KMAX] -> d(loss)/d(logits) in place, statistics as per-workgroup partials
+// per (step, sequence); logits [CL R][KCAP] -> d(loss)/d(logits) in place, statistics as per-workgroup partials (KCAP = wide_kw(K): 32 or 64)
+template <int KCAP>
 __global__ __launch_bounds__(NTHREADS) void k_gw_loss(const GwLossArgs a, float* __restrict__ out, float* __restrict__ partial) {
     __shared__ float red[6][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,23 +119,23 @@ __global__ __launch_bounds__(NTHREADS) void k_gw_loss(const GwLossArgs a, float*
         const int e = (int)(seq / a.A), ag = (int)(seq - (long)e * a.A);
         const long idx = seq * a.T + t;
         const bool valid = t < a.ep_len[e];
-        float* z = out + row * KMAX;
+        float* z = out + row * KCAP;
         const int act = a.action[idx];
-        float zr[KMAX], p[KMAX];
+        float zr[KCAP], p[KCAP];
         float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KCAP; ++k) {
             zr[k] = -INFINITY;
             if (k < a.K) zr[k] = a.avail[idx * a.K + k] ? z[k] : -1e9f;  // masked_fill(~avail, -1e9), :182
             m = fmaxf(m, zr[k]);
         }
         float sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { p[k] = k < a.K ? expf(zr[k] - m) : 0.0f; sum += p[k]; }
+        for (int k = 0; k < KCAP; ++k) { p[k] = k < a.K ? expf(zr[k] - m) : 0.0f; sum += p[k]; }
         const float rs = 1.0f / sum, lse = m + logf(sum), advv = a.adv[idx];
         float ent = 0.0f, lpa = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k < KCAP; ++k)
             if (k < a.K) {
                 const float lp = zr[k] - lse;
                 p[k] *= rs;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gw_loss(const GwLossArgs a, float*
         }
         const float gr = g * ratio;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KCAP; ++k) {
             float d = 0.0f;
             if (k < a.K) {
                 const float lp = zr[k] - lse;
@@ -194,7 +195,7 @@ inline GwWs gw_ws(long R, int CL, int din, int H, int K, bool train) {
     w.gh = p; p += gw_al((size_t)R * 3 * Hs);
     w.hall = p; p += gw_al((SR + R) * Hs);
     w.hr = p; p += gw_al(SR * Hs);
-    w.out = p; p += gw_al(SR * KMAX);
+    w.out = p; p += gw_al(SR * wide_kw(K));
     w.rzn = w.ghn = w.dhh = w.dgi = w.dgh = w.rec = w.dhz = w.dz1 = w.wthh = w.wtih = w.wt2 = w.part = p;
     if (train) {
         w.rzn = p; p += gw_al(SR * 3 * Hs);
@@ -207,7 +208,7 @@ inline GwWs gw_ws(long R, int CL, int din, int H, int K, bool train) {
         w.dz1 = p; p += gw_al(SR * Hs);
         w.wthh = p; p += gw_al((size_t)H * 3 * Hs);
         w.wtih = p; p += gw_al((size_t)H * 3 * Hs);
-        w.wt2 = p; p += gw_al((size_t)H * KMAX);
+        w.wt2 = p; p += gw_al((size_t)H * wide_kw(K));
         w.part = p;
         const size_t kmax = (size_t)max(w.dl, (int)Hs);
         p += max((size_t)DW0_GRID * 64 * kmax, max((size_t)CS_GRID * WIDE_HMAX, (size_t)LOSS_GRID * CM_NUM_STATS));
@@ -219,7 +220,7 @@ inline GwWs gw_ws(long R, int CL, int din, int H, int K, bool train) {
 inline int gw_check(const char* who, int din, int H, int K) {
     CM_REQUIRE(din > 0 && H > 0 && K > 0, "%s: bad dims din=%d H=%d K=%d", who, din, H, K);
     CM_REQUIRE(H <= WIDE_HMAX, "%s: hidden_dim=%d > %d is not supported by this build", who, H, WIDE_HMAX);
-    CM_REQUIRE(K <= KMAX, "%s: n_actions=%d > %d is not supported by this build", who, K, KMAX);
+    CM_REQUIRE(K <= KWMAX, "%s: n_actions=%d > %d is not supported by this build", who, K, KWMAX);
     return 0;
 }
 
@@ -270,21 +271,23 @@ int cm_gru_wide_chunk(const float* obs, const uint8_t* avail, const int32_t* act
     }
     CM_CHECK_LAUNCH(who);
     // ---------------- head over the chunk: logits -> PPO loss -> dlogits, statistics
-    wide_gemm<EPI_BIAS>(hr, Hs, SR, H, params + off.W2, H, K, params + off.b2, nullptr, 0, nullptr, 0, out, KMAX, KMAX, s);
+    const int kw = wide_kw(K);
+    wide_gemm<EPI_BIAS>(hr, Hs, SR, H, params + off.W2, H, K, params + off.b2, nullptr, 0, nullptr, 0, out, kw, kw, s);
     {
         GwLossArgs la = {avail, action, logp_old, adv, ep_len, R, A, T, t0, CL, K, (float)(1.0 - ppo_clip), (float)(1.0 + ppo_clip), (float)ppo_clip,
                          (float)entropy_coef};
         const int grid = (int)min((SR + NTHREADS - 1) / NTHREADS, (long)LOSS_GRID);
-        hipLaunchKernelGGL(k_gw_loss, dim3(grid), dim3(NTHREADS), 0, s, la, out, part);
+        if (kw == KMAX) hipLaunchKernelGGL(k_gw_loss<KMAX>, dim3(grid), dim3(NTHREADS), 0, s, la, out, part);
+        else hipLaunchKernelGGL(k_gw_loss<KWMAX>, dim3(grid), dim3(NTHREADS), 0, s, la, out, part);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(RED_COLS * RED_GROUPS), 0, s, part, grid, CM_NUM_STATS, 0, CM_NUM_STATS, g + off.P);
         CM_CHECK_LAUNCH(who);
     }
-    if (int rc = stream_dw<true>(out, hr, SR, H, K, part, g + off.W2, s, who, KMAX, Hs)) return rc;
-    wide_colsum(out, KMAX, SR, K, part, g + off.b2, s);
+    if (int rc = stream_dw<true>(out, hr, SR, H, K, part, g + off.W2, s, who, kw, Hs)) return rc;
+    wide_colsum(out, kw, SR, K, part, g + off.b2, s);
     {   // dh_head = (dlogits W2) .* (h' > 0)
         const int ldt = (K + 3) / 4 * 4;
         hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, params + off.W2, K, H, f + w.wt2, ldt);
-        wide_gemm<EPI_GATE>(out, KMAX, SR, ldt, f + w.wt2, ldt, H, nullptr, nullptr, 0, hr, Hs, dhh, Hs, Hs, s);
+        wide_gemm<EPI_GATE>(out, kw, SR, ldt, f + w.wt2, ldt, H, nullptr, nullptr, 0, hr, Hs, dhh, Hs, Hs, s);
     }
     // ---------------- reverse recurrence
     hipLaunchKernelGGL(k_gw_transpose3, dim3((H * 3 * Hs + 255) / 256), dim3(256), 0, s, params + off.Whh, H, Hs, f + w.wthh);
@@ -338,9 +341,9 @@ int cm_gru_wide_act(const float* x, int64_t x_stride, const uint8_t* avail, int6
     gw_gates_gemm(hall, Hs, rows, H, Hs, params + off.Whh, params + off.bhh, gh, s);
     hipLaunchKernelGGL(k_gw_gates_fwd, dim3(gw_blocks(rows * Hs)), dim3(256), 0, s, gi, gh, hall, rows, H, Hs, nullptr, nullptr,
                        hall + (size_t)rows * Hs, hr, h);
-    wide_gemm<EPI_BIAS>(hr, Hs, rows, H, params + off.W2, H, K, params + off.b2, avail, avail_stride, nullptr, 0, out, KMAX, KMAX, s);
+    wide_gemm<EPI_BIAS>(hr, Hs, rows, H, params + off.W2, H, K, params + off.b2, avail, avail_stride, nullptr, 0, out, wide_kw(K), wide_kw(K), s);
     hipLaunchKernelGGL(k_wide_sample, dim3(gw_blocks(rows)), dim3(256), 0, s, out, (long)rows, K, (unsigned long long)seed, (long)row_offset, t, eps,
-                       action, logp, (long)out_stride);
+                       action, logp, (long)out_stride, wide_kw(K));
     CM_CHECK_LAUNCH(who);
     return 0;
 }

@@ -12,7 +12,7 @@ extern "C" size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden
 
 /* rows-aware query: the layered schedule of wide / deep actors keeps its activations in the workspace */
 extern "C" size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions) {
-    if (wide_shape(hidden, n_hidden_layers)) return wide_ws_bytes((long)E * A * T, din, hidden, n_hidden_layers, n_actions, true);
+    if (wide_shape(hidden, n_hidden_layers, n_actions)) return wide_ws_bytes((long)E * A * T, din, hidden, n_hidden_layers, n_actions, true);
     return train_ws_bytes(din, hidden, n_hidden_layers, n_actions);
 }
 
@@ -29,7 +29,7 @@ static int actor_pass(const float* obs, int64_t obs_ld, const uint8_t* avail, co
                       const float* params, double ppo_clip, double entropy_coef,
                       float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream, const cm_opt_step_t* opt) {
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && obs_ld >= din, "cm_ppo_actor_fwd_bwd: bad dims E=%d A=%d T=%d ld=%lld din=%d", E, A, T, (long long)obs_ld, din);
-    if (wide_shape(hidden, n_hidden_layers)) {  // layered schedule (cm_mlp_wide.h)
+    if (wide_shape(hidden, n_hidden_layers, n_actions)) {  // layered schedule (cm_mlp_wide.h)
         MlpArgs a = {};
         a.x = obs; a.x_stride = obs_ld; a.rows = (long)E * A * T; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
         a.params = params; a.avail = avail; a.avail_stride = n_actions;

@@ -29,7 +29,7 @@ extern "C" int cm_mlp_forward(const float* x, int64_t rows, int din, int hidden,
 /* cm_mlp_forward with a caller workspace: also covers the shapes of the layered schedule (hidden 65..256, any depth), whose
  * activations live in the workspace.  cm_mlp_forward_workspace_bytes is 0 for shapes the fused kernel covers. */
 extern "C" size_t cm_mlp_forward_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int dout) {
-    return wide_shape(hidden, n_hidden_layers) ? wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, false)
+    return wide_shape(hidden, n_hidden_layers, dout) ? wide_ws_bytes((long)rows, din, hidden, n_hidden_layers, dout, false)
                                               : w0_image_floats(din, hidden) * sizeof(float);  // optional: the padded W0 image of the _ld form
 }
 /* bytes of the optional scratch of the *_ld inference entry points (padded W0 image; 0 when W0 is not streamed or its rows are aligned) */
@@ -37,7 +37,7 @@ extern "C" size_t cm_w0_image_bytes(int din, int hidden) { return w0_image_float
 
 extern "C" int cm_mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                                  const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
-    if (!wide_shape(hidden, n_hidden_layers)) return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream, ws, ws_bytes);
+    if (!wide_shape(hidden, n_hidden_layers, dout)) return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream, ws, ws_bytes);
     CM_REQUIRE(x_ld >= din, "cm_mlp_forward_ld: leading dimension %lld < din %d", (long long)x_ld, din);
     if (rows <= 0) return 0;
     MlpArgs a = {};
@@ -106,7 +106,7 @@ extern "C" int cm_policy_act_greedy(const float* x, int64_t x_row_stride, const 
  * mixture, eps < 0 takes the argmax.  Same Philox keying (seed, row_offset + row, t) for every shape.  The query is 0 for
  * shapes the fused kernel covers. */
 extern "C" size_t cm_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions) {
-    return wide_shape(hidden, n_hidden_layers) ? wide_ws(rows, din, hidden, n_hidden_layers, n_actions, false, true).total * sizeof(float) : 0;
+    return wide_shape(hidden, n_hidden_layers, n_actions) ? wide_ws(rows, din, hidden, n_hidden_layers, n_actions, false, true).total * sizeof(float) : 0;
 }
 
 extern "C" int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
@@ -114,7 +114,7 @@ extern "C" int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint
                                 double eps, uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp,
                                 int64_t out_stride, void* ws, size_t ws_bytes, cm_stream_t stream) {
     CM_REQUIRE(eps <= 1.0, "cm_policy_act_ws: eps=%g > 1", eps);
-    if (!wide_shape(hidden, n_hidden_layers)) {
+    if (!wide_shape(hidden, n_hidden_layers, n_actions)) {
         if (eps < 0.0) return cm_policy_act_greedy(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_hidden_layers, n_actions,
                                                    params, action, logp, out_stride, stream);
         if (eps > 0.0) return cm_policy_act_eps(x, x_row_stride, avail, avail_row_stride, rows, din, hidden, n_hidden_layers, n_actions,

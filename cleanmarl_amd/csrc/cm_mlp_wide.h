@@ -32,7 +32,9 @@ enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_
 
 #define WIDE_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-inline bool wide_shape(int H, int L) { return H > HP || L > LMAX; }
+constexpr int KWMAX = 64;  // widest head of the layered schedule (the fused kernels' heads stop at KMAX = 32: SMAC maps with more than 26 enemies)
+inline int wide_kw(int dout) { return dout <= KMAX ? KMAX : KWMAX; }  // row stride of the logits / dlogits plane
+inline bool wide_shape(int H, int L, int dout = 1) { return H > HP || L > LMAX || dout > KMAX; }
 inline int wide_hs(int H) { return (H + 63) / 64 * 64; }  // activation row stride (zero padded; whole 64-unit slabs)
 
 // Y[r][n] = epi( sum_k X[r][k] * W[n][k] ),  n < N <= 32 * NJ, k < K.  Columns N..ncols-1 of Y are written as zeros.
@@ -419,13 +421,13 @@ __device__ __forceinline__ void wide_loss_row(const MlpArgs& a, long row, float*
     }
 }
 
-template <int MODE>
+template <int MODE, int KCAP = KMAX>
 __global__ __launch_bounds__(NTHREADS) void k_wide_loss(const MlpArgs a, float* __restrict__ out, float* __restrict__ partial) {
     __shared__ float red[6][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long row = (long)blockIdx.x * NTHREADS + tid; row < a.rows; row += (long)gridDim.x * NTHREADS)
-        wide_loss_row<MODE>(a, row, out + row * KMAX, sv);
+        wide_loss_row<MODE, KCAP>(a, row, out + row * KCAP, sv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const float v = cm_wave_sum(sv[i]);
@@ -447,7 +449,7 @@ inline WideWs wide_ws(long rows, int din, int H, int L, int dout, bool train, bo
     const size_t plane = ((size_t)rows * w.Hs + 63) / 64 * 64;
     w.act = p; p += (train ? (size_t)(L + 1) : 2) * plane;  // forward only: two ping-pong planes
     w.dz = p; if (train) p += 2 * plane;
-    w.out = p; if (train || with_out) p += ((size_t)rows * KMAX + 63) / 64 * 64;
+    w.out = p; if (train || with_out) p += ((size_t)rows * wide_kw(dout) + 63) / 64 * 64;
     w.wt = p; if (train) p += (size_t)WIDE_HMAX * WIDE_HMAX;
     const int kmax = max(din, w.Hs);
     w.part = p;
@@ -461,7 +463,7 @@ inline size_t wide_ws_bytes(long rows, int din, int H, int L, int dout, bool tra
 inline int wide_check(const char* who, int din, int H, int L, int dout) {
     CM_REQUIRE(din > 0 && H > 0 && L >= 0 && dout > 0, "%s: bad dims din=%d H=%d L=%d dout=%d", who, din, H, L, dout);
     CM_REQUIRE(H <= WIDE_HMAX, "%s: hidden_dim=%d > %d is not supported by this build", who, H, WIDE_HMAX);
-    CM_REQUIRE(dout <= KMAX, "%s: output width %d > %d is not supported by this build", who, dout, KMAX);
+    CM_REQUIRE(dout <= KWMAX, "%s: output width %d > %d is not supported by this build", who, dout, KWMAX);
     return 0;
 }
 
@@ -471,7 +473,7 @@ inline int wide_forward_layers(const MlpArgs& a, float* wsf, const WideWs& w, bo
     const Offsets off = make_offsets(a.din, a.H, a.L, a.dout);
     const size_t plane = ((size_t)a.rows * w.Hs + 63) / 64 * 64;
     auto act = [&](int l) { return wsf + w.act + (size_t)(train ? l : (l & 1)) * plane; };
-    if (fused128_shape(a.H, a.L)) {  // one launch (cm_mlp_fused128.h); inputs wider than 64 columns: layer 0's product first
+    if (fused128_shape(a.H, a.L) && a.dout <= KMAX) {  // one launch (cm_mlp_fused128.h); inputs wider than 64 columns: layer 0's product first
         F128X e = {};
         e.z0 = a.z0_add; e.ldz0 = w.Hs; e.y = y; e.ldy = ldy; e.ncols = ncols; e.vecx = x_rows_vec(a) ? 1 : 0;
         if (a.din > KC) {
@@ -502,15 +504,15 @@ inline int wide_forward(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t
     return wide_forward_layers(a, (float*)ws, w, false, a.y, a.dout, a.dout, s, who);
 }
 
-// Actor.act for wide shapes: layered forward to masked logits [rows][KMAX] in the workspace, then one thread per row draws with the
+// Actor.act for wide shapes: layered forward to masked logits [rows][wide_kw(K)] in the workspace, then one thread per row draws with the
 // SAME Philox keying and samplers as the fused M_ACT kernel (eps > 0: COMA's mixed sampling, eps < 0: greedy)
 __global__ void k_wide_sample(const float* __restrict__ logits, long rows, int K, unsigned long long seed, long row_offset, int t,
-                              float eps, int* __restrict__ action, float* __restrict__ logp, long out_stride) {
+                              float eps, int* __restrict__ action, float* __restrict__ logp, long out_stride, int ldl) {
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     const unsigned long long gr = (unsigned long long)(row_offset + row);
     const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float* z = logits + row * KMAX;
+    const float* z = logits + row * ldl;
     int chosen; float lp;
     if (eps < 0.0f) cm_categorical_greedy(z, K, &chosen, &lp);
     else if (eps > 0.0f) cm_categorical_sample_eps(z, K, cm_u01(rnd.x), eps, &chosen, &lp);
@@ -524,9 +526,10 @@ inline int wide_act(const MlpArgs& a, void* ws, size_t ws_bytes, hipStream_t s, 
     const WideWs w = wide_ws(a.rows, a.din, a.H, a.L, a.dout, false, true);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
     float* out = (float*)ws + w.out;
-    if (int rc = wide_forward_layers(a, (float*)ws, w, false, out, KMAX, KMAX, s, who)) return rc;
+    const int kw = wide_kw(a.dout);
+    if (int rc = wide_forward_layers(a, (float*)ws, w, false, out, kw, kw, s, who)) return rc;
     hipLaunchKernelGGL(k_wide_sample, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, s, out, a.rows, a.dout, a.seed, a.row_offset, a.t,
-                       a.act_eps, a.action_out, a.logp_out, a.out_stride);
+                       a.act_eps, a.action_out, a.logp_out, a.out_stride, kw);
     CM_CHECK_LAUNCH(who);
     return 0;
 }
@@ -548,7 +551,7 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
     float* part = wsf + w.part;
     float* wt = wsf + w.wt;
     const int H = a.H, Hs = w.Hs;
-    if (fused128_shape(a.H, a.L)) {  // forward + loss + backward in one launch (cm_mlp_fused128.h)
+    if (fused128_shape(a.H, a.L) && a.dout <= KMAX) {  // forward + loss + backward in one launch (cm_mlp_fused128.h)
         MlpArgs b = a;
         const int64_t P = off.P;
         b.partial = part; b.PS = (int)((P + CM_NUM_STATS + 63) / 64 * 64);
@@ -579,18 +582,20 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
         if (dz0_out) *dz0_out = dz;
         return 0;
     }
-    if (int rc = wide_forward_layers(a, wsf, w, true, out, KMAX, KMAX, s, who)) return rc;
+    const int kw = wide_kw(a.dout);
+    if (int rc = wide_forward_layers(a, wsf, w, true, out, kw, kw, s, who)) return rc;
     // ---- loss heads: logits -> dlogits in place, statistics
     {
         const int grid = (int)min((a.rows + NTHREADS - 1) / NTHREADS, (long)LOSS_GRID);
-        hipLaunchKernelGGL((k_wide_loss<MODE>), dim3(grid), dim3(NTHREADS), 0, s, a, out, part);
+        if (kw == KMAX) hipLaunchKernelGGL((k_wide_loss<MODE, KMAX>), dim3(grid), dim3(NTHREADS), 0, s, a, out, part);
+        else hipLaunchKernelGGL((k_wide_loss<MODE, KWMAX>), dim3(grid), dim3(NTHREADS), 0, s, a, out, part);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(RED_COLS * RED_GROUPS), 0, s, part, grid, CM_NUM_STATS, 0, CM_NUM_STATS,
                            grad_and_stats + off.P);
         CM_CHECK_LAUNCH(who);
     }
     // ---- head: dWout = dOut^T act_L, dbout, dZ_L = (dOut Wout) .* relu'(act_L)
-    if (int rc = stream_dw<true>(out, act(a.L), a.rows, H, a.dout, part, grad_and_stats + off.Wout, s, who, KMAX, Hs)) return rc;
-    wide_colsum(out, KMAX, a.rows, a.dout, part, grad_and_stats + off.bout, s);
+    if (int rc = stream_dw<true>(out, act(a.L), a.rows, H, a.dout, part, grad_and_stats + off.Wout, s, who, kw, Hs)) return rc;
+    wide_colsum(out, kw, a.rows, a.dout, part, grad_and_stats + off.bout, s);
     float* dz = wsf + w.dz;
     float* dz2 = dz + plane;
     {
@@ -598,7 +603,7 @@ inline int wide_train(const MlpArgs& a, float* grad_and_stats, void* ws, size_t 
         hipLaunchKernelGGL(k_wide_transpose, dim3((H * ldt + 255) / 256), dim3(256), 0, s, a.params + off.Wout, a.dout, H, wt, ldt);
         // Wt[h][k] = Wout[k][h]: N = H output columns, contraction over the ldt (zero padded) head outputs
         // the bias gradient of the layer that produced act(L) = column sums of dZ_L, accumulated in the GEMM's epilogue
-        wide_gemm<EPI_GATE>(out, KMAX, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(a.L), Hs, dz, Hs, Hs, s, part,
+        wide_gemm<EPI_GATE>(out, kw, a.rows, ldt, wt, ldt, H, nullptr, nullptr, 0, act(a.L), Hs, dz, Hs, Hs, s, part,
                             grad_and_stats + (a.L >= 1 ? off.bl(a.L - 1) : off.b0));
         CM_CHECK_LAUNCH(who);
     }

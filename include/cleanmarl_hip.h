@@ -116,7 +116,7 @@ int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t* avail, in
                   const float* params, uint64_t seed, int64_t row_offset, int t,
                   int32_t* action, float* logp, int64_t out_stride, cm_stream_t stream);
 /* The three act entry points (cm_policy_act, cm_policy_act_eps, cm_policy_act_greedy) behind one with a caller workspace, which
- * also covers actors of the layered schedule (hidden 65..256, any depth): eps == 0 samples Categorical(logits), eps in (0, 1]
+ * also covers actors of the layered schedule (hidden 65..256, any depth, or 33..64 actions): eps == 0 samples Categorical(logits), eps in (0, 1]
  * samples COMA's mixture, eps < 0 takes the argmax.  Same Philox keying for every shape; the query is 0 for fused shapes. */
 size_t cm_policy_act_workspace_bytes(int64_t rows, int din, int hidden, int n_hidden_layers, int n_actions);
 int cm_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* avail, int64_t avail_row_stride,
@@ -164,7 +164,7 @@ int cm_normalize(float* x, const int32_t* ep_len, int E, int A, int T,
  * but not by N = b_mask.sum()); the division by the (global) N happens in cm_grad_norm_clip_adam so
  * that env-sharded ranks can all-reduce the buffer first. */
 size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden_layers, int dout);
-/* rows-aware query (use this one): also sizes the layered schedule of wide / deep actors (hidden 65..256, any depth) */
+/* rows-aware query (use this one): also sizes the layered schedule of wide / deep actors (hidden 65..256, any depth, or 33..64 actions) */
 size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions);
 int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action,
                          const float* logp_old, const float* adv, const int32_t* ep_len,

@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
     ("ippo", 5, 4, 12, 115, 40, 17, 128, 5),     # both: SMAClite-shaped obs on a 128-wide GRU
     ("mappo", 130, 2, 7, 70, 30, 6, 128, 7),     # several row tiles, one chunk
     ("mappo", 4, 2, 9, 33, 20, 4, 200, 3),       # more than three 64-unit slabs
+    ("ippo", 7, 3, 13, 35, 50, 36, 64, 5),       # a fused-size GRU whose head has more than 32 actions (64-wide logits plane)
+    ("mappo", 5, 2, 9, 70, 30, 64, 96, 4),       # widest head
 ])
 def test_layered_gru_update_matches_oracle(algo, E, A, T, Do, Ds, K, H, tb, fused_step):
     from oracle import restatement as R
@@ -51,7 +53,7 @@ def test_layered_gru_update_matches_oracle(algo, E, A, T, Do, Ds, K, H, tb, fuse
         assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
 
 
-@pytest.mark.parametrize("rows,Do,Hd,K", [(150, 115, 64, 17), (70, 35, 128, 5), (33, 70, 96, 6), (150, 35, 64, 5)])
+@pytest.mark.parametrize("rows,Do,Hd,K", [(150, 115, 64, 17), (70, 35, 128, 5), (33, 70, 96, 6), (90, 35, 64, 36), (150, 35, 64, 5)])
 def test_layered_gru_policy_act_matches_oracle(rows, Do, Hd, K):
     """cm_gru_policy_act_ws: hidden state, sampled action and log-prob vs the CPU oracle + sampler; greedy (eps < 0) = argmax of the
     masked logits.  The last shape is a FUSED one: the workspace entry point must hand it to the fused step kernel unchanged."""

@@ -105,6 +105,10 @@ def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
     ("mappo", 9, 2, 17, 70, 140, 6, 200, 0),    # no hidden->hidden layer, 200 units
     ("mappo", 7, 3, 11, 21, 54, 5, 32, 4),      # narrow but deep
     ("mappo", 5, 2, 300, 24, 48, 5, 256, 2),    # widest supported, several row tiles
+    # more than 32 actions (SMAC's 27m_vs_30m has 36): the layered schedule's 64-wide head, whatever the hidden width
+    ("ippo", 12, 4, 15, 37, 50, 36, 64, 1),     # a shape the fused kernels would serve but for its head
+    ("mappo", 9, 3, 17, 70, 140, 64, 128, 1),   # widest head; 128 units with one hidden->hidden layer stay OFF the fused 128-wide tile
+    ("ippo", 6, 3, 20, 140, 10, 33, 96, 2),     # one action past the fused head, 1.5 slabs, wide observations
 ])
 def test_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, L):
     _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize=True)
@@ -373,8 +377,8 @@ def test_policy_act_matches_cpu_sampler():
     assert (action[:, :, untouched] == -7).all() and (logp[:, :, untouched] == 9.0).all()
 
 
-@pytest.mark.parametrize("H,L", [(64, 1), (128, 1), (200, 3), (32, 4)])
-def test_policy_act_ws_matches_cpu_sampler_for_fused_and_layered_shapes(H, L):
+@pytest.mark.parametrize("H,L,K", [(64, 1, 9), (128, 1, 9), (200, 3, 9), (32, 4, 9), (64, 1, 36), (128, 1, 64)])
+def test_policy_act_ws_matches_cpu_sampler_for_fused_and_layered_shapes(H, L, K):
     """cm_policy_act_ws (the three act modes behind one entry point; layered schedule for wide / deep actors) vs oracle/sampling.py."""
     import ctypes as C
     from oracle import restatement as R
@@ -384,7 +388,7 @@ def test_policy_act_ws_matches_cpu_sampler_for_fused_and_layered_shapes(H, L):
     lib = N.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(6)
-    E, A, T, Do, K, t = 29, 5, 7, 40, 9, 4
+    E, A, T, Do, t = 29, 5, 7, 40, 4
     spec = NetSpec(Do, H, L, K)
     p = init_params_like_torch(spec)
     obs = torch.randn(E, A, T, Do)
@@ -392,7 +396,7 @@ def test_policy_act_ws_matches_cpu_sampler_for_fused_and_layered_shapes(H, L):
     avail[..., 2] = True
     d_obs, d_av, d_p = obs.to(dev), avail.to(torch.uint8).to(dev), flatten_params(p, dev)
     need = lib.cm_policy_act_workspace_bytes(E * A, Do, H, L, K)
-    assert (need == 0) == (H <= 64 and L <= 2)
+    assert (need == 0) == (H <= 64 and L <= 2 and K <= 32)  # heads wider than 32 actions: layered schedule (64-wide logits plane)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     av_t = avail[:, :, t].reshape(E * A, K).numpy()
     logits = R.actor_logits(p, obs[:, :, t].reshape(E * A, Do), avail[:, :, t].reshape(E * A, K)).numpy()
@@ -430,6 +434,21 @@ def test_wide_actor_rollout_and_training_run_end_to_end(env_type, tmp_path, monk
     out = run("mappo_multienvs", [f"--env_type={env_type}", "--batch_size=8", "--synthetic_steps=10", "--total_timesteps=400",
                                   "--actor_hidden_dim=128", "--critic_hidden_dim=128", "--critic_num_layers=3", "--log_every=1",
                                   "--eval_steps=2", "--num_eval_ep=2"])
+    assert all(math.isfinite(v) for _, v, _ in out["history"])
+    assert out["training_step"] >= 3 and "eval/ep_reward" in {t for t, _, _ in out["history"]}
+
+
+@pytest.mark.parametrize("script,env_type", [("ippo_multienvs", "synthetic_shape"), ("mappo_multienvs", "synthetic_shape_cpu"),
+                                             ("mappo_lstm_multienvs", "synthetic_shape")])
+def test_scripts_run_with_more_than_32_actions(script, env_type, tmp_path, monkeypatch):
+    """36 actions (SMAC's 27m_vs_30m: 6 + 30 enemies) through the CLI at the reference's default network widths: the act passes, the
+    actor's training pass and greedy evaluation leave the fused kernels (heads up to 32 actions) for the layered schedule's 64-wide head."""
+    import math
+    from cleanmarl_amd.driver import run
+    monkeypatch.chdir(tmp_path)
+    out = run(script, [f"--env_type={env_type}", "--batch_size=6", "--synthetic_agents=4", "--synthetic_steps=9", "--synthetic_obs=40",
+                       "--synthetic_state=60", "--synthetic_actions=36", "--total_timesteps=300", "--log_every=1", "--eval_steps=2",
+                       "--num_eval_ep=2"])
     assert all(math.isfinite(v) for _, v, _ in out["history"])
     assert out["training_step"] >= 3 and "eval/ep_reward" in {t for t, _, _ in out["history"]}
 
