@@ -571,6 +571,250 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
     PH_FLUSH;
 }
 
+// Six-wave form of the fused GRU rollout (round 3; the role split of cm_rollout.hip's six-wave kernels): waves 0-3 run the chain
+// obs tile -> gru2_step -> head -> sample + physics exactly as k_gru32_rollout does; everything that only CONSUMES a step moves off it:
+//   * wave 4 (writer) copies the step's obs tile to the rollout buffer (obs rows while the chain is in its first products, state rows
+//     during the x-products; the tile is stable from the barrier after the obs build to the top of the next step);
+//   * wave 5 (scorer) takes the reward partials + reward store of step t - 1 and the Philox uniforms of step t (LDS: uscr).
+// In the four-wave kernel those were 31 % of the step (phase profile: reward partials + obs build 2.7 k, buffer writes + Philox 4.3 k of
+// 22.5 k cycles).  Every wave passes the same five barriers per step (two of them inside gru2_step); the helpers' barriers order LDS
+// traffic only (lds_barrier), so their global stores stay in flight across steps.  Same arithmetic in the same order: bit-identical
+// buffers to k_gru32_rollout (option rollout_tile = 16 / 64 keeps the four-wave kernel; tests/test_hip_parity.py compares the two).
+constexpr int NT6R = 6 * 64;
+constexpr int G32R6_LDS_FLOATS = G32R_LDS_FLOATS + T32;  // + uscr
+
+__global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KJ = 2, KP = 8;
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    float* p = smem;
+    float* XA = p; p += T32 * LDT;   // obs tile
+    float* X1 = p; p += T32 * LDT;   // x1
+    float* hp = p; p += T32 * LDT;
+    float* hn = p; p += T32 * LDT;
+    GruLds L = {};
+    L.wouts = p; p += KP * HP;
+    L.b2 = p; p += KMAX;
+    L.red = p; p += 64;
+    float* ls = p; p += T32 * 8;
+    float* epos = p; p += T32 * 2;
+    float* evel = p; p += T32 * 2;
+    float* elm = p; p += T32 * 2;
+    float* rscr = p; p += 2 * T32;
+    long* obase = reinterpret_cast<long*>(p);  // 8-byte aligned: every carve above is a multiple of 2 floats
+    long* sbase = obase + T32;
+    float* uscr = reinterpret_cast<float*>(sbase + T32);  // [T32] the step's uniforms (scorer -> sampler)
+    const int tid = threadIdx.x;
+    // the role is wave-uniform and the compiler must know it (scalar branches: no helper registers live through the chain)
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool compute = role < 4;
+    const int hl = tid & 63;                   // lane of a helper wave
+    const int hrow = tid >> 2, hq = tid & 3;   // compute waves: four lanes per row
+    const int A = a.A, T = a.T, K = a.K, H = a.H, din = a.din;
+    const int EPT = T32 / A, RT = EPT * A, Ds = 6 * A * A;
+    G2W w;  // the seven weight blocks: this wave's 16 hidden columns in registers for the whole episode (cm_gru_step2.h)
+    if (compute) {
+        g2_load_weights<false>(w, a.params, off, din, H);
+        for (int i = tid; i < KP * HP; i += NTHREADS) {
+            const int k = i / HP, c = i % HP;
+            L.wouts[i] = (c < H && k < K) ? a.params[off.W2 + k * H + c] : 0.0f;
+        }
+        for (int i = tid; i < KMAX; i += NTHREADS) L.b2[i] = (i < K) ? a.params[off.b2 + i] : 0.0f;
+    }
+    PH_DECL
+    const int ntiles = (a.E + EPT - 1) / EPT;
+    const float inv_din = 1.0f / (float)din, inv_sw = 1.0f / (float)(6 * A);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int e0 = tile * EPT;
+        __syncthreads();
+        // ---- reset (cm_env.hip k_env_reset): thread per (env, agent) row; h = 0 at the start of the episode
+        if (tid < T32) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            const bool live = tid < RT && e < a.E;
+            obase[tid] = live ? (e * A + i) * (long)T * din : -1;
+            sbase[tid] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            if (live) {
+                const unsigned long long ge = (unsigned long long)(a.env_offset + e);
+                const cm_u4 ra = cm_philox4x32((uint32_t)ge, (uint32_t)a.episode, (uint32_t)i, CM_STREAM_ENV_RESET,
+                                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                epos[2 * tid] = 2.0f * cm_u01(ra.x) - 1.0f; epos[2 * tid + 1] = 2.0f * cm_u01(ra.y) - 1.0f;
+                elm[2 * tid] = 2.0f * cm_u01(ra.z) - 1.0f; elm[2 * tid + 1] = 2.0f * cm_u01(ra.w) - 1.0f;
+            } else {
+                epos[2 * tid] = epos[2 * tid + 1] = 0.0f; elm[2 * tid] = elm[2 * tid + 1] = 0.0f;
+            }
+            evel[2 * tid] = 0.0f; evel[2 * tid + 1] = 0.0f;
+        }
+        if (compute)  // the chain's waves only: hp / hn swap every step in THEIR loop, a helper's copy of the pointers does not
+            for (int i = tid; i < T32 * LDT; i += NTHREADS) hp[i] = 0.0f;
+        // scorer: nearest-agent distance per landmark, collisions per agent (current positions), then the env's reward of step ts.
+        // One wave: its LDS writes are performed in order before its later reads (no barrier needed, the wave runs in lockstep)
+        auto score = [&](int ts) {
+            if (hl < RT) {
+                const int el = hl / A, l = hl - el * A;
+                const float* pos = epos + el * 2 * A;
+                const float lx = elm[2 * hl], ly = elm[2 * hl + 1];
+                const float qx = pos[2 * l], qy = pos[2 * l + 1];
+                float best = 3.0e38f, col = 0.0f;
+                for (int j = 0; j < A; ++j) {
+                    const float dx = pos[2 * j] - lx, dy = pos[2 * j + 1] - ly;
+                    best = fminf(best, __builtin_amdgcn_sqrtf(dx * dx + dy * dy));
+                    if (j > l) {
+                        const float cx = qx - pos[2 * j], cy = qy - pos[2 * j + 1];
+                        if (__builtin_amdgcn_sqrtf(cx * cx + cy * cy) < GR_COLLIDE) col += 1.0f;
+                    }
+                }
+                rscr[hl] = best; rscr[T32 + hl] = col;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // compiler fence + the partials are in LDS
+            __builtin_amdgcn_wave_barrier();
+            if (hl < EPT && e0 + hl < a.E) {
+                float r = 0.0f;
+                for (int l = 0; l < A; ++l) r -= rscr[hl * A + l];
+                for (int l = 0; l < A; ++l) r -= rscr[T32 + hl * A + l];
+                a.reward[(long)(e0 + hl) * T + ts] = r;
+            }
+        };
+        // three step loops, one per role (separate live ranges: nothing of a helper's state occupies registers of the chain);
+        // every wave passes the same five barriers per step
+        if (compute) {
+            for (int t = 0; t < T; ++t) {
+                lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
+                PH(0);
+                // ---- observations of step t -> XA: 4 lanes per row (threads 0..127), lane hq handles entities j = hq, hq+4, ...
+                if (hrow < T32) {
+                    const int el = hrow / A, i = hrow - el * A;
+                    const bool live = hrow < RT && (e0 + el) < a.E;
+                    float* xr = XA + hrow * LDT;
+                    if (live) {
+                        const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
+                        const float px = pos[2 * i], py = pos[2 * i + 1];
+                        if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
+                        for (int j = hq; j < A; j += 4) {
+                            xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
+                            if (j != i) {
+                                const int jj = j < i ? j : j - 1;
+                                xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
+                                xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                            }
+                            if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
+                        }
+                        for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
+                    }
+                }
+                PH(1);
+                lds_barrier();  // B1: obs tile complete
+                PH(2);
+                gru2_step<false>(w, XA, X1, hp, hn, nullptr, nullptr, nullptr, nullptr, din, H);  // two barriers inside
+                PH(4);
+                if (hrow < T32) {
+                    unsigned char avb[KJ] = {1, 1};
+                    float zreg[KJ];
+                    gru_head_logits<KJ>(L, hn, K, avb, zreg);
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j)
+                        if (4 * j + hq < K) ls[hrow * 8 + 4 * j + hq] = zreg[j];
+                }
+                PH(5);
+                lds_barrier();  // B2: logits (and the scorer's uniforms)
+                PH(6);
+                if (tid < RT) {
+                    const int el = tid / A, i = tid - el * A;
+                    const long e = e0 + el;
+                    if (e < a.E) {
+                        int chosen; float lpv;
+                        cm_categorical_sample(ls + tid * 8, K, uscr[tid], &chosen, &lpv);
+                        const long o = (e * A + i) * (long)T + t;
+                        a.action[o] = chosen;
+                        a.logp[o] = lpv;
+                        const float ux = (chosen == 1) ? -GR_ACCEL : (chosen == 2 ? GR_ACCEL : 0.0f);
+                        const float uy = (chosen == 3) ? -GR_ACCEL : (chosen == 4 ? GR_ACCEL : 0.0f);
+                        const float vx = evel[2 * tid] * (1.0f - GR_DAMP) + ux * GR_DT;
+                        const float vy = evel[2 * tid + 1] * (1.0f - GR_DAMP) + uy * GR_DT;
+                        evel[2 * tid] = vx; evel[2 * tid + 1] = vy;
+                        epos[2 * tid] += vx * GR_DT; epos[2 * tid + 1] += vy * GR_DT;
+                    }
+                }
+                PH(7);
+                float* tmp = hp; hp = hn; hn = tmp;
+            }
+        } else if (role == 4) {
+            // writer geometry of this tile: row 16 * pass + (lane >> 2), columns (lane & 3) + 4k
+            long wob[2], wsb[2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int r = 16 * ps + (hl >> 2), el = r / A, i = r - el * A;
+                const long e = e0 + el;
+                const bool live = r < RT && e < a.E;
+                wob[ps] = live ? (e * A + i) * (long)T * din : -1;
+                wsb[ps] = live ? e * (long)T * Ds + (long)i * 6 * A : -1;
+            }
+            auto write_rows = [&](int ps, int t) {
+                if (wob[ps] < 0) return;
+                const int q = hl & 3;
+                const float* xs = XA + (16 * ps + (hl >> 2)) * LDT + q;
+                float* od = a.obs + wob[ps] + (long)t * din + q;
+                float* sd = a.state + wsb[ps] + (long)t * Ds + q;
+                float v[KC / 4];
+#pragma unroll
+                for (int k = 0; k < KC / 4; ++k) v[k] = xs[4 * k];
+#pragma unroll
+                for (int k = 0; k < KC / 4; ++k) {
+                    if (q + 4 * k < din) od[4 * k] = v[k];
+                    if (q + 4 * k < 6 * A) sd[4 * k] = v[k];
+                }
+            };
+            for (int t = 0; t < T; ++t) {
+                lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
+                // ---- writer: four lanes per row (lane q of a row: columns q, q + 4, ...), 16 rows per pass -- static LDS / global offsets,
+                // no index math and no dependent LDS read on the way (the flat enumeration of the four-wave kernel cost this single wave
+                // ~5 k cycles per step and made it the last arrival at the chain's barriers).  The first 6A columns of an obs row are
+                // also the agent's block of the env's state row: one LDS read feeds both stores.
+                lds_barrier();  // B1
+                lds_barrier();  // x1 complete (inside the chain's gru2_step)
+                write_rows(0, t);  // under the x-products
+                lds_barrier();  // h' complete
+                lds_barrier();  // B2
+                write_rows(1, t);  // under the sampler (one active wave, no products): the tile is rebuilt only after the next B0
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
+                // ---- scorer: the step's uniforms under the chain's first products (the sampler reads them after B2), the reward of step
+                // t - 1 (positions after its physics update: stable until this step's sampler) under the x-products
+                lds_barrier();  // B1 (nothing before it: the obs build is the shortest stretch of the chain)
+                if (hl < RT) {
+                    const int el = hl / A, i = hl - el * A;
+                    const unsigned long long gr = (unsigned long long)((a.env_offset + e0 + el) * A + i);
+                    const cm_u4 rnd = cm_philox4x32((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)t, CM_STREAM_ACT,
+                                                    (uint32_t)a.act_seed, (uint32_t)(a.act_seed >> 32));
+                    uscr[hl] = cm_u01(rnd.x);
+                }
+                lds_barrier();  // x1 complete
+                if (t > 0) score(t - 1);
+                lds_barrier();  // h' complete
+                lds_barrier();  // B2
+            }
+        }
+        __syncthreads();
+        if (role == 5) score(T - 1);
+        if (tid < RT) {
+            const int el = tid / A, i = tid - el * A;
+            const long e = e0 + el;
+            if (e < a.E) {
+                float* es = a.env_state + e * 6 * A;
+                es[2 * i] = epos[2 * tid]; es[2 * i + 1] = epos[2 * tid + 1];
+                es[2 * A + 2 * i] = evel[2 * tid]; es[2 * A + 2 * i + 1] = evel[2 * tid + 1];
+                es[4 * A + 2 * i] = elm[2 * tid]; es[4 * A + 2 * i + 1] = elm[2 * tid + 1];
+            }
+        }
+    }
+    PH_FLUSH;
+}
+
 template <int KJ, bool WV>
 __global__ __launch_bounds__(NTHREADS) void k_gru_chunk_bwd(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1074,8 +1318,15 @@ extern "C" int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int 
     const int EPT = T32 / A;
     const int ntiles = (E + EPT - 1) / EPT;
     const size_t lds = (size_t)G32R_LDS_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_gru32_rollout, dim3(ntiles < 256 ? ntiles : 256), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    const int tiling = cm_option(CM_OPTION_ROLLOUT_TILE);  // 16 / 64: the four-wave kernel; auto / 16s / 64s: writer + scorer waves
+    if (tiling == 16 || tiling == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_gru32_rollout, dim3(ntiles < 256 ? ntiles : 256), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    } else {
+        const size_t lds6 = (size_t)G32R6_LDS_FLOATS * sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru32_rollout6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+        hipLaunchKernelGGL(k_gru32_rollout6, dim3(ntiles < 256 ? ntiles : 256), dim3(NT6R), lds6, (hipStream_t)stream, a);
+    }
     CM_CHECK_LAUNCH("cm_gru_rollout_spread");
     return 0;
 }

@@ -65,7 +65,8 @@ int cm_version(void);
  *                                              on the idle CUs), eight-wave 32-row forward above, 64-row streaming sweeps from 512 64-row tiles;
  *                                              32: four-wave 32-row sweeps, 8w: eight-wave forward, 64: the 64-row sweeps at any batch size
  *   "rollout_tile"     auto | 64 | 16 | 16s | 64s   tiling of the fused rollout (64 / 16: four-wave workgroups; 64s / 16s: four compute
- *                                              waves + a writer and a scorer wave, the defaults)
+ *                                              waves + a writer and a scorer wave, the defaults); the fused GRU rollout: 64 / 16 = its
+ *                                              four-wave kernel, anything else = the six-wave one (bit-identical buffers)
  *   "mfma"             fp32 | bf16x3 | bf16    GEMM arithmetic of the PPO training passes: exact fp32 MFMA; error-compensated bf16
  *                                              (3 MFMAs per product, ~3e-6 of sum|a b|, inside the 1e-4 parity bar); single-pass bf16
  *                                              (1 MFMA per product, operands rounded to 8 bits: ~4e-3, its own looser parity tier);

@@ -517,12 +517,45 @@ def test_rollout_tilings_are_bit_identical(E, A, T, H, L, eps, monkeypatch):
                 assert torch.equal(x[k], y[k]), (tile, ep, k)
 
 
-@pytest.mark.parametrize("E,A,T,H", [(37, 5, 12, 64), (50, 3, 9, 32), (9, 8, 7, 64), (3, 1, 5, 48)])
-def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H):
-    """cm_gru_rollout_spread (one persistent launch, 32-row tiles, weights LDS-resident) ==
-    reset + T x (cm_gru_policy_act, cm_synth_env_step) with the same seeds."""
+@pytest.mark.parametrize("E,A,T,H", [(37, 5, 12, 64), (50, 3, 9, 32), (9, 8, 7, 64), (3, 1, 5, 48), (300, 5, 11, 64)])
+def test_fused_gru_rollout_six_wave_equals_four_wave(E, A, T, H, monkeypatch):
+    """The six-wave fused GRU rollout (writer + scorer waves off the step chain, the default) leaves the SAME BITS in every buffer as
+    the four-wave kernel (rollout_tile = 16); the last shape has more tiles than compute units (the tile loop runs twice)."""
     from cleanmarl_amd.gru import GRUSyntheticRollout
     from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(14)
+    spec = NetSpec(6 * A + A, H, 0, 5, "gru")
+    p = flatten_params(init_params_like_torch(spec), dev)
+    outs = {}
+    for tile in ("16", "auto"):
+        if tile == "auto":
+            monkeypatch.delenv("CM_ROLLOUT_TILE", raising=False)
+        else:
+            monkeypatch.setenv("CM_ROLLOUT_TILE", tile)
+        r = GRUSyntheticRollout(E, A, T, seed=5, device=dev, env_offset=77)
+        eps = []
+        for _ in range(2):
+            b = r.collect(p, spec, fused=True)
+            torch.cuda.synchronize()
+            eps.append({k: getattr(b, k).clone() for k in ("obs", "state", "action", "logp", "reward")} | {"env": r.env_state.clone()})
+        outs[tile] = eps
+    for ep, (x, y) in enumerate(zip(outs["16"], outs["auto"])):
+        for k in x:
+            assert torch.equal(x[k], y[k]), (ep, k)
+
+
+@pytest.mark.parametrize("tile", ["auto", "16"])
+@pytest.mark.parametrize("E,A,T,H", [(37, 5, 12, 64), (50, 3, 9, 32), (9, 8, 7, 64), (3, 1, 5, 48)])
+def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H, tile, monkeypatch):
+    """cm_gru_rollout_spread (one persistent launch, 32-row tiles, weights register-resident; six-wave default and the four-wave
+    kernel) == reset + T x (cm_gru_policy_act, cm_synth_env_step) with the same seeds."""
+    from cleanmarl_amd.gru import GRUSyntheticRollout
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    if tile == "auto":
+        monkeypatch.delenv("CM_ROLLOUT_TILE", raising=False)
+    else:
+        monkeypatch.setenv("CM_ROLLOUT_TILE", tile)
     dev = torch.device("cuda:0")
     torch.manual_seed(13)
     ra = GRUSyntheticRollout(E, A, T, seed=5, device=dev, env_offset=77)
