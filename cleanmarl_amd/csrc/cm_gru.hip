@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
 //     during the x-products; the tile is stable from the barrier after the obs build to the top of the next step);
 //   * wave 5 (scorer) takes the reward partials + reward store of step t - 1 and the Philox uniforms of step t (LDS: uscr).
 // In the four-wave kernel those were 31 % of the step (phase profile: reward partials + obs build 2.7 k, buffer writes + Philox 4.3 k of
-// 22.5 k cycles).  Every wave passes the same five barriers per step (two of them inside gru2_step); the helpers' barriers order LDS
+// 22.5 k cycles).  Every wave passes the same four barriers per step (two of them inside gru2_step); the helpers' barriers order LDS
 // traffic only (lds_barrier), so their global stores stay in flight across steps.  Same arithmetic in the same order: bit-identical
 // buffers to k_gru32_rollout (option rollout_tile = 16 / 64 keeps the four-wave kernel; tests/test_hip_parity.py compares the two).
 constexpr int NT6R = 6 * 64;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
             }
         };
         // three step loops, one per role (separate live ranges: nothing of a helper's state occupies registers of the chain);
-        // every wave passes the same five barriers per step
+        // every wave passes the same four barriers per step
         if (compute) {
             for (int t = 0; t < T; ++t) {
                 lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
@@ -711,31 +711,26 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
                 gru2_step<false>(w, XA, X1, hp, hn, nullptr, nullptr, nullptr, nullptr, din, H);  // two barriers inside
                 PH(4);
                 if (hrow < T32) {
+                    // head + sampler on the four lanes of a row, straight from registers (quad_categorical_sample: the operation order of
+                    // cm_categorical_sample, two exponentials per lane instead of eight on one) -- no logits tile, no barrier before the sampler
                     unsigned char avb[KJ] = {1, 1};
                     float zreg[KJ];
                     gru_head_logits<KJ>(L, hn, K, avb, zreg);
-#pragma unroll
-                    for (int j = 0; j < KJ; ++j)
-                        if (4 * j + hq < K) ls[hrow * 8 + 4 * j + hq] = zreg[j];
-                }
-                PH(5);
-                lds_barrier();  // B2: logits (and the scorer's uniforms)
-                PH(6);
-                if (tid < RT) {
-                    const int el = tid / A, i = tid - el * A;
+                    PH(5);
+                    int chosen; float lpv;
+                    quad_categorical_sample<KJ>(zreg, K, hq, uscr[hrow], &chosen, &lpv);
+                    const int el = hrow / A, i = hrow - el * A;
                     const long e = e0 + el;
-                    if (e < a.E) {
-                        int chosen; float lpv;
-                        cm_categorical_sample(ls + tid * 8, K, uscr[tid], &chosen, &lpv);
+                    if (hq == 0 && hrow < RT && e < a.E) {
                         const long o = (e * A + i) * (long)T + t;
                         a.action[o] = chosen;
                         a.logp[o] = lpv;
                         const float ux = (chosen == 1) ? -GR_ACCEL : (chosen == 2 ? GR_ACCEL : 0.0f);
                         const float uy = (chosen == 3) ? -GR_ACCEL : (chosen == 4 ? GR_ACCEL : 0.0f);
-                        const float vx = evel[2 * tid] * (1.0f - GR_DAMP) + ux * GR_DT;
-                        const float vy = evel[2 * tid + 1] * (1.0f - GR_DAMP) + uy * GR_DT;
-                        evel[2 * tid] = vx; evel[2 * tid + 1] = vy;
-                        epos[2 * tid] += vx * GR_DT; epos[2 * tid + 1] += vy * GR_DT;
+                        const float vx = evel[2 * hrow] * (1.0f - GR_DAMP) + ux * GR_DT;
+                        const float vy = evel[2 * hrow + 1] * (1.0f - GR_DAMP) + uy * GR_DT;
+                        evel[2 * hrow] = vx; evel[2 * hrow + 1] = vy;
+                        epos[2 * hrow] += vx * GR_DT; epos[2 * hrow + 1] += vy * GR_DT;
                     }
                 }
                 PH(7);
@@ -777,13 +772,12 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
                 lds_barrier();  // x1 complete (inside the chain's gru2_step)
                 write_rows(0, t);  // under the x-products
                 lds_barrier();  // h' complete
-                lds_barrier();  // B2
-                write_rows(1, t);  // under the sampler (one active wave, no products): the tile is rebuilt only after the next B0
+                write_rows(1, t);  // under the head + sampler (two active waves, no products): the tile is rebuilt only after the next B0
             }
         } else {
             for (int t = 0; t < T; ++t) {
                 lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
-                // ---- scorer: the step's uniforms under the chain's first products (the sampler reads them after B2), the reward of step
+                // ---- scorer: the step's uniforms under the chain's first products (the sampler reads them after gru2_step), the reward of step
                 // t - 1 (positions after its physics update: stable until this step's sampler) under the x-products
                 lds_barrier();  // B1 (nothing before it: the obs build is the shortest stretch of the chain)
                 if (hl < RT) {
@@ -796,7 +790,6 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
                 lds_barrier();  // x1 complete
                 if (t > 0) score(t - 1);
                 lds_barrier();  // h' complete
-                lds_barrier();  // B2
             }
         }
         __syncthreads();
