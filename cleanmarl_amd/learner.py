@@ -438,16 +438,20 @@ class PPOLearner:
         leaves most of the chip idle and the critic's launches only delay the actor's).
         Measured (profiles/r02_critic_overlap_schedules.txt, ms per iteration, schedule 0 / 1 / 2): config 3 at 512 envs (one GPU's
         share of 8) 1.81 / 1.60 / 1.56, 1024 envs 2.92 / 2.98 / 2.77, 4096 envs 9.51 / 9.53 / 9.31; config 4 at 256 envs 4.10 / 4.19 /
-        3.91; config 2 1.44 / 1.30 / 1.32; config 3 at 256 envs (a share of 16) 1.26 / 1.09 / 1.27.  Default: 1 up to 2^18 rows, 2 up to
-        2^21 rows, 0 above -- at full size the gain is 2 % and the actor kernel,
-        the one the roofline is quoted on, would be timed with a second kernel beside it (1.87 -> 2.2 ms per launch).
+        3.91; config 2 1.44 / 1.30 / 1.32; config 3 at 256 envs (a share of 16) 1.26 / 1.09 / 1.27.  Re-measured at the end of round 3, once
+        the optimiser-step launch and the streaming dW0 kernel could be placed beside the other stream's kernels (gpurun_out/r03ac, r03ad;
+        schedule 0 / 1 / 2): config 3 at 2048 envs 4.72 / 4.74 / 4.80, 1024 envs 2.71 / 2.74 / 2.68, 768 envs 2.35 / 2.19 / 2.09, 384 envs
+        - / 1.26 / 1.24, 256 envs - / 0.97 / 1.00, 128 envs - / 0.745 / 0.752; config 2 1.33 / 1.21 / 1.19 (512 envs: - / 0.885 / 0.870);
+        config 4 at 512 envs 6.22 / 6.26 / 5.93, 256 envs 3.26 / 3.29 / 3.07, 128 envs - / 1.79 / 1.60.  Default: 1 below 2^17 rows, 2 below
+        2^21 rows, 0 from there -- at full size schedule 2 gains 2.6 % (8.43 vs 8.66 ms) but the actor kernel,
+        the one the roofline is quoted on, would be timed with a second kernel beside it (1.85 -> 2.2 ms per launch).
         CM_CRITIC_OVERLAP=0 / 1 / 2 forces a schedule."""
         import os
         v = os.environ.get("CM_CRITIC_OVERLAP")
         if v in ("0", "1", "2"):
             return int(v)
         rows = self._schedule_rows(b)
-        return 1 if rows < (1 << 19) else 2 if rows <= (1 << 21) else 0
+        return 1 if rows < (1 << 17) else 2 if rows < (1 << 21) else 0
 
     def _schedule_rows(self, b):
         """Row count the schedule is chosen from -- the SAME number on every rank: env shards may differ by one env (dist.shard), and

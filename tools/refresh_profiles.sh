@@ -31,6 +31,7 @@ python $R/tools/phase_prof.py rollout > $O/phase_rollout.txt 2>&1
 python $R/tools/phase_prof.py rollout 512 8 > $O/phase_rollout16s.txt 2>&1
 python $R/tools/phase_prof.py act > $O/phase_act.txt 2>&1
 CM_PROF_WARMUP=50 python $R/tools/phase_prof.py gru > $O/phase_gru.txt 2>&1
+python $R/tools/phase_prof.py grurollout > $O/phase_grurollout.txt 2>&1
 python $R/tools/bench_configs.py > $O/configs_learner.txt 2>&1
 # ---- widened rows: COMA, host-env plumbing, layered schedule
 python $R/tools/bench_coma.py > $O/coma_bench.json 2> $O/coma.err
