@@ -132,6 +132,36 @@ def test_wide_critic_split_schedule_matches_oracle(algo, E, A, T, Do, Ds, K, H, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("E,A,T,Ds,H", [(16, 8, 32, 384, 64), (7, 2, 29, 200, 48), (40, 3, 130, 475, 64)])
+def test_streaming_dw0_batch_sizes_leave_the_same_bits(E, A, T, Ds, H, monkeypatch):
+    """k_dw0_stream with 16 rows in flight per lane (the default above 2^16 rows) and with 8 (what fits beside the six-wave rollout, the
+    default below) accumulate the same rows in the same order: bit-identical critic gradients and post-step parameters on the split
+    schedule; the last case has four 32-column tiles per wave (the 16-row form spills there)."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+    monkeypatch.setenv("CM_CRITIC_SCHEDULE", "split")
+    dev = torch.device("cuda:0")
+    batch = _random_case(321, E, A, T, 24, Ds, 5)
+    aspec, cspec = NetSpec(24, 64, 1, 5), NetSpec(Ds, H, 1, 1)
+    torch.manual_seed(3)
+    ap, cp = init_params_like_torch(aspec), init_params_like_torch(cspec)
+    outs = []
+    for bsz in ("8", "4"):
+        monkeypatch.setenv("CM_DW0_BATCH", bsz)
+        N.sync_env_options()
+        assert N.load().cm_get_option(b"dw0_batch") == bsz.encode()
+        b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], batch["log_probs"], batch["reward"], batch["states"],
+                                              batch["avail"], batch["mask"], dev)
+        Lr = PPOLearner("mappo", aspec, cspec, A, HParams(epochs=2), dev, actor_params=[p.clone() for p in ap],
+                        critic_params=[p.clone() for p in cp])
+        recs = Lr.train_iteration(b, keep_grads=True)
+        outs.append([(r["critic_grads"].clone(), r["critic_after"].clone()) for r in recs])
+    for (g8, p8), (g4, p4) in zip(*outs):
+        assert torch.equal(g8, g4) and torch.equal(p8, p4)
+        assert g8.abs().sum().item() > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
     ("mappo", 21, 3, 19, 21, 54, 5, 128, 1),    # actor + critic inside one launch each (inputs <= 64 columns, odd widths: scalar tile loads)
     ("mappo", 16, 8, 32, 56, 384, 5, 128, 1),   # config-3 shapes: critic on the 384-wide state (layer 0 outside: k_wide_gemm + k_dw0_stream)
