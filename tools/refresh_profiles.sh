@@ -43,3 +43,9 @@ CM_MFMA=bf16 python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ext
 # ---- steady-state rate of the product surface (driver.run through the CLI), not only of bench.py's inner loop
 python $R/tools/cli_steady_state.py > $O/cli_steady_state.txt 2>&1
 ls -la $O
+# ---- kernel timelines of one steady-state iteration (two queues): the 512-env share of config 3, config 2
+for w in "cfg3 --envs 512" "cfg2"; do
+  n=$(echo $w | tr -d ' -')
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$n -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  python $R/tools/trace_timeline.py $(find /tmp/kt_$n -name "*kernel_trace.csv" | head -1) k_ro 3 > $O/timeline_$n.txt 2>&1
+done
