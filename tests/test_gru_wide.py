@@ -91,6 +91,21 @@ def test_layered_gru_policy_act_matches_oracle(rows, Do, Hd, K):
             assert np.abs(lp.cpu().numpy()[same] - (lg.max(-1) - lse)[same]).max() <= TOL
 
 
+def test_more_than_64_actions_is_an_explicit_error():
+    """Heads of 33 .. 64 actions run on the layered schedule; beyond that both actor families refuse with a message (never a silent fallback)."""
+    from cleanmarl_amd import _native as N
+    lib, dev = N.load(), torch.device("cuda:0")
+    z = torch.zeros(1 << 16, device=dev)
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=dev)
+    act = torch.zeros(8, dtype=torch.int32, device=dev)
+    rc = lib.cm_policy_act_ws(N.ptr(z), 40, None, 65, 4, 40, 64, 1, 65, N.ptr(z), 0.0, 1, 0, 0, N.ptr(act), N.ptr(z), 1, N.ptr(ws), ws.numel(),
+                              N.stream_ptr())
+    assert rc != 0 and b"65" in lib.cm_last_error() and b"64" in lib.cm_last_error()
+    rc = lib.cm_gru_policy_act_ws(N.ptr(z), 40, None, 65, 4, 40, 64, 65, N.ptr(z), N.ptr(z), 0.0, 1, 0, 0, N.ptr(act), N.ptr(z), 1, N.ptr(ws),
+                                  ws.numel(), N.stream_ptr())
+    assert rc != 0 and b"65" in lib.cm_last_error()
+
+
 def test_fused_entry_points_still_refuse_layered_shapes_without_a_workspace():
     from cleanmarl_amd import _native as N
     lib, dev = N.load(), torch.device("cuda:0")
