@@ -39,7 +39,9 @@ def _same(x, y):
 @pytest.mark.parametrize("optimizer", ["Adam", "AdamW", "SGD", "RMSprop"])
 @pytest.mark.parametrize("sched", ["fused", "split"])
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [("mappo", 16, 8, 32, 56, 384, 5, 64, 1), ("ippo", 6, 3, 20, 140, 10, 5, 64, 1),
-                                                      ("mappo", 37, 3, 25, 21, 54, 5, 32, 2)])
+                                                      ("mappo", 37, 3, 25, 21, 54, 5, 32, 2),
+                                                      # 512 partial rows for the actor (four row batches per group), 141 for the critic (a ragged last batch)
+                                                      ("mappo", 300, 8, 30, 56, 384, 5, 64, 1)])
 def test_fused_step_equals_the_three_launch_step_bit_for_bit(algo, E, A, T, Do, Ds, K, H, L, sched, optimizer, clip, monkeypatch):
     monkeypatch.setenv("CM_CRITIC_SCHEDULE", sched)  # one-pass critic where its shape rules allow / two-kernel split schedule (two partial sets)
     (Lf, bf), (Lu, bu) = _mlp_learners(algo, E, A, T, Do, Ds, K, H, L, clip, optimizer)
