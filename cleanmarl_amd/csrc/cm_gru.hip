@@ -681,16 +681,18 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
             for (int t = 0; t < T; ++t) {
                 lds_barrier();  // B0: positions of step t (sampler of t - 1), h_{t-1}; the writer is done reading the previous tile
                 PH(0);
-                // ---- observations of step t -> XA: 4 lanes per row (threads 0..127), lane hq handles entities j = hq, hq+4, ...
-                if (hrow < T32) {
-                    const int el = hrow / A, i = hrow - el * A;
-                    const bool live = hrow < RT && (e0 + el) < a.E;
-                    float* xr = XA + hrow * LDT;
+                // ---- observations of step t -> XA: 8 lanes per row on all four chain waves, lane oq handles entities j = oq, oq+8, ...
+                // (the four-wave kernel builds them with 4 lanes per row on two waves; pure data movement: same values)
+                {
+                    const int orow = tid >> 3, oq = tid & 7;
+                    const int el = orow / A, i = orow - el * A;
+                    const bool live = orow < RT && (e0 + el) < a.E;
+                    float* xr = XA + orow * LDT;
                     if (live) {
                         const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
                         const float px = pos[2 * i], py = pos[2 * i + 1];
-                        if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
-                        for (int j = hq; j < A; j += 4) {
+                        if (oq == 7) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }  // the lane with the fewest entities
+                        for (int j = oq; j < A; j += 8) {
                             xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
                             if (j != i) {
                                 const int jj = j < i ? j : j - 1;
@@ -699,10 +701,10 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
                             }
                             if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
                         }
-                        for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;
+                        for (int c = din + oq; c < KC; c += 8) xr[c] = 0.0f;
                     } else {
 #pragma unroll
-                        for (int j = 0; j < KC / 4; ++j) xr[4 * j + hq] = 0.0f;
+                        for (int j = 0; j < KC / 8; ++j) xr[8 * j + oq] = 0.0f;
                     }
                 }
                 PH(1);
