@@ -13,8 +13,10 @@ grad all-reduce when N > 1, fused norm/clip/Adam).  Inputs never leave HBM.
 Prints ONE JSON line on rank 0 (contract in the task statement): `value` = agents*envs*steps per second summed over all
 ranks.  Scaling is STRONG by default, as BASELINE.json's north_star defines it ("num_envs shards across the 8 GPUs"): the
 workload's env count is global, rank r owns envs dist.shard(E, r, N), global env index = first + e.  `--scaling weak` keeps E
-envs on every rank instead; with N > 1 the default run also times a short weak-scaling leg after the timed region and reports
-it under "weak_scaling" (extra key; `value` is always the mode named in "scaling").
+envs on every rank instead.  With N > 1 the default run times the two all-reduce messages of an optimiser step alone ("allreduce_us"
+in the line), prints the line, and only THEN runs a short leg in the other scaling mode, reported on stderr as
+`[bench extra leg] {...}` -- an extra leg can never cost the headline record (`value` is always the mode named in "scaling").
+Every N = 1 extra leg is guarded the same way ("extras_error" / "cpu_baseline_error" instead of a lost line).
 
 Extra keys (N = 1): "phase_roofline" (rollout / value pass / critic against their own bounds), "other_workloads" (the other
 BASELINE.json configs, a few steps each after the timed region) and "strong_scaling_shares" (the per-GPU share of each sharded
@@ -287,21 +289,30 @@ def main():
             out["roofline"]["algorithmic_bytes_per_launch"] = wk["actor"]["bytes"]
     w.close()
 
+    weak_leg = None
     if not args.no_extras and world > 1:
-        # the two messages of an optimiser step, timed alone (latency-bound: 33 KB / 116 KB at cfg 3), and a short weak-scaling leg
+        # the two messages of an optimiser step, timed alone (latency-bound: 33 KB / 116 KB at cfg 3).  Plain all-reduces on the group the
+        # timed region just used; rank 0's line is printed right after them and BEFORE the leg in the other scaling mode, so that nothing
+        # that leg does on a node this code has not seen yet (new buffers, 8 x the envs) can cost the headline record
         lat = {}
-        for nm, n in (("actor", w.aspec.nparams + N.NUM_STATS), ("critic", w.cspec.nparams + N.NUM_STATS)):
-            buf = torch.zeros(n, dtype=torch.float32, device=dev)
-            for _ in range(20):
-                torch.distributed.all_reduce(buf, group=pg)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(100):
-                torch.distributed.all_reduce(buf, group=pg)
-            e1.record()
-            torch.cuda.synchronize()
-            lat[f"{nm}_{4 * n}B"] = 1e3 * e0.elapsed_time(e1) / 100
+        try:
+            for nm, n in (("actor", w.aspec.nparams + N.NUM_STATS), ("critic", w.cspec.nparams + N.NUM_STATS)):
+                buf = torch.zeros(n, dtype=torch.float32, device=dev)
+                for _ in range(20):
+                    torch.distributed.all_reduce(buf, group=pg)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(100):
+                    torch.distributed.all_reduce(buf, group=pg)
+                e1.record()
+                torch.cuda.synchronize()
+                lat[f"{nm}_{4 * n}B"] = 1e3 * e0.elapsed_time(e1) / 100
+        except Exception as ex:  # noqa: BLE001 -- reported in the line, never instead of it
+            lat = {"error": repr(ex)[:300]}
+        if rank == 0:
+            out["allreduce_us"] = lat
+            print(json.dumps(out), flush=True)
         other = "weak" if args.scaling == "strong" else "strong"
         if other == "weak":
             w2 = Workload(args.workload, E_glob, rank * E_glob, dev, pg, world)
@@ -310,57 +321,65 @@ def main():
             f2, e2 = dist.shard(E_glob, rank, world)
             w2 = Workload(args.workload, e2, f2, dev, pg, world)
             tot2 = E_glob
+        w2.learner.global_envs = tot2  # rank-invariant schedule choice, as for the timed workload
         r2 = w2.run(max(3, min(args.steps, 10)), 2)
         w2.close()
         if rank == 0:
-            out["allreduce_us"] = lat
-            out[f"{other}_scaling"] = {"value": tot2 * A * T * r2["steps"] / r2["dt"], "ms_per_step": r2["ms_per_step"],
-                                       "global_envs": tot2, "steps": r2["steps"], "phase_ms": r2["phase_ms"]}
+            weak_leg = {"leg": f"{other}_scaling", "n_gpus": world, "value": tot2 * A * T * r2["steps"] / r2["dt"],
+                        "ms_per_step": r2["ms_per_step"], "global_envs": tot2, "steps": r2["steps"], "phase_ms": r2["phase_ms"]}
+            # NOT a second line on stdout (the contract is ONE JSON line there): stderr, tagged
+            print("[bench extra leg] " + json.dumps(weak_leg), file=sys.stderr, flush=True)
 
     if rank == 0 and world == 1 and not args.no_extras and not args.envs:
-        # the other BASELINE configs (parity-test cases) and the per-GPU shares of the sharded ones, a few steps each, after the
-        # timed region of the headline config
-        others, shares = {}, {}
-        full_ms = {args.workload: out["ms_per_step"]}
-        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
-            if name == args.workload:
-                continue
-            ww = Workload(name, WORKLOADS[name][0], 0, dev)
-            rr = ww.run(5, 2)
-            others[name] = dict(summarize(ww, rr), workload=ww.desc)
-            full_ms[name] = rr["ms_per_step"]
-            ww.close()
-        for name in ("cfg3", "cfg4"):  # the configs north_star shards over 8 GPUs
-            Eg = WORKLOADS[name][0]
-            rec = {}
-            for g in (2, 4, 8):
-                ww = Workload(name, Eg // g, 0, dev)
-                rr = ww.run(20, 6)
-                rec[f"1/{g} ({Eg // g} envs)"] = dict(ms_per_step=rr["ms_per_step"], phase_ms=rr["phase_ms"],
-                                                      speedup_bound=full_ms[name] / rr["ms_per_step"])
+        try:
+            # the other BASELINE configs (parity-test cases) and the per-GPU shares of the sharded ones, a few steps each, after the
+            # timed region of the headline config
+            others, shares = {}, {}
+            full_ms = {args.workload: out["ms_per_step"]}
+            for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+                if name == args.workload:
+                    continue
+                ww = Workload(name, WORKLOADS[name][0], 0, dev)
+                rr = ww.run(5, 2)
+                others[name] = dict(summarize(ww, rr), workload=ww.desc)
+                full_ms[name] = rr["ms_per_step"]
                 ww.close()
-            shares[name] = dict(full_ms_per_step=full_ms[name], shares=rec,
-                                note="one GPU's share timed on ONE GPU: full / share bounds the N-GPU speed-up before the all-reduces")
-        out["other_workloads"] = others
-        out["strong_scaling_shares"] = shares
+            for name in ("cfg3", "cfg4"):  # the configs north_star shards over 8 GPUs
+                Eg = WORKLOADS[name][0]
+                rec = {}
+                for g in (2, 4, 8):
+                    ww = Workload(name, Eg // g, 0, dev)
+                    rr = ww.run(20, 6)
+                    rec[f"1/{g} ({Eg // g} envs)"] = dict(ms_per_step=rr["ms_per_step"], phase_ms=rr["phase_ms"],
+                                                          speedup_bound=full_ms[name] / rr["ms_per_step"])
+                    ww.close()
+                shares[name] = dict(full_ms_per_step=full_ms[name], shares=rec,
+                                    note="one GPU's share timed on ONE GPU: full / share bounds the N-GPU speed-up before the all-reduces")
+            out["other_workloads"] = others
+            out["strong_scaling_shares"] = shares
 
+        except Exception as ex:  # noqa: BLE001 -- an extra leg must never cost the headline line
+            out["extras_error"] = repr(ex)[:500]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import reference_loop  # checker / baseline only -- never part of the measured path
-        Ec, cores = args.cpu_envs, os.cpu_count() or 1
-        sweep = sorted({1, min(8, cores), min(32, cores)})  # never all cores: 256 intra-op threads took 470 s for ONE probe epoch
-        rc = reference_loop.run(E=Ec, A=A, T=T, thread_sweep=sweep)
-        th = rc["threads"]
-        out["cpu_baseline"] = {"value": rc["agent_steps_per_s"], "unit": "agent-env-steps/s",
-                               "cores": min(cores, Ec + max(th.values())), "kind": "port",
-                               "sample": f"one iteration of the reference-structured driver (oracle/reference_loop.py: "
-                                         f"process-per-env pipes, per-step python loops) at {Ec} envs x {A} agents x {T} steps on a "
-                                         f"{cores}-core host; torch intra-op threads swept over {sweep} per phase on a slice of the batch "
-                                         f"and the fastest kept (rollout {th['rollout']}, scan {th['gae']}, update {th['update']}; torch's "
-                                         f"default = all cores is the slowest for these tiny ops); rollout {rc['rollout_s']:.2f}s gae "
-                                         f"{rc['gae_s']:.2f}s update {rc['update_s']:.2f}s",
-                               "thread_probe_s": rc["thread_probes"]}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        try:
+            from oracle import reference_loop  # checker / baseline only -- never part of the measured path
+            Ec, cores = args.cpu_envs, os.cpu_count() or 1
+            sweep = sorted({1, min(8, cores), min(32, cores)})  # never all cores: 256 intra-op threads took 470 s for ONE probe epoch
+            rc = reference_loop.run(E=Ec, A=A, T=T, thread_sweep=sweep)
+            th = rc["threads"]
+            out["cpu_baseline"] = {"value": rc["agent_steps_per_s"], "unit": "agent-env-steps/s",
+                                   "cores": min(cores, Ec + max(th.values())), "kind": "port",
+                                   "sample": f"one iteration of the reference-structured driver (oracle/reference_loop.py: "
+                                             f"process-per-env pipes, per-step python loops) at {Ec} envs x {A} agents x {T} steps on a "
+                                             f"{cores}-core host; torch intra-op threads swept over {sweep} per phase on a slice of the batch "
+                                             f"and the fastest kept (rollout {th['rollout']}, scan {th['gae']}, update {th['update']}; torch's "
+                                             f"default = all cores is the slowest for these tiny ops); rollout {rc['rollout_s']:.2f}s gae "
+                                             f"{rc['gae_s']:.2f}s update {rc['update_s']:.2f}s",
+                                   "thread_probe_s": rc["thread_probes"]}
+        except Exception as ex:  # noqa: BLE001 -- an extra leg must never cost the headline line
+            out["cpu_baseline_error"] = repr(ex)[:500]
+    if rank == 0 and (world == 1 or args.no_extras):
+        print(json.dumps(out), flush=True)  # N > 1 with extras: already printed above, before the extra leg
     if world > 1:
         torch.distributed.destroy_process_group()
 
