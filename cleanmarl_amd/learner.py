@@ -291,6 +291,7 @@ class PPOLearner:
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
         self.mom_ws = None
+        self.stats_stream = None  # the stream the last update()'s statistics left on when it was NOT the launch stream (the critic's, overlapped schedules)
         self.events = None  # bench.py sets this to a list to collect per-launch (kind, start, end) HIP events
         self._ring = _HostRing()
         # optimiser steps as ONE launch (cm_optimizer_step), riding on the reduction launch of the pass when no all-reduce comes between
@@ -534,6 +535,7 @@ class PPOLearner:
             if keep_grads:
                 kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
 
+        self.stats_stream = None
         if not overlap:
             pending = None  # the critic's optimiser step of the previous epoch, due before the next critic pass
             for ep in range(nE0):
@@ -601,6 +603,7 @@ class PPOLearner:
                 host, ev, attach = _to_host_async(self._ring, rec)
                 self._critic_done = torch.cuda.Event()
                 self._critic_done.record(side)
+                self.stats_stream = side
                 self._critic_joined = {(side.device_index, side.cuda_stream)}  # the critic stream itself is ordered behind its own work
         nE, ent_coef = int(hp.epochs), hp.entropy_coef
         kept = [(ka[0], kc[0], ka[1], kc[1]) for ka, kc in zip(kept_a, kept_c)]
