@@ -174,6 +174,10 @@ class COMALearner:
             rec.update(actor_grads=self.g_actor[:Pa].clone(), critic_grads=self.g_critic[:Pc].clone())
         return rec
 
+    def critic_params(self):
+        """Same accessor as PPOLearner.critic_params (COMA's critic runs on the launch stream: nothing to join)."""
+        return self.critic
+
     def train_iteration(self, b, keep_grads=False):
         self.compute_targets(b)
         return self.update(b, keep_grads=keep_grads)

@@ -7,6 +7,7 @@ Adam step with the chunk loss normalised by N_chunk * T_chunk (:605-607); h is c
 critic takes one step per epoch (:646-655).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -26,6 +27,17 @@ class GRUPPOLearner(PPOLearner):
         self.g_rows = None
         self.h = [None, None]
         self._critic_stream = None
+        # where the critic's epochs run (the critic stream's own order never changes, so the results do not depend on it):
+        #   "beside"  epoch e on a second normal-priority stream beside actor epoch e, joined at the end of update() (rounds 1 - 3);
+        #   "low"     the same on the lowest-priority stream;
+        #   "deferN"  the last N epochs behind the actor's epochs on the lowest-priority stream: they run under the NEXT rollout and are
+        #             joined by the next value pass (wait_critic), the first epochs stay beside the actor's.
+        # Kernel trace of config 5 (tools/gpu/r03_cfg5_trace.sh): a critic epoch (pass 143 + streamed dW0 142 + step 35 us) beside the
+        # pipelined GRU sweeps -- which have no idle CUs any more -- stretches the first chunk of the actor epoch by ~115 us (forward
+        # sweep 67 -> 105 us, backward 80 -> 157); beside the rollout it costs 69 us once, however many epochs follow.  Measured
+        # (tools/gpu/r03_gru_critic.sh, two runs each): beside 7.33 / 7.34 ms, defer1 7.20 / 7.23, defer2 7.23 / 7.26 (the value pass starts
+        # to wait), defer3 7.30.  CM_GRU_CRITIC is a Python-side A/B hook, not an option of the C-ABI.
+        self.critic_schedule = os.environ.get("CM_GRU_CRITIC", "defer1")
 
     def _ensure(self, b):
         a = self.actor_spec
@@ -49,18 +61,21 @@ class GRUPPOLearner(PPOLearner):
         rec_c = torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
         kept, kept_c = [], []
         # The critic's epoch (one pass + one step, independent of the actor: it reads returns and states only, own workspace, own
-        # gradient buffer) is enqueued on a second stream at the start of every actor epoch.  The TBPTT chunk kernels are 32-row
-        # sweeps -- E*A/32 workgroups, fewer than the 256 CUs at config 5 -- and strictly sequential, so the critic kernels fill the
-        # idle CUs instead of extending the serial chain.  Issue order (critic epoch, then that epoch's chunks) is identical on all
-        # ranks, so the collectives still pair up.
+        # gradient buffer) is enqueued on a second stream: at the start of an actor epoch, or -- the last `n_defer` of them -- behind the
+        # actor's epochs, i.e. under the next rollout (self.critic_schedule, measurements in __init__).  The serial chain of TBPTT chunk
+        # kernels is never extended by them.  Issue order is identical on all ranks, so the collectives still pair up.
         ride = self.fused_step and not self._coll
         main = torch.cuda.current_stream()
+        sched = self.critic_schedule
         if self._critic_stream is None:
-            self._critic_stream = N.side_stream(self.device)  # one per process: see _native.low_priority_stream
+            # one per process: see _native.low_priority_stream
+            self._critic_stream = N.side_stream(self.device) if sched == "beside" else N.low_priority_stream(self.device)
         side = self._critic_stream
         self.wait_critic()
+        self._critic_done = None
         side.wait_stream(main)
-        for ep in range(nE):
+
+        def critic_epoch(ep):
             with torch.cuda.stream(side):
                 sc = N.stream_ptr()
                 if ride:  # one process: the optimiser step rides on the pass's reduction launch
@@ -73,6 +88,11 @@ class GRUPPOLearner(PPOLearner):
                 rec_c[ep, N.NUM_STATS] = self.norms[1]
                 if keep_grads:
                     kept_c.append((self.g_critic[:Pc].clone(), self.critic.clone()))
+
+        n_defer = 0 if not sched.startswith("defer") else min(nE, int(sched[5:] or nE))
+        for ep in range(nE):
+            if ep < nE - n_defer:
+                critic_epoch(ep)
             steps = []
             h_in = None
             if self.events is not None:  # bench.py: one event pair around all TBPTT chunks of the epoch
@@ -104,8 +124,24 @@ class GRUPPOLearner(PPOLearner):
                 ev1.record()
                 self.events.append(("actor", ev0, ev1))
             if keep_grads:
-                kept.append((steps,) + kept_c[ep])
-        main.wait_stream(side)
+                kept.append((steps,))
+        if n_defer:
+            # all critic epochs behind the actor's, on the lowest-priority stream, NOT joined here: they run under the next rollout (one
+            # six-wave workgroup on 171 of the 256 CUs at config 5) and are joined by the next value pass (wait_critic)
+            side.wait_stream(main)
+            for ep in range(nE - n_defer, nE):
+                critic_epoch(ep)
+            with torch.cuda.stream(side):
+                host, ev, attach = _to_host_async(self._ring, rec_a, rec_c)
+                self._critic_done = torch.cuda.Event()
+                self._critic_done.record(side)
+                self._critic_joined = {(side.device_index, side.cuda_stream)}
+            self.stats_stream = side
+        else:
+            main.wait_stream(side)
+            self.stats_stream = None
+        if keep_grads:
+            kept = [k + kept_c[ep] for ep, k in enumerate(kept)]
         ent_coef = hp.entropy_coef
 
         def build(ra, rc):
@@ -121,7 +157,8 @@ class GRUPPOLearner(PPOLearner):
                     d.update(actor_steps=kept[ep][0], critic_grads=kept[ep][1], critic_after=kept[ep][2])
                 out.append(d)
             return out
-        host, ev, attach = _to_host_async(self._ring, rec_a, rec_c)  # no host wait here: see learner.LazyRecords
+        if not n_defer:
+            host, ev, attach = _to_host_async(self._ring, rec_a, rec_c)  # no host wait here: see learner.LazyRecords
         out = LazyRecords(nE, host, ev, build)
         attach(out)
         return out

@@ -122,7 +122,7 @@ def _worker_peer(rank, world, port, gold, algo, out):
         more = [dict(r) for r in L.train_iteration(b)]  # a second iteration: the slot sets alternate, the tags keep counting
         L.wait_critic()
         torch.cuda.synchronize()
-        res[sched] = dict(recs=recs, more=more, actor=L.actor.cpu(), critic=L.critic.cpu(), seq=(L.peer_a.seq, L.peer_c.seq))
+        res[sched] = dict(recs=recs, more=more, actor=L.actor.cpu(), critic=L.critic_params().cpu(), seq=(L.peer_a.seq, L.peer_c.seq))
         L.peer_a.close(); L.peer_c.close()
     torch.save(res, f"{out}.{rank}")
     torch.distributed.barrier()
@@ -233,7 +233,7 @@ def _coma_worker(rank, world, port, gold, out):
     L = COMALearner(aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
                     process_group=torch.distributed.group.WORLD, world_size=world)
     rec = L.train_iteration(b)
-    torch.save(dict(rec=rec, actor=L.actor.cpu(), critic=L.critic.cpu(), target=L.target.cpu()), f"{out}.{rank}")
+    torch.save(dict(rec=rec, actor=L.actor.cpu(), critic=L.critic_params().cpu(), target=L.target.cpu()), f"{out}.{rank}")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -279,7 +279,7 @@ def _gru_worker(rank, world, port, gold, algo, out):
     L = GRUPPOLearner(algo, aspec, cspec, batch["obs"].shape[2], H, dev, actor_params=ap, critic_params=cp,
                       process_group=torch.distributed.group.WORLD, world_size=world)
     recs = L.train_iteration(b)
-    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu()), f"{out}.{rank}")
+    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic_params().cpu()), f"{out}.{rank}")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -370,7 +370,7 @@ def _worker_overlap(rank, world, port, gold, algo, out):
     recs = [dict(r) for r in recs]  # materialises the lazily copied statistics (waits for both streams)
     L.wait_critic()
     torch.cuda.synchronize()
-    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu()), f"{out}.{rank}")
+    torch.save(dict(recs=recs, actor=L.actor.cpu(), critic=L.critic_params().cpu()), f"{out}.{rank}")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -431,7 +431,7 @@ def _worker_rccl(rank, world, port, gold, algo, out):
         recs = [dict(r) for r in L.train_iteration(b)]
         L.wait_critic()
         torch.cuda.synchronize()
-        res[sched] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu())
+        res[sched] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic_params().cpu())
     torch.save(res, f"{out}.{rank}")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -483,7 +483,7 @@ def _worker_rccl_gru_coma(rank, world, port, gold_gru, gold_coma, out):
     assert L._coll and L.pg_c is not L.pg
     recs = [dict(r) for r in L.train_iteration(b)]
     torch.cuda.synchronize()
-    res["gru"] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic.cpu())
+    res["gru"] = dict(recs=recs, actor=L.actor.cpu(), critic=L.critic_params().cpu())
     # ---- COMA: gradient buffers + the float64 per-time-step advantage sums
     batch, ap, cp, hp, z = C.load_golden(gold_coma)
     b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), batch["reward"], batch["states"],

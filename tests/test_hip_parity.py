@@ -832,7 +832,7 @@ def test_full_size_env_sharding_additivity():
               learning_rate_actor=8e-4, learning_rate_critic=8e-4)
     ap = [p.cpu() for p in torch.split(L.actor.cpu(), [int(np.prod(sh)) for sh in L.actor_spec.shapes()])]
     ap = [p.reshape(sh) for p, sh in zip(ap, L.actor_spec.shapes())]
-    cp = [p.reshape(sh) for p, sh in zip(torch.split(L.critic.cpu(), [int(np.prod(sh)) for sh in L.critic_spec.shapes()]), L.critic_spec.shapes())]
+    cp = [p.reshape(sh) for p, sh in zip(torch.split(L.critic_params().cpu(), [int(np.prod(sh)) for sh in L.critic_spec.shapes()]), L.critic_spec.shapes())]
     scal, ag, cg = R.mlp_epoch(ap, cp, batch, sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu(), hp, "mappo")
     n = float(first[Pa + 5])
     assert n == float(mask.sum())
@@ -873,7 +873,7 @@ def test_full_size_update_is_deterministic_and_finite():
     r1 = L.train_iteration(b)
     L2, b2 = _full_size_setup()
     r2 = L2.train_iteration(b2)
-    assert torch.equal(L.actor, L2.actor) and torch.equal(L.critic, L2.critic)  # no atomics anywhere on the path
+    assert torch.equal(L.actor, L2.actor) and torch.equal(L.critic_params(), L2.critic_params())  # no atomics anywhere on the path
     assert all(np.isfinite(v) for r in r1 for v in r.values())
     assert [r["actor_loss"] for r in r1] == [r["actor_loss"] for r in r2]
 
@@ -952,7 +952,7 @@ def test_time_padding_does_not_change_the_update():
         b = pad_time(b, T_pad)
         L = PPOLearner("mappo", aspec, cspec, 3, HParams(epochs=2), dev, [p.clone() for p in ap], [p.clone() for p in cp])
         recs = L.train_iteration(b)
-        outs.append((b.ret[:, :, :11].clone(), L.actor.clone(), L.critic.clone(), [r["actor_loss"] for r in recs]))
+        outs.append((b.ret[:, :, :11].clone(), L.actor.clone(), L.critic_params().clone(), [r["actor_loss"] for r in recs]))
     assert torch.equal(outs[0][0], outs[1][0])
     # row tiles are cut at different places (rows = (e*A + a)*T + t), so sums re-associate: equal to fp32 round-off
     assert _err(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 1e-6
@@ -1127,7 +1127,7 @@ def test_hand_ordered_and_compiler_scheduled_product_forms_agree_bit_for_bit(alg
         L_ = PPOLearner(algo, aspec, cspec, A, HParams(**hpd), dev, [p.clone() for p in ap], [p.clone() for p in cp])
         r = L_.train_iteration(b, keep_grads=True)
         torch.cuda.synchronize()
-        out[forms] = (b.ret.clone(), [dict(d) for d in r], L_.actor.clone(), L_.critic.clone())
+        out[forms] = (b.ret.clone(), [dict(d) for d in r], L_.actor.clone(), L_.critic_params().clone())
     assert torch.equal(out["hand"][0], out["loop"][0])
     assert torch.equal(out["hand"][2], out["loop"][2]) and torch.equal(out["hand"][3], out["loop"][3])
     for e in range(2):
