@@ -6,13 +6,14 @@ step with the counterfactual baseline (cm_coma_advantage / cm_coma_normalize_adv
 Env-sharded data parallelism as in learner.py: per optimiser step one all-reduce(sum) of the un-normalised flat gradient
 + statistics buffer; the per-time-step advantage moments are all-reduced as raw float64 sums [T][4].
 """
+from collections.abc import Mapping
 from dataclasses import dataclass
 
 import torch
 
 from . import _native as N
 from . import dist
-from .learner import NetSpec, _Adam, flatten_params, init_params_like_torch
+from .learner import LazyRecords, NetSpec, _Adam, _HostRing, _to_host_async, flatten_params, init_params_like_torch
 
 
 @dataclass
@@ -43,6 +44,30 @@ def coma_critic_input_dim(Do, Ds, A, K):
     return Do + Ds + (A - 1) * K
 
 
+class LazyRecord(Mapping):
+    """The record of one COMA iteration as a read-only mapping whose numbers are still on their way from the device (same staging
+    as learner.LazyRecords: pinned ring buffer, converted on first access) -- a caller that does not log every iteration no longer
+    stalls the launch queue once per iteration (kernel trace of tools/bench_coma.py: 131 us before the next rollout)."""
+
+    def __init__(self, lazy):
+        self._lazy = lazy
+
+    def _d(self):
+        return self._lazy[0]
+
+    def __getitem__(self, k):
+        return self._d()[k]
+
+    def __iter__(self):
+        return iter(self._d())
+
+    def __len__(self):
+        return len(self._d())
+
+    def __reduce__(self):  # pickles (torch.save) as a plain dict
+        return (dict, (dict(self._d()),))
+
+
 class COMALearner:
     def __init__(self, actor_spec, critic_spec, n_agents, hp, device, actor_params=None, critic_params=None,
                  process_group=None, world_size=1):
@@ -67,6 +92,7 @@ class COMALearner:
         self.training_step = 0
         self._shape = None
         self.events = None
+        self._ring = _HostRing()
 
     # ------------------------------------------------------------------ buffers sized on first use
     def _ensure(self, b):
@@ -163,16 +189,23 @@ class COMALearner:
                                           N.ptr(self.ws), self.ws.numel(), s), "cm_coma_actor_fwd_bwd")
         self._allreduce(self.g_actor)
         self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
-        st = torch.cat([self.g_actor[Pa:], self.g_critic[Pc:], self.norms]).cpu().double()  # single sync
-        st_a, st_c = st[:N.NUM_STATS], st[N.NUM_STATS:2 * N.NUM_STATS]
-        n = float(st_a[N.STAT_COUNT])
-        rec = dict(actor_loss=float(-st_a[N.STAT_PG] - hp.entropy_coef * st_a[N.STAT_ENT]) / n,
-                   critic_loss=float(st_c[N.STAT_VLOSS]) / float(st_c[N.STAT_COUNT]), entropy=float(st_a[N.STAT_ENT]) / n,
-                   actor_gnorm=float(st[2 * N.NUM_STATS]), critic_gnorm=float(st[2 * N.NUM_STATS + 1]), n_valid=n,
-                   training_step=self.training_step)
-        if keep_grads:
-            rec.update(actor_grads=self.g_actor[:Pa].clone(), critic_grads=self.g_critic[:Pc].clone())
-        return rec
+        ent_coef, tstep = hp.entropy_coef, self.training_step
+        extra = dict(actor_grads=self.g_actor[:Pa].clone(), critic_grads=self.g_critic[:Pc].clone()) if keep_grads else {}
+
+        def build(st):
+            st_a, st_c = st[:N.NUM_STATS], st[N.NUM_STATS:2 * N.NUM_STATS]
+            n = float(st_a[N.STAT_COUNT])
+            rec = dict(actor_loss=float(-st_a[N.STAT_PG] - ent_coef * st_a[N.STAT_ENT]) / n,
+                       critic_loss=float(st_c[N.STAT_VLOSS]) / float(st_c[N.STAT_COUNT]), entropy=float(st_a[N.STAT_ENT]) / n,
+                       actor_gnorm=float(st[2 * N.NUM_STATS]), critic_gnorm=float(st[2 * N.NUM_STATS + 1]), n_valid=n,
+                       training_step=tstep)
+            rec.update(extra)
+            return [rec]
+        # no host wait here (learner.LazyRecords): the statistics go to a pinned ring slot asynchronously
+        host, ev, attach = _to_host_async(self._ring, torch.cat([self.g_actor[Pa:], self.g_critic[Pc:], self.norms]))
+        lazy = LazyRecords(1, host, ev, build)
+        attach(lazy)
+        return LazyRecord(lazy)
 
     def critic_params(self):
         """Same accessor as PPOLearner.critic_params (COMA's critic runs on the launch stream: nothing to join)."""
