@@ -19,6 +19,7 @@ from .coma_learner import COMAHParams, COMALearner, coma_critic_input_dim
 from .driver import HostActor, host_rollout, host_rollout_shm, host_rollout_single
 from .env.shm_vector import ShmVectorEnv
 from .env.vector import PipeVectorEnv, environment
+from .evaluate import DeviceEvaluator, HostEvaluator, eval_base
 from .learner import NetSpec, init_params_like_torch, pad_time
 from .logger import ScalarWriter
 from .rollout import SyntheticShapeRollout, SyntheticSpreadRollout
@@ -66,7 +67,7 @@ def run(script, argv=None):
                  actions=args.synthetic_actions, avail_p=args.synthetic_avail_p)
     fac = dict(env_type=args.env_type, env_name=args.env_name, env_family=args.env_family, agent_ids=args.agent_ids,
                kwargs={}, seed=args.seed, synthetic=synth)
-    eval_env = environment(**dict(fac, index=10 ** 6))
+    eval_env = environment(**dict(fac, index=eval_base(E_glob)))
     A, Do, Ds, K = eval_env.n_agents, eval_env.get_obs_size(), eval_env.get_state_size(), eval_env.get_action_size()
 
     # construction order actor -> critic (coma_multienvs.py:391-405); the target starts as a copy of the critic (:406)
@@ -119,6 +120,7 @@ def run(script, argv=None):
             torch.save(dict(learner=learner.state_dict(), step=step, episode=roll.episode if roll is not None else 0), args.checkpoint)
 
     iteration = 0
+    evaluator, pending_eval = None, []
     while step < args.total_timesteps:
         training_step = learner.training_step
         epsilon = linear_schedule(args.start_e, args.end_e, args.exploration_fraction, training_step)  # :449-451
@@ -169,28 +171,36 @@ def run(script, argv=None):
             writer.add_scalar("train/epsilon", epsilon, step)
             writer.add_scalar("train/num_updates", learner.training_step, step)
 
-        if rank == 0 and learner.training_step % args.eval_steps == 0:  # :692-727 (actions sampled with eps = 0)
-            eval_obs, _ = eval_env.reset()
-            rets, lens, infos_l, cur_r, cur_l = [], [], [], 0.0, 0
-            while len(rets) < args.num_eval_ep:
-                act, _, _ = host_actor.act(eval_obs[None], np.asarray(eval_env.get_avail_actions())[None], seed=args.seed + 7919)
-                eval_obs, r, done, trunc, info = eval_env.step(act.reshape(-1))
-                cur_r += r; cur_l += 1
-                if done or trunc:
-                    eval_obs, _ = eval_env.reset()
-                    rets.append(cur_r); lens.append(cur_l); infos_l.append(info); cur_r, cur_l = 0.0, 0
-            writer.add_scalar("eval/ep_reward", np.mean(rets), step)
-            writer.add_scalar("eval/std_ep_reward", np.std(rets), step)
-            writer.add_scalar("eval/ep_length", np.mean(lens), step)
-            if args.env_type == "smaclite":
-                writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
+        for log_eval in pending_eval:  # the evaluation launched behind the previous iteration ran under this one (evaluate.py)
+            log_eval()
+        pending_eval.clear()
+        if learner.training_step % args.eval_steps == 0:  # :692-727 (actions sampled with eps = 0), num_eval_ep episodes side by side
+            eval_round = learner.training_step // args.eval_steps
+            greedy = bool(getattr(args, "greedy_eval", False))
+            if device_env:
+                if rank == 0:
+                    if evaluator is None:
+                        evaluator = DeviceEvaluator(args, actor_spec, A, device, E_glob)
+                    res = evaluator.launch(learner.actor, eval_round, greedy=greedy)
+                    pending_eval.append(lambda res=res, step=step: res.log(writer, step))
+            else:
+                if evaluator is None:
+                    evaluator = HostEvaluator(lambda index: environment(**dict(fac, index=index)), eval_env, host_actor, args, A, False,
+                                              device, E_glob, rank, world, pg)
+                res = evaluator.run(eval_round, greedy=greedy)
+                if rank == 0:
+                    res.log(writer, step, smaclite=args.env_type == "smaclite")
 
+    for log_eval in pending_eval:
+        log_eval()
     save_checkpoint()
     if writer:
         writer.close()
     if args.use_wnb and rank == 0:
         import wandb
         wandb.finish()
+    if isinstance(evaluator, HostEvaluator):
+        evaluator.close()
     eval_env.close()
     if pinned is not None:
         pinned.close()

@@ -41,7 +41,7 @@ struct RolloutArgs {
     float* env_state;  // [E][6A]: pos(2A) vel(2A) landmarks(2A) -- written at the end (state after step T-1)
     int E, A, T, agent_ids;
     unsigned long long seed, act_seed;
-    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_rollout_spread_eps)
+    float act_eps;  // > 0: COMA's epsilon-mixed sampling (cm_rollout_spread_eps); < 0: greedy (evaluation rollouts)
     long env_offset, episode;
     const float* params; int din, H, L, K;
     float* obs; float* state; int* action; float* logp; float* reward;
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
                     int chosen; float lpv;
                     const float u_row = ubuf[(t & 3) * TM + tid];
                     if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + tid * 8, K, u_row, a.act_eps, &chosen, &lpv);
+                    else if (a.act_eps < 0.0f) cm_categorical_greedy(ls + tid * 8, K, &chosen, &lpv);  // evaluation rollouts (--greedy_eval)
                     else cm_categorical_sample(ls + tid * 8, K, u_row, &chosen, &lpv);
                     const long o = (e * A + i) * (long)T + t;
                     a.action[o] = chosen;
@@ -730,6 +731,17 @@ __device__ __forceinline__ void sample_row8(const float (&z)[8], int K, float u,
     for (int k = 0; k < 8; ++k) if (k < K) m = fmaxf(m, z[k]);
     float e[8], s = 0.0f;
     int chosen = -1, last = 0;
+    if (eps < 0.0f) {  // greedy (cm_categorical_greedy: first maximal logit, log-prob = -log sum exp(z - max))
+        int best = 0;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < K && z[k] > mm) { mm = z[k]; best = k; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < K) s += expf(z[k] - mm);
+        *action = best;
+        *logp = -logf(s);
+        return;
+    }
     if (eps > 0.0f) {
         int navail = 0;
 #pragma unroll
@@ -1396,6 +1408,7 @@ __global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArg
                 const int i = srow - s_el * A;
                 int chosen; float lpv;
                 if (a.act_eps > 0.0f) cm_categorical_sample_eps(ls + srow * 8, K, u_row, a.act_eps, &chosen, &lpv);
+                else if (a.act_eps < 0.0f) cm_categorical_greedy(ls + srow * 8, K, &chosen, &lpv);  // evaluation rollouts (--greedy_eval)
                 else cm_categorical_sample(ls + srow * 8, K, u_row, &chosen, &lpv);
                 (void)i;
                 const float ux = (chosen == 1) ? -ACCEL : (chosen == 2 ? ACCEL : 0.0f);
@@ -1466,7 +1479,7 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
         CM_CHECK_LAUNCH("cm_rollout_spread");
         return 0;
     }
-    if (use16) {
+    if (use16 && !(eps < 0.0f)) {  // greedy evaluation rollouts of 257 .. 768 16-row tiles take the 64-row forms below
         const size_t lds16 = ((size_t)TS * LDT * 2 + TS * 2 * 3 + 4 * TS + 2 * TS) * sizeof(float);  // tiles + env scratch: the weights are in registers
         const int grid16 = nt16 < 768 ? nt16 : 768;  // three workgroups per CU (launch bounds)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_spread16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
@@ -1516,7 +1529,7 @@ extern "C" int cm_rollout_spread_ld(float* env_state, int E, int A, int T, int a
                                     int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, double eps,
                                     float* obs, int64_t obs_ld, float* state, int64_t state_ld, int32_t* action, float* logp,
                                     float* reward, cm_stream_t stream) {
-    CM_REQUIRE(eps >= 0.0 && eps <= 1.0, "cm_rollout_spread_ld: eps=%g outside [0, 1]", eps);
+    CM_REQUIRE(eps <= 1.0, "cm_rollout_spread_ld: eps=%g above 1 (eps < 0: greedy, the argmax of the masked logits)", eps);
     return rollout_spread(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, n_hidden_layers, (float)eps,
                           obs, state, action, logp, reward, stream, obs_ld, state_ld);
 }

@@ -20,6 +20,7 @@ from . import _native as N
 from .args import parse_args
 from .env.shm_vector import ShmVectorEnv
 from .env.vector import PipeVectorEnv, environment
+from .evaluate import DeviceEvaluator, HostEvaluator, eval_base
 from .learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch, pad_time
 from .logger import ScalarWriter
 from .rollout import SyntheticShapeRollout, SyntheticSpreadRollout
@@ -44,14 +45,19 @@ class HostActor:
         self.calls = 0
         self.ws = None
 
-    def act(self, obs, avail, h=None, seed=0, greedy=False, eps=0.0):
+    def act(self, obs, avail, h=None, seed=0, greedy=False, eps=0.0, t=None, row_offset=None):
+        """t / row_offset: explicit Philox step counter / global index of the first row (the evaluators key their draws like the device
+        rollouts: evaluate.py); default: this actor's own call counter and row offset (the training rollouts of the host envs)."""
         spec = self.L.actor_spec
         x = torch.as_tensor(np.ascontiguousarray(obs), dtype=torch.float32).reshape(-1, spec.din).to(self.dev)
         av = torch.as_tensor(np.ascontiguousarray(avail)).reshape(-1, spec.dout).to(torch.uint8).to(self.dev)
         rows = x.shape[0]
         action = torch.empty(rows, dtype=torch.int32, device=self.dev)
         logp = torch.empty(rows, dtype=torch.float32, device=self.dev)
-        self.calls += 1
+        if t is None:
+            self.calls += 1
+            t = self.calls
+        row_offset = self.row_offset if row_offset is None else int(row_offset)
         if self.recurrent:
             if h is None:
                 h = torch.zeros(rows, spec.hidden, dtype=torch.float32, device=self.dev)
@@ -60,7 +66,7 @@ class HostActor:
             if self.ws is None or self.ws.numel() < need:
                 self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             N.check(self.lib.cm_gru_policy_act_ws(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.dout,
-                                                  N.ptr(self.L.actor), N.ptr(h), -1.0 if greedy else 0.0, seed, self.row_offset, self.calls,
+                                                  N.ptr(self.L.actor), N.ptr(h), -1.0 if greedy else 0.0, seed, row_offset, t,
                                                   N.ptr(action), N.ptr(logp), 1, N.ptr(self.ws), self.ws.numel(), N.stream_ptr()),
                     "cm_gru_policy_act_ws")
         else:
@@ -70,7 +76,7 @@ class HostActor:
             if need and (self.ws is None or self.ws.numel() < need):
                 self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             N.check(self.lib.cm_policy_act_ws(N.ptr(x), spec.din, N.ptr(av), spec.dout, rows, spec.din, spec.hidden, spec.n_layers,
-                                              spec.dout, N.ptr(self.L.actor), mode, seed, self.row_offset, self.calls, N.ptr(action), N.ptr(logp), 1,
+                                              spec.dout, N.ptr(self.L.actor), mode, seed, row_offset, t, N.ptr(action), N.ptr(logp), 1,
                                               N.ptr(self.ws) if need else None, need, N.stream_ptr()), "cm_policy_act_ws")
         return action.cpu().numpy(), logp.cpu().numpy(), h
 
@@ -215,7 +221,7 @@ def run(script, argv=None):
                  actions=args.synthetic_actions, avail_p=args.synthetic_avail_p)
     fac = dict(env_type=args.env_type, env_name=args.env_name, env_family=args.env_family, agent_ids=args.agent_ids,
                kwargs={}, seed=args.seed, synthetic=synth)
-    eval_env = environment(**dict(fac, index=10 ** 6))
+    eval_env = environment(**dict(fac, index=eval_base(E_glob)))
     A, Do, Ds, K = eval_env.n_agents, eval_env.get_obs_size(), eval_env.get_state_size(), eval_env.get_action_size()
 
     # networks in the reference's construction order actor -> critic (:329-339) so torch.manual_seed reproduces them
@@ -291,16 +297,20 @@ def run(script, argv=None):
     # device env nothing on the host depends on them, so iteration i is accounted for AFTER iteration i + 1 has been enqueued: the host
     # never waits for work it has just launched and the launch queue stays fed (the CLI's steady state was 1.75 ms per iteration at 512
     # envs against 1.52 ms of bench.py's loop, profiles/r03_cli_steady_state.txt).  The accounting runs in iteration order with that
-    # iteration's step / training_step, so the logged history is exactly the undeferred one; evaluation, checkpoints and the end of
+    # iteration's step / training_step (the rollout-logging cadence of mappo_lstm_multienvs from the PRE-update counter, as the reference
+    # tests it), so the logged history is exactly the undeferred one; evaluation, checkpoints and the end of
     # the run flush it first.  Host envs account immediately (their rollouts wait for the host anyway).
     pending = []
     rew_ring = [None, None]
+    evaluator = None  # built at the first evaluation (evaluate.py)
 
     def flush():
         while pending:
             pending.pop(0)()
 
-    def make_account(stats_fn, recs, step, training_step, num_episodes):
+    def make_account(stats_fn, recs, step, training_step, num_episodes, ts_rollout):
+        """ts_rollout: training_step BEFORE this iteration's update -- the reference tests its rollout-logging cadence between rollout
+        and update (mappo_lstm_multienvs.py:486); training_step (after the update) is what train/num_updates logs (:612)."""
         def account():
             nonlocal ep_rewards, ep_lengths, ep_stats
             stats = stats_fn()
@@ -322,7 +332,7 @@ def run(script, argv=None):
                 ep_rewards.extend(stats["ep_reward"]); ep_lengths.extend(stats["ep_len"])
                 if args.env_type == "smaclite":
                     ep_stats.extend([i["battle_won"] for i in stats["infos"]])
-            log_now = (training_step % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
+            log_now = (ts_rollout % args.log_every == 0) if script == "mappo_lstm_multienvs" else (len(ep_rewards) > args.log_every)
             if log_now:
                 if writer:
                     writer.add_scalar("rollout/ep_reward", np.mean(ep_rewards), step)
@@ -391,9 +401,10 @@ def run(script, argv=None):
             def stats_fn(slot=rew_ring[k], T_=b.T):
                 slot[1].synchronize()
                 return dict(ep_reward=slot[0].tolist(), ep_len=[T_] * E, infos=[None] * E)
+        ts_rollout = training_step
         training_step += len(recs)
         iteration += 1
-        acct = make_account(stats_fn, recs, step, training_step, num_episodes)
+        acct = make_account(stats_fn, recs, step, training_step, num_episodes, ts_rollout)
         if device_env:
             flush()                 # iteration i - 1, now that iteration i is enqueued
             pending.append(acct)
@@ -403,24 +414,24 @@ def run(script, argv=None):
             flush()
             save_checkpoint()
 
-        if (training_step / args.epochs) % args.eval_steps == 0:
-            flush()  # on every rank: the accounting contains collectives at world > 1
-        if rank == 0 and (training_step / args.epochs) % args.eval_steps == 0:  # :614-650 (actions are SAMPLED)
-            eval_obs, _ = eval_env.reset()
-            rets, lens, infos_l, cur_r, cur_l, h_eval = [], [], [], 0.0, 0, None
-            while len(rets) < args.num_eval_ep:
-                act, _, h_eval = host_actor.act(eval_obs[None], np.asarray(eval_env.get_avail_actions())[None], h=h_eval,
-                                                seed=args.seed + 7919, greedy=args.greedy_eval)
-                eval_obs, r, done, trunc, info = eval_env.step(act.reshape(-1))
-                cur_r += r; cur_l += 1
-                if done or trunc:
-                    eval_obs, _ = eval_env.reset()
-                    rets.append(cur_r); lens.append(cur_l); infos_l.append(info); cur_r, cur_l, h_eval = 0.0, 0, None
-            writer.add_scalar("eval/ep_reward", np.mean(rets), step)
-            writer.add_scalar("eval/std_ep_reward", np.std(rets), step)
-            writer.add_scalar("eval/ep_length", np.mean(lens), step)
-            if args.env_type == "smaclite":
-                writer.add_scalar("eval/battle_won", np.mean([i["battle_won"] for i in infos_l]), step)
+        if (training_step / args.epochs) % args.eval_steps == 0:  # :614-650 (actions are SAMPLED unless --greedy_eval)
+            # num_eval_ep episodes side by side (evaluate.py): device envs as ONE rollout on the lowest-priority evaluation stream of rank 0
+            # (it runs under the next iteration; its numbers are logged when this iteration is accounted for), host envs stepped together with
+            # one act call per time step, the episodes dealt over the ranks
+            eval_round = int(training_step / args.epochs) // args.eval_steps
+            if device_env:
+                if rank == 0:
+                    if evaluator is None:
+                        evaluator = DeviceEvaluator(args, actor_spec, A, device, E_glob)
+                    res = evaluator.launch(learner.actor, eval_round, greedy=args.greedy_eval)
+                    pending.append(lambda res=res, step=step: res.log(writer, step))
+            else:
+                if evaluator is None:
+                    evaluator = HostEvaluator(lambda index: environment(**dict(fac, index=index)), eval_env, host_actor, args, A, recurrent,
+                                              device, E_glob, rank, world, pg)
+                res = evaluator.run(eval_round, greedy=args.greedy_eval)
+                if rank == 0:
+                    res.log(writer, step, smaclite=args.env_type == "smaclite")
 
     flush()
     save_checkpoint()
@@ -429,6 +440,8 @@ def run(script, argv=None):
     if args.use_wnb and rank == 0:
         import wandb
         wandb.finish()
+    if isinstance(evaluator, HostEvaluator):
+        evaluator.close()
     eval_env.close()
     if pinned is not None:
         pinned.close()

@@ -185,12 +185,16 @@ class GRUSyntheticRollout:
         self.h = None
         self.episode = 0
 
-    def collect(self, actor_flat, actor_spec, fused=None):
+    def collect(self, actor_flat, actor_spec, fused=None, eps=0.0):
+        """eps < 0: greedy actions (evaluation rollouts of --greedy_eval, evaluate.py) -- on the per-step path, whose act kernel has the
+        argmax; the recurrent scripts have no epsilon-mixed exploration (eps > 0 is an error of the library)."""
         N.sync_env_options()
         self.batch = self.batches[self.episode & 1]
         lib, b, s = self.lib, self.batch, N.stream_ptr()
         E, A, T, Do, K = self.E, self.A, self.T, self.Do, self.K
         can_fuse = bool(lib.cm_gru_rollout_spread_supported(A, int(self.agent_ids), actor_spec.hidden))
+        if eps != 0.0:
+            fused = False
         if fused is None:
             fused = can_fuse
         if fused:  # the whole episode in one persistent launch (same seeds => same rollout as the per-step path below)
@@ -214,7 +218,7 @@ class GRUSyntheticRollout:
             self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         for t in range(T):
             N.check(lib.cm_gru_policy_act_ws(off(b.obs, 4 * t * Do), T * Do, off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                             actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), 0.0, act_seed, self.env_offset * A, t,
+                                             actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), float(eps), act_seed, self.env_offset * A, t,
                                              off(b.action, 4 * t), off(b.logp, 4 * t), T, N.ptr(self.act_ws), self.act_ws.numel(), s),
                     "cm_gru_policy_act_ws")
             N.check(lib.cm_synth_env_step(N.ptr(self.env_state), N.ptr(b.action), E, A, int(self.agent_ids), t, T,

@@ -118,7 +118,7 @@ class SyntheticShapeRollout:
             need = lib.cm_policy_act_workspace_bytes(E * A, actor_spec.din, actor_spec.hidden, actor_spec.n_layers, K)
             if need and (getattr(self, "act_ws", None) is None or self.act_ws.numel() < need):
                 self.act_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if eps > 0.0 or need:
+        if eps != 0.0 or need:  # eps > 0: COMA's mixture; eps < 0: greedy evaluation rollouts -- the per-step act kernel has both samplers
             fused = False
         N.check(lib.cm_shape_env_fill_ld(E, A, T, self.obs_raw, int(self.agent_ids), self.Ds, K, self.avail_p, self.seed, self.env_offset,
                                          self.episode, N.ptr(b.obs), b.obs_ld, N.ptr(b.state), b.state_ld, N.ptr(b.avail), s),
@@ -147,7 +147,7 @@ class SyntheticShapeRollout:
         for t in range(T):
             if gru:
                 N.check(lib.cm_gru_policy_act_ws(_off(b.obs, 4 * t * b.obs_ld), T * b.obs_ld, _off(b.avail, t * K), T * K, E * A, actor_spec.din,
-                                                 actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), 0.0, act_seed, self.env_offset * A, t,
+                                                 actor_spec.hidden, K, N.ptr(actor_flat), N.ptr(self.h), float(min(eps, 0.0)), act_seed, self.env_offset * A, t,
                                                  _off(b.action, 4 * t), _off(b.logp, 4 * t), T, N.ptr(self.gru_ws), self.gru_ws.numel(), s),
                         "cm_gru_policy_act_ws")
             else:

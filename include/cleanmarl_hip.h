@@ -355,7 +355,8 @@ int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* ava
 int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
                          int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                          const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
-/* eps = 0: cm_rollout_spread; eps in (0, 1]: cm_rollout_spread_eps */
+/* eps = 0: cm_rollout_spread; eps in (0, 1]: cm_rollout_spread_eps; eps < 0: greedy -- every agent takes the first maximal masked logit
+ * (the evaluation rollouts of --greedy_eval: cleanmarl/mappo_multienvs.py:614-650 as ONE launch over num_eval_ep environments) */
 int cm_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
                          int64_t env_offset, int64_t episode, const float* params, int hidden, int n_hidden_layers, double eps,
                          float* obs, int64_t obs_ld, float* state, int64_t state_ld, int32_t* action, float* logp, float* reward,
