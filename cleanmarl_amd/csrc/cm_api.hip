@@ -80,3 +80,32 @@ extern "C" int cm_stream_destroy(cm_stream_t stream) {
     if (e != hipSuccess) CM_FAIL(-2, "cm_stream_destroy: %s", hipGetErrorString(e));
     return 0;
 }
+
+// ---- known-answer access to the counter RNG (include/cleanmarl_hip.h): cm_philox4x32 of cm_common.h, the generator behind every
+// sampler and synthetic env of the library, evaluated on explicit (counter, key) words -- on the host and on the device -- so that
+// tests can hold it to the published Random123 Philox4x32-10 vectors instead of to its own numpy twin.
+extern "C" int cm_philox4x32_host(const uint32_t* ctr_key, int64_t n, uint32_t* out) {
+    CM_REQUIRE(ctr_key && out && n >= 0, "cm_philox4x32_host: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* c = ctr_key + 6 * i;
+        const cm_u4 r = cm_philox4x32(c[0], c[1], c[2], c[3], c[4], c[5]);
+        out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+    }
+    return 0;
+}
+namespace {
+__global__ void k_philox_kat(const uint32_t* __restrict__ ctr_key, int64_t n, uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* c = ctr_key + 6 * i;
+    const cm_u4 r = cm_philox4x32(c[0], c[1], c[2], c[3], c[4], c[5]);
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+}  // namespace
+extern "C" int cm_philox4x32_device(const uint32_t* ctr_key, int64_t n, uint32_t* out, cm_stream_t stream) {
+    CM_REQUIRE(ctr_key && out && n >= 0, "cm_philox4x32_device: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_philox_kat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctr_key, n, out);
+    CM_CHECK_LAUNCH("cm_philox4x32_device");
+    return 0;
+}

@@ -282,6 +282,14 @@ int cm_gru_policy_act_ws(const float* x, int64_t x_row_stride, const uint8_t* av
                          uint64_t seed, int64_t row_offset, int t, int32_t* action, float* logp, int64_t out_stride,
                          void* ws, size_t ws_bytes, cm_stream_t stream);
 
+/* ---- the counter RNG behind every sampler and synthetic env: Philox4x32-10 (Salmon et al., SC'11; Random123).  The reference draws from
+ * torch's global generator (Categorical.sample, cleanmarl/mappo_multienvs.py:172-176) and re-seeds its workers from OS entropy (:251), so
+ * its streams are not reproducible; this build keys every draw by (seed, global row, t, stream id).  These two entry points evaluate the
+ * library's generator on explicit words -- ctr_key [n][6] = c0 c1 c2 c3 k0 k1, out [n][4] -- on the host and on the device (device
+ * pointers), so that tests can pin it to the published known-answer vectors. */
+int cm_philox4x32_host(const uint32_t* ctr_key, int64_t n, uint32_t* out);
+int cm_philox4x32_device(const uint32_t* ctr_key, int64_t n, uint32_t* out, cm_stream_t stream);
+
 /* ---- a15: on-device synthetic MPE-like environment (replaces the pipe round trips at
  * cleanmarl/mappo_multienvs.py:393-453 for the synthetic configs; CommonInterface semantics of
  * cleanmarl/env/common_interface.py:5-23 and the obs/state construction of

@@ -3,18 +3,14 @@ Restates Actor.act (cleanmarl/mappo_multienvs.py:172-176) with the build's count
 inverse-CDF on softmax(logits) with one Philox4x32-10 uniform keyed by (seed, global row, t)."""
 import numpy as np
 
-from cleanmarl_amd.env.philox import STREAM_ACT, philox4x32, split_seed, u01
+from .philox import act_uniforms  # the checker's own Philox4x32-10 (pinned to the Random123 known-answer vectors), not the product's
 
 
 def act(logits, avail, seed, row_offset, t):
     """logits [R,K] float32 (already masked with -1e9), avail [R,K] bool -> (action[R], logp[R], u[R])"""
     logits = np.asarray(logits, dtype=np.float32)
     R, K = logits.shape
-    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row_offset))
-    k0, k1 = split_seed(seed)
-    x, _, _, _ = philox4x32((rows & np.uint64(0xFFFFFFFF)).astype(np.uint32), (rows >> np.uint64(32)).astype(np.uint32),
-                            np.uint32(t), np.uint32(STREAM_ACT), k0, k1)
-    u = u01(x)
+    u = act_uniforms(R, seed, row_offset, t)
     m = logits.max(1, keepdims=True)
     e = np.exp(logits - m).astype(np.float32)
     ssum = np.zeros(R, np.float32)
@@ -41,11 +37,7 @@ def act_eps(logits, avail, eps, seed, row_offset, t):
     logits = np.asarray(logits, dtype=np.float32)
     avail = np.asarray(avail, dtype=bool)
     R, K = logits.shape
-    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row_offset))
-    k0, k1 = split_seed(seed)
-    x, _, _, _ = philox4x32((rows & np.uint64(0xFFFFFFFF)).astype(np.uint32), (rows >> np.uint64(32)).astype(np.uint32),
-                            np.uint32(t), np.uint32(STREAM_ACT), k0, k1)
-    u = u01(x)
+    u = act_uniforms(R, seed, row_offset, t)
     m = logits.max(1, keepdims=True)
     e = np.exp(logits - m).astype(np.float64)
     probs = (1.0 - eps) * e / e.sum(1, keepdims=True) + eps * avail / np.maximum(avail.sum(1, keepdims=True), 1)

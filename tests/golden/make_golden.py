@@ -14,8 +14,9 @@ the per-epoch logged scalars; initial weights, per-step gradients and post-step
 weights are captured by subclassing the torch optimiser the script looks up with
 ``getattr(optim, args.optimizer)``.
 
-The synthetic environment below is OURS (deterministic, numpy, implements the
-reference's CommonInterface surface: cleanmarl/env/common_interface.py:5-23).
+The synthetic environment (tests/stub_envs.py::SynthEnv) is OURS (deterministic, numpy, implements
+the reference's CommonInterface surface: cleanmarl/env/common_interface.py:5-23); it lives next to the other
+test stand-ins so that the host-collation tests can replay the very episodes the goldens were captured on.
 
 usage:  python tests/golden/make_golden.py            # writes tests/golden/*.npz
 """
@@ -33,88 +34,8 @@ REF = "/root/reference/cleanmarl"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-# --------------------------------------------------------------------------
-# deterministic synthetic env (implements CommonInterface)
-# --------------------------------------------------------------------------
-class SynthEnv:
-    """Fixed-shape multi-agent env whose transitions are a pure function of
-    (env_id, episode, t).  Horizon differs per env instance when ``ragged``."""
-
-    counter = 0
-    spec = dict(A=3, obs_raw=6, K=5, horizon=16, ragged=False, avail_p=1.0,
-                state_dim=None, done_mode="truncate")
-
-    def __init__(self, agent_ids=True, **kw):
-        s = SynthEnv.spec
-        self.env_id = SynthEnv.counter
-        SynthEnv.counter += 1
-        self.n_agents = s["A"]
-        self.agent_ids = agent_ids
-        self.obs_raw = s["obs_raw"]
-        self.K = s["K"]
-        self.state_dim = s["state_dim"] or self.obs_raw * self.n_agents
-        h = s["horizon"]
-        if s["ragged"]:
-            h = h - (self.env_id * 5) % (h // 2 + 1)
-        self.horizon = max(2, h)
-        self.avail_p = s["avail_p"]
-        self.done_mode = s["done_mode"]
-        self.episode = -1
-        self.t = 0
-
-    # -- helpers ----------------------------------------------------------
-    def _rng(self, salt):
-        return np.random.default_rng([self.env_id, self.episode, self.t, salt])
-
-    def _observe(self):
-        raw = self._rng(0).standard_normal((self.n_agents, self.obs_raw))
-        if self.state_dim == self.obs_raw * self.n_agents:
-            self.state = raw.reshape(-1).copy()
-        else:
-            self.state = self._rng(1).standard_normal(self.state_dim)
-        if self.agent_ids:
-            raw = np.concatenate((raw, np.eye(self.n_agents)), axis=1)
-        return raw
-
-    # -- CommonInterface --------------------------------------------------
-    def reset(self, seed=None):
-        self.episode += 1
-        self.t = 0
-        return self._observe(), {}
-
-    def step(self, actions):
-        acts = np.asarray([int(a) for a in actions])
-        reward = float(self._rng(2).standard_normal() + 0.1 * np.mean(acts == (self.t % self.K)))
-        self.t += 1
-        end = self.t >= self.horizon
-        done = bool(end and self.done_mode == "done" and self.env_id % 2 == 0)
-        truncated = bool(end and not done)
-        return self._observe(), reward, done, truncated, {"battle_won": False}
-
-    def get_avail_actions(self):
-        if self.avail_p >= 1.0:
-            return np.ones((self.n_agents, self.K), dtype=np.int64)
-        av = (self._rng(3).random((self.n_agents, self.K)) < self.avail_p).astype(np.int64)
-        av[:, 0] = 1
-        return av
-
-    def get_state(self):
-        return self.state
-
-    def get_obs_size(self):
-        return self.obs_raw + self.agent_ids * self.n_agents
-
-    def get_state_size(self):
-        return self.state_dim
-
-    def get_action_size(self):
-        return self.K
-
-    def sample(self):
-        return [0] * self.n_agents
-
-    def close(self):
-        pass
+sys.path.insert(0, os.path.dirname(OUT))
+from stub_envs import SynthEnv  # noqa: E402  the deterministic env the goldens were collected on (OURS; tests replay it: test_pins.py)
 
 
 class _SW:

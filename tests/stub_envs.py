@@ -126,6 +126,93 @@ class FakeTimeLimit:
         self.env.close()
 
 
+class SynthEnv:
+    """The env the reference goldens were collected on (tests/golden/make_golden.py runs the unmodified reference scripts against it):
+    fixed-shape multi-agent env whose transitions are a pure function of (env_id, episode, t).  Horizon differs per env instance when
+    ``ragged``.  Implements the reference's CommonInterface surface (cleanmarl/env/common_interface.py:5-23)."""
+
+    counter = 0
+    spec = dict(A=3, obs_raw=6, K=5, horizon=16, ragged=False, avail_p=1.0,
+                state_dim=None, done_mode="truncate")
+
+    def __init__(self, agent_ids=True, env_id=None, **kw):
+        """env_id: explicit instance number (the host-collation replay builds env i of a vector env with env_id = i, which is what
+        the reference's construction order -- batch_size training envs, then eval_env, mappo_multienvs.py:301-326 -- gave the goldens);
+        default: the class counter, as tests/golden/make_golden.py uses it."""
+        s = SynthEnv.spec
+        if env_id is None:
+            env_id = SynthEnv.counter
+            SynthEnv.counter += 1
+        self.env_id = int(env_id)
+        self.n_agents = s["A"]
+        self.agent_ids = agent_ids
+        self.obs_raw = s["obs_raw"]
+        self.K = s["K"]
+        self.state_dim = s["state_dim"] or self.obs_raw * self.n_agents
+        h = s["horizon"]
+        if s["ragged"]:
+            h = h - (self.env_id * 5) % (h // 2 + 1)
+        self.horizon = max(2, h)
+        self.avail_p = s["avail_p"]
+        self.done_mode = s["done_mode"]
+        self.episode = -1
+        self.t = 0
+
+    # -- helpers ----------------------------------------------------------
+    def _rng(self, salt):
+        return np.random.default_rng([self.env_id, self.episode, self.t, salt])
+
+    def _observe(self):
+        raw = self._rng(0).standard_normal((self.n_agents, self.obs_raw))
+        if self.state_dim == self.obs_raw * self.n_agents:
+            self.state = raw.reshape(-1).copy()
+        else:
+            self.state = self._rng(1).standard_normal(self.state_dim)
+        if self.agent_ids:
+            raw = np.concatenate((raw, np.eye(self.n_agents)), axis=1)
+        return raw
+
+    # -- CommonInterface --------------------------------------------------
+    def reset(self, seed=None):
+        self.episode += 1
+        self.t = 0
+        return self._observe(), {}
+
+    def step(self, actions):
+        acts = np.asarray([int(a) for a in actions])
+        reward = float(self._rng(2).standard_normal() + 0.1 * np.mean(acts == (self.t % self.K)))
+        self.t += 1
+        end = self.t >= self.horizon
+        done = bool(end and self.done_mode == "done" and self.env_id % 2 == 0)
+        truncated = bool(end and not done)
+        return self._observe(), reward, done, truncated, {"battle_won": False}
+
+    def get_avail_actions(self):
+        if self.avail_p >= 1.0:
+            return np.ones((self.n_agents, self.K), dtype=np.int64)
+        av = (self._rng(3).random((self.n_agents, self.K)) < self.avail_p).astype(np.int64)
+        av[:, 0] = 1
+        return av
+
+    def get_state(self):
+        return self.state
+
+    def get_obs_size(self):
+        return self.obs_raw + self.agent_ids * self.n_agents
+
+    def get_state_size(self):
+        return self.state_dim
+
+    def get_action_size(self):
+        return self.K
+
+    def sample(self):
+        return [0] * self.n_agents
+
+    def close(self):
+        pass
+
+
 def install(monkeypatch):
     """Put the fake packages into sys.modules for the duration of a test."""
     pz, mpe, spread = types.ModuleType("pettingzoo"), types.ModuleType("pettingzoo.mpe"), types.ModuleType("pettingzoo.mpe.simple_spread_v3")

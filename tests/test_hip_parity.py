@@ -878,6 +878,115 @@ def test_full_size_update_is_deterministic_and_finite():
     assert [r["actor_loss"] for r in r1] == [r["actor_loss"] for r in r2]
 
 
+# BASELINE.json configs[3] (IPPO, SMAClite-shaped: 2048 envs x 10 agents x 256 steps, obs 105 + 10 ids, 17 actions with availability masks,
+# per-agent critic of width 32 as ippo_multienvs.py:34 defaults) and configs[1] (MAPPO 1024 x 3 x 128, obs 18 + 3 ids) at FULL size, in the
+# storage the product uses (leading dimensions rounded up to 4 floats: the two-chunk k_mlp<2, ...> actor / k_mlp<-2> forward of config 4
+# and the padded 21-wide rows of config 2 are otherwise only ever launched by bench.py)
+_FULL = {"cfg4": dict(algo="ippo", E=2048, A=10, T=256, Do=115, Ds=243, K=17, Hc=32, avail_p=0.7, shard=16),
+         "cfg2": dict(algo="mappo", E=1024, A=3, T=128, Do=21, Ds=54, K=5, Hc=64, avail_p=1.0, shard=32)}
+
+
+def _full_size_cfg(name, seed=0):
+    from cleanmarl_amd.learner import DeviceBatch, HParams, NetSpec, PPOLearner, init_params_like_torch
+    c = _FULL[name]
+    dev = torch.device("cuda:0")
+    E, A, T, Do, Ds, K = c["E"], c["A"], c["T"], c["Do"], c["Ds"], c["K"]
+    g = torch.Generator(device=dev).manual_seed(seed)
+    b = DeviceBatch(E, A, T, Do, Ds, K, dev, pad_obs=True, pad_state=True)
+    b.obs.copy_(torch.randn(E, A, T, Do, generator=g, device=dev)); b.state.copy_(torch.randn(E, T, Ds, generator=g, device=dev))
+    av = torch.rand(E, A, T, K, generator=g, device=dev) < c["avail_p"]
+    av[..., 0] = True  # action 0 is always legal
+    b.avail.copy_(av.to(torch.uint8))
+    # taken actions must be legal ones: the first legal action at or after a random index
+    r = torch.randint(0, K, (E, A, T, 1), generator=g, device=dev)
+    idx = (torch.arange(K, device=dev).view(1, 1, 1, K) + r) % K
+    first = torch.gather(av, 3, idx).float().argmax(3, keepdim=True)
+    b.action.copy_(torch.gather(idx, 3, first).squeeze(3).int())
+    b.logp.copy_(-1.6 + 0.1 * torch.randn(E, A, T, generator=g, device=dev)); b.reward.copy_(torch.randn(E, T, generator=g, device=dev))
+    b.ep_len.copy_(torch.randint(T // 2, T + 1, (E,), generator=g, device=dev).int())
+    torch.manual_seed(1)
+    aspec, cspec = NetSpec(Do, 64, 1, K), NetSpec(Ds if c["algo"] == "mappo" else Do, c["Hc"], 1, 1)
+    L = PPOLearner(c["algo"], aspec, cspec, A, HParams(), dev, init_params_like_torch(aspec), init_params_like_torch(cspec))
+    return L, b, c
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg2"])
+def test_full_size_other_configs_shard_additivity_and_oracle_shard(name):
+    """Configs 4 and 2 at BASELINE size: the sums of uneven env shards add up to the full batch, N = b_mask.sum(), and one shard small
+    enough for the CPU restatement (16 / 32 envs) matches it -- gradients of both networks, losses, returns and advantages."""
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    L, b, c = _full_size_cfg(name)
+    algo, E = c["algo"], c["E"]
+    L.compute_targets(b)
+    s = N.stream_ptr()
+    L.actor_pass(b, s); L.critic_pass(b, s)
+    full = L.gbuf.clone()
+    parts = torch.zeros_like(full)
+    first = None
+    n0 = c["shard"]
+    for lo, hi in ((0, n0), (n0, E // 3 + 5), (E // 3 + 5, E)):
+        sb = b.shard(lo, hi)
+        L.actor_pass(sb, s); L.critic_pass(sb, s)
+        parts += L.gbuf
+        if first is None:
+            first = L.gbuf.clone()
+    torch.cuda.synchronize()
+    assert (full - parts).abs().max().item() <= 1e-4 * full.abs().max().item()
+    Pa, Pc = L.actor.numel(), L.critic.numel()
+    n_rows = b.ep_len.sum().item()
+    assert full[Pa + 5].item() == n_rows and full[Pa + 8 + Pc + 5].item() == n_rows  # N = b_mask.sum() for both networks (ippo_multienvs.py:571-572)
+    sb = b.shard(0, n0)
+    T = b.T
+    mask = torch.arange(T)[None, :] < sb.ep_len.cpu()[:, None]
+    batch = dict(obs=sb.obs.permute(0, 2, 1, 3).cpu(), actions=sb.action.permute(0, 2, 1).long().cpu(), log_probs=sb.logp.permute(0, 2, 1).cpu(),
+                 reward=sb.reward.cpu(), states=sb.state.cpu(), avail=sb.avail.permute(0, 2, 1, 3).bool().cpu(), mask=mask)
+    hp = dict(gamma=0.99, td_lambda=0.95, epochs=1, ppo_clip=0.2, entropy_coef=0.001, clip_gradients=-1, optimizer="Adam",
+              learning_rate_actor=8e-4, learning_rate_critic=8e-4, normalize_reward=False, normalize_advantage=False, normalize_return=False)
+    split = lambda flat, spec: [q.reshape(sh) for q, sh in zip(torch.split(flat.cpu(), [int(np.prod(sh)) for sh in spec.shapes()]), spec.shapes())]
+    ap, cp = split(L.actor, L.actor_spec), split(L.critic_params(), L.critic_spec)
+    ret, adv = R.prepare_targets(batch, cp, hp, algo)
+    m3 = mask[:, :, None].numpy()
+    assert _err(sb.ret.permute(0, 2, 1).cpu().numpy() * m3, ret.numpy() * m3) <= TOL
+    assert _err(sb.adv.permute(0, 2, 1).cpu().numpy() * m3, adv.numpy() * m3) <= TOL
+    scal, ag, cg = R.mlp_epoch(ap, cp, batch, sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu(), hp, algo)
+    n = float(first[Pa + 5])
+    assert n == float(mask.sum())
+    assert _err((first[:Pa] / n).cpu().numpy(), R.flat(ag).numpy()) <= TOL
+    assert _err((first[Pa + 8:Pa + 8 + Pc] / n).cpu().numpy(), R.flat(cg).numpy()) <= TOL
+    assert abs(float((-first[Pa + 0] - hp["entropy_coef"] * first[Pa + 1]) / n) - scal["actor_loss"]) <= TOL * (1 + abs(scal["actor_loss"]))
+    assert abs(float(first[Pa + 8 + Pc + 4] / n) - scal["critic_loss"]) <= TOL * (1 + abs(scal["critic_loss"]))
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg2"])
+def test_full_size_other_configs_update_is_deterministic_and_finite(name):
+    """Two independent full-size iterations (value pass, scan, three epochs on whichever schedule the size selects -- config 2 runs its
+    critic epochs on the second stream) leave bit-identical parameters and finite records; the act pass over the whole episode
+    (cm_policy_act_episode_ld: config 4's one-launch sampler) only ever picks legal actions and is reproducible."""
+    from cleanmarl_amd import _native as N
+    L, b, c = _full_size_cfg(name)
+    r1 = L.train_iteration(b)
+    L2, b2, _ = _full_size_cfg(name)
+    r2 = L2.train_iteration(b2)
+    assert torch.equal(L.actor, L2.actor) and torch.equal(L.critic_params(), L2.critic_params())
+    assert all(np.isfinite(v) for r in r1 for v in r.values())
+    assert [r["actor_loss"] for r in r1] == [r["actor_loss"] for r in r2] and [r["critic_loss"] for r in r1] == [r["critic_loss"] for r in r2]
+    lib, dev, sp = N.load(), b.device, L.actor_spec
+    outs = []
+    for _ in range(2):
+        act = torch.full((b.E, b.A, b.T), -1, dtype=torch.int32, device=dev); lp = torch.zeros(b.E, b.A, b.T, device=dev)
+        w0b = lib.cm_w0_image_bytes(sp.din, sp.hidden)
+        ws = torch.empty(max(w0b, 16), dtype=torch.uint8, device=dev)
+        N.check(lib.cm_policy_act_episode_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), b.E * b.A, b.T, sp.din, sp.hidden, sp.n_layers, sp.dout,
+                                             N.ptr(L.actor), 1234, 0, N.ptr(act), N.ptr(lp), N.ptr(ws) if w0b else None, w0b, N.stream_ptr()),
+                "cm_policy_act_episode_ld")
+        outs.append((act, lp))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    legal = torch.gather(b.avail, 3, outs[0][0].long().unsqueeze(3)).squeeze(3)
+    assert bool(legal.all()) and bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].max()) <= 1e-6
+
+
 @pytest.mark.parametrize("algo,E,A,T,Do,Ds,K,H,L", [
     ("mappo", 1, 1, 1, 3, 5, 2, 8, 1),      # smallest possible batch: one env, one agent, one step
     ("ippo", 1, 2, 3, 4, 9, 1, 64, 1),      # single action (degenerate softmax), E = 1 (the reference's IPPO crashes here)

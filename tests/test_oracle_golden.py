@@ -158,7 +158,9 @@ def test_plain_c_clip_and_optimiser_step_matches_reference_golden(golden_dir, na
 
 
 def test_plain_c_clip_branch_matches_torch():
-    """The goldens never clip (their norms stay below max_norm): the clipping branch of clip_optim_step_ref against torch itself."""
+    """Six goldens DO clip (mappo_ragged_norm, mappo_wide, mappo_rmsprop, ippo_ragged_norm and both COMA cases with max_norm 0.5: critic norms
+    0.51 .. 3.56; test_plain_c_clip_and_optimiser_step_matches_reference_golden runs that branch against the reference's post-step
+    parameters).  This test adds what they cannot: the same branch for every optimiser kind over several consecutive steps, against torch itself."""
     from oracle.build_c import clip_optim_step_c
     torch.manual_seed(0)
     for kind, cls in (("Adam", torch.optim.Adam), ("AdamW", torch.optim.AdamW), ("SGD", torch.optim.SGD), ("RMSprop", torch.optim.RMSprop)):
