@@ -167,6 +167,31 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+DOMINANT_KERNEL = "k_mlp<1, 2,"  # cm_ppo_actor_fwd_bwd at config 3: one input chunk, M_ACTOR (the name rocprofv3 prints starts "... k_mlp<1, 2, ...")
+
+
+def load_pmc(path, workload="cfg3"):
+    """roofline.traffic comes from rocprofv3 --pmc passes that cannot run inside this process (profiles/pmc_dominant_kernel.json, written
+    by tools/pmc_summary.py --emit).  It is only valid for the kernels it was measured on: the record carries the hash of the library's
+    sources (cleanmarl_amd/build.py::source_hash) and the profiled kernel's name; a record taken on other sources, of another kernel or
+    for another workload is refused.  -> (record or None, reason it was refused or None)."""
+    from cleanmarl_amd.build import source_hash
+    if not os.path.exists(path):
+        return None, "no PMC record (profiles/pmc_dominant_kernel.json missing)"
+    try:
+        pmc = json.load(open(path))
+    except Exception as ex:  # noqa: BLE001
+        return None, f"unreadable PMC record: {ex!r}"[:200]
+    if pmc.get("workload") != workload:
+        return None, f"PMC record is for workload {pmc.get('workload')!r}, not {workload!r}"
+    if DOMINANT_KERNEL not in str(pmc.get("kernel", "")):
+        return None, f"PMC record is for kernel {str(pmc.get('kernel'))[:80]!r}, not the actor pass {DOMINANT_KERNEL!r}"
+    have, want = pmc.get("source_hash"), source_hash()
+    if have != want:
+        return None, f"stale PMC record: taken on sources {have}, the library being timed is built from {want} (re-run tools/refresh_profiles.sh)"
+    return pmc, None
+
+
 def _bound(work, ms):
     """Achieved rates of one launch / phase against BOTH peaks; the bound is the one that takes longer at peak."""
     if ms <= 0:
@@ -186,6 +211,52 @@ def summarize(w, r):
                 roofline_frac=(_bound(wk["actor"], r["actor_ms"]) or {}).get("frac"))
 
 
+def message_latencies(w, dev, pg, N, peer_too=True):
+    """The two messages of an optimiser step timed alone, on the stream, in microseconds: as RCCL all-reduces (+ the stand-alone
+    optimiser-step launch that follows one, for a like-for-like sum) and as the one-shot peer exchange fused with the step
+    (dist.PeerAllReduce: push + fold / step; SGD with lr = 0, so nothing moves)."""
+    from cleanmarl_amd import dist as D
+    lat = {"rccl": {}, "optimizer_step": {}, "peer_exchange_plus_step": {}}
+    lib = N.load()
+
+    def timed(fn, reps=100, warm=20):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
+
+    for nm, npar in (("actor", w.aspec.nparams), ("critic", w.cspec.nparams)):
+        n = npar + N.NUM_STATS
+        key = f"{nm}_{4 * n}B"
+        buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        buf[npar + N.STAT_COUNT] = 1.0
+        params = torch.zeros(npar, dtype=torch.float32, device=dev)
+        norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        scratch = torch.zeros(lib.cm_opt_step_scratch_bytes(), dtype=torch.uint8, device=dev)
+        step = [0]
+
+        def opt():
+            step[0] += 1
+            return N.OptStep(params=params.data_ptr(), exp_avg=0, exp_avg_sq=0, out_norm=norm.data_ptr(), scratch=scratch.data_ptr(), lr=0.0,
+                             beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_norm=-1.0, grad_scale=1.0, step=step[0], opt_kind=N.OPT_SGD)
+        lat["rccl"][key] = timed(lambda: torch.distributed.all_reduce(buf, group=pg))
+        lat["optimizer_step"][key] = timed(lambda: N.check(lib.cm_optimizer_step(N.ptr(buf), npar, opt(), N.stream_ptr()), "cm_optimizer_step"))
+        if peer_too:
+            try:
+                peer = D.PeerAllReduce(n, pg)
+                lat["peer_exchange_plus_step"][key] = timed(lambda: peer.step(buf, npar, opt(), N.stream_ptr()))
+                peer.close()
+            except Exception as ex:  # noqa: BLE001 -- e.g. a node without peer access: reported, not fatal
+                lat["peer_exchange_plus_step"][key] = repr(ex)[:200]
+    return lat
+
+
 def total_envs_of(args, world, E_glob):
     return E_glob if args.scaling == "strong" else world * E_glob
 
@@ -199,6 +270,9 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong (default, north_star): the workload's envs are sharded over the ranks; weak: every rank owns all of them")
     ap.add_argument("--envs", type=int, default=0, help="override the env count (global in strong mode, per GPU in weak mode)")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "peer"],
+                    help="exchange step of the MLP learner at N > 1: RCCL all-reduce + optimiser step (default) or the one-shot peer "
+                         "all-reduce over hipIpc mailboxes fused with the step (csrc/cm_peer.hip); the same flag on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / strong_scaling_shares / weak_scaling legs")
     ap.add_argument("--cpu-envs", type=int, default=256, help="envs in the bounded CPU-baseline sample")
@@ -241,6 +315,8 @@ def main():
     from cleanmarl_amd import _native as N
     from cleanmarl_amd import dist
 
+    # rank-invariant by construction: a command-line flag, identical on every rank (the learner reads it at construction)
+    os.environ["CM_PEER_ALLREDUCE"] = "1" if args.allreduce == "peer" else "0"
     E_glob = args.envs or WORKLOADS[args.workload][0]
     if args.scaling == "strong":
         if E_glob < world:
@@ -269,7 +345,8 @@ def main():
                       2: "bf16 (opt-in CM_MFMA=bf16: single-pass bf16 MFMA products in the training passes, fp32 accumulate and storage; looser parity tier)"}[N.load().cm_mfma_mode()],
             "data": "synthetic",
             "config": {"workload": desc, "global_envs": total_envs, "envs_per_gpu": E, "agents": A, "steps": T, "epochs": hp.epochs,
-                       "parallelism": f"env-sharded x{world} ({args.scaling} scaling), one all-reduce per network and optimiser step"},
+                       "parallelism": f"env-sharded x{world} ({args.scaling} scaling), one all-reduce per network and optimiser step",
+                       "allreduce": args.allreduce if world > 1 else "none (one rank: the optimiser step rides on the pass's reduction launch)"},
             "ppo_update_ms": r["phase_ms"]["update"], "ppo_update_ms_per_epoch": r["phase_ms"]["update"] / hp.epochs,
             "phase_ms": r["phase_ms"],
             "kernel_ms": {"actor_fwd_bwd": r["actor_ms"], "critic_fwd_bwd": r["critic_ms"]},
@@ -287,13 +364,15 @@ def main():
         }
         # HBM bytes of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read
         # live here); tools/pmc_summary.py writes them to profiles/pmc_dominant_kernel.json
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
-        if os.path.exists(pmc_path) and args.workload == "cfg3" and not args.envs and world == 1:
-            pmc = json.load(open(pmc_path))
-            out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = pmc["source"]
-            out["roofline"]["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
-            out["roofline"]["algorithmic_bytes_per_launch"] = wk["actor"]["bytes"]
+        out["roofline"]["algorithmic_bytes_per_launch"] = wk["actor"]["bytes"]
+        if args.workload == "cfg3" and not args.envs and world == 1:
+            pmc, why = load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
+            if pmc is not None:
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = pmc["source"]
+                out["roofline"]["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
+            else:
+                out["roofline"]["traffic_refused"] = why  # traffic stays null: never a number measured on other kernels
     w.close()
 
     weak_leg = None
@@ -303,22 +382,35 @@ def main():
         # that leg does on a node this code has not seen yet (new buffers, 8 x the envs) can cost the headline record
         lat = {}
         try:
-            for nm, n in (("actor", w.aspec.nparams + N.NUM_STATS), ("critic", w.cspec.nparams + N.NUM_STATS)):
-                buf = torch.zeros(n, dtype=torch.float32, device=dev)
-                for _ in range(20):
-                    torch.distributed.all_reduce(buf, group=pg)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(100):
-                    torch.distributed.all_reduce(buf, group=pg)
-                e1.record()
-                torch.cuda.synchronize()
-                lat[f"{nm}_{4 * n}B"] = 1e3 * e0.elapsed_time(e1) / 100
+            lat = message_latencies(w, dev, pg, N, peer_too=False)
         except Exception as ex:  # noqa: BLE001 -- reported in the line, never instead of it
             lat = {"error": repr(ex)[:300]}
         if rank == 0:
             out["allreduce_us"] = lat
+        # The peer exchange has never crossed xGMI before the first multi-GPU run of this file.  It is measured under a watchdog: if it
+        # has not finished within 90 s, rank 0 prints the headline line as it stands (marked) and every rank exits -- a stuck exchange
+        # can cost its own numbers only.  (The step kernel's wait for the peers' tags is itself bounded: csrc/cm_optim.hip.)
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["allreduce_us"]["peer_exchange_plus_step"] = "watchdog: not finished within 90 s"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(90.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            lat["peer_exchange_plus_step"] = message_latencies(w, dev, pg, N, peer_too=True)["peer_exchange_plus_step"]
+        except Exception as ex:  # noqa: BLE001
+            lat["peer_exchange_plus_step"] = repr(ex)[:300]
+        dog.cancel()
+        if rank == 0:
+            # what the exchange costs INSIDE the iteration: time on the launch stream per epoch that is not the actor's pass (its
+            # all-reduce / peer exchange + the optimiser step + launch gaps; the critic's messages travel on the critic's stream)
+            ep = max(1, hp.epochs)
+            out["comm_exposure_us"] = {"actor_stream_per_epoch_outside_the_pass": 1e3 * (r["phase_ms"]["update_actor_stream"] / ep - r["actor_ms"]),
+                                       "note": "update_actor_stream / epochs - actor_fwd_bwd (HIP events of the instrumented steps)"}
             print(json.dumps(out), flush=True)
         other = "weak" if args.scaling == "strong" else "strong"
         if other == "weak":

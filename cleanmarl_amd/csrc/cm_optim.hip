@@ -146,10 +146,24 @@ template <bool UPDATE, bool PEER = false>
 __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const StepArgs a) {
     __shared__ float sh[STEP_GROUPS][STEP_COLS];
     const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;  // g: wave of the workgroup
+    bool peer_lost = false;
     if (PEER) {  // the partial rows are mailbox slots: wait until every rank has published this step's (cm_peer.hip)
-        if (threadIdx.x < a.np1)
-            while (__hip_atomic_load(a.peer_tags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)a.peer_seq)
+        // BOUNDED: a peer that never publishes (a mapping that silently does not reach this GPU, a dead rank) must not leave a kernel
+        // spinning for ever on a box nobody can reset -- after 2^23 polls (seconds; ranks of a healthy run are microseconds apart) the
+        // launch gives up and poisons the step with NaN (parameters, moments, logged norm: loud, never silent)
+        bool lost = false;
+        if (threadIdx.x < a.np1) {
+            unsigned polls = 0;
+            while (__hip_atomic_load(a.peer_tags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)a.peer_seq) {
                 __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 23)) { lost = true; break; }
+            }
+        }
+        peer_lost = __syncthreads_or(lost ? 1 : 0) != 0;
+        // acquire at system scope, pairing with the pusher's release store of the tag (cm_peer.hip): the slot loads below are relaxed
+        // system-scope loads and must not be satisfied from anything older than the tag that certified them.  One fence per
+        // workgroup of the OPT-IN peer path only; the default launches (PEER = false) contain no fence (§3.4 of DESIGN.md: why)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         __syncthreads();
     }
     const int icnt = a.n + CM_STAT_COUNT, slab_n = icnt / STEP_COLS;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
         if (c == 0) N = step_wait(a.nword, a.tag);
         N = __shfl(N, 0, 64);
     }
-    const float scale = (N > 0.0f) ? a.grad_scale / N : 0.0f;
+    const float scale = (PEER && peer_lost) ? __builtin_nanf("") : ((N > 0.0f) ? a.grad_scale / N : 0.0f);
     const float step_size = a.lr / a.bc1;
     float ss = 0.f;
     if (i < a.n) {

@@ -449,6 +449,8 @@ def run(script, argv=None):
         venv.close()
     if the_env is not None:
         the_env.close()
+    if hasattr(learner, "close"):
+        learner.close()
     if world > 1 or force:
         torch.distributed.destroy_process_group()
     return dict(step=step, training_step=training_step, history=writer.history if writer else [], learner=learner)

@@ -38,6 +38,18 @@ class GRUPPOLearner(PPOLearner):
         # (tools/gpu/r03_gru_critic.sh, two runs each): beside 7.33 / 7.34 ms, defer1 7.20 / 7.23, defer2 7.23 / 7.26 (the value pass starts
         # to wait), defer3 7.30.  CM_GRU_CRITIC is a Python-side A/B hook, not an option of the C-ABI.
         self.critic_schedule = os.environ.get("CM_GRU_CRITIC", "defer1")
+        self._parse_schedule(self.critic_schedule)  # a typo fails here, not in the middle of an update
+        self._sched_fixed = None
+        self._grecs, self._grec_i = None, 0
+
+    @staticmethod
+    def _parse_schedule(sched):
+        """-> (stream kind, number of deferred epochs or None for "all"); raises on anything but beside | low | defer | defer<N>."""
+        if sched in ("beside", "low"):
+            return sched, 0
+        if sched.startswith("defer") and (sched[5:] == "" or sched[5:].isdigit()):
+            return "low", (int(sched[5:]) if sched[5:] else None)
+        raise N.NativeError(f"critic_schedule / CM_GRU_CRITIC = {sched!r}: expected beside, low, defer or defer<N>")
 
     def _ensure(self, b):
         a = self.actor_spec
@@ -55,10 +67,18 @@ class GRUPPOLearner(PPOLearner):
         T, tb = b.T, int(hp.tbptt)
         chunks = [(t0, min(t0 + tb, T)) for t0 in range(0, T, tb)]
         nE = int(hp.epochs)
-        rec_a = torch.zeros(nE, len(chunks), N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
+        # statistics of this update: two persistent buffer pairs used alternately (like PPOLearner._recs).  With deferred critic epochs
+        # the un-joined critic stream still writes rec_c and copies both to the host after update() has returned: buffers allocated per
+        # update on the launch stream would go back to its allocator pool with that work pending.  Every field is rewritten by
+        # each update (all epochs, all chunks), and the pair used two updates ago has been read: its copy precedes the previous update's
+        # critic epochs on the critic stream, which this update's wait_critic() below joins before anything is enqueued.
+        if self._grecs is None or self._grecs[0][0].shape[:2] != (nE, len(chunks)):
+            self._grecs = [(torch.zeros(nE, len(chunks), N.NUM_STATS + 1, dtype=torch.float32, device=self.device),
+                            torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)) for _ in range(2)]
+        self._grec_i ^= 1
+        rec_a, rec_c = self._grecs[self._grec_i]
         if self.g_rows is None or self.g_rows.shape[0] < len(chunks):
             self.g_rows = torch.zeros(len(chunks), Pa + N.NUM_STATS, dtype=torch.float32, device=self.device)
-        rec_c = torch.zeros(nE, N.NUM_STATS + 1, dtype=torch.float32, device=self.device)
         kept, kept_c = [], []
         # The critic's epoch (one pass + one step, independent of the actor: it reads returns and states only, own workspace, own
         # gradient buffer) is enqueued on a second stream: at the start of an actor epoch, or -- the last `n_defer` of them -- behind the
@@ -66,10 +86,13 @@ class GRUPPOLearner(PPOLearner):
         # kernels is never extended by them.  Issue order is identical on all ranks, so the collectives still pair up.
         ride = self.fused_step and not self._coll
         main = torch.cuda.current_stream()
-        sched = self.critic_schedule
+        kind, defer = self._parse_schedule(self.critic_schedule)
         if self._critic_stream is None:
-            # one per process: see _native.low_priority_stream
-            self._critic_stream = N.side_stream(self.device) if sched == "beside" else N.low_priority_stream(self.device)
+            # one per process: see _native.low_priority_stream.  The stream kind is fixed by the first update
+            self._critic_stream = N.side_stream(self.device) if kind == "beside" else N.low_priority_stream(self.device)
+            self._sched_fixed = kind
+        elif kind != self._sched_fixed:
+            raise N.NativeError(f"critic_schedule changed from a {self._sched_fixed!r} to a {kind!r} stream after the first update")
         side = self._critic_stream
         self.wait_critic()
         self._critic_done = None
@@ -89,7 +112,7 @@ class GRUPPOLearner(PPOLearner):
                 if keep_grads:
                     kept_c.append((self.g_critic[:Pc].clone(), self.critic.clone()))
 
-        n_defer = 0 if not sched.startswith("defer") else min(nE, int(sched[5:] or nE))
+        n_defer = min(nE, nE if defer is None else defer)
         for ep in range(nE):
             if ep < nE - n_defer:
                 critic_epoch(ep)

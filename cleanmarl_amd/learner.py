@@ -630,6 +630,15 @@ class PPOLearner:
         self.compute_targets(b)
         return self.update(b, keep_grads=keep_grads)
 
+    def close(self):
+        """Release what outlives a learner otherwise: the hipIpc mappings / mailboxes of the opt-in peer all-reduce (dist.PeerAllReduce)."""
+        for name in ("peer_a", "peer_c"):
+            peer = getattr(self, name, None)
+            if peer is not None:
+                torch.cuda.synchronize(self.device)  # no step launch may still be reading a mailbox
+                peer.close()
+                setattr(self, name, None)
+
     # ------------------------------------------------------------------ checkpointing (SURVEY.md §8f-2; README TODO of the reference)
     def state_dict(self):
         """Flat parameters + Adam moments + step counters (CPU tensors; torch.save-able)."""

@@ -322,3 +322,31 @@ def test_cli_defaults_are_the_reference_args_as_the_goldens_recorded_them(name, 
     assert checked >= 20, checked
     for f in forced - {"env_type"}:
         assert hasattr(a, f)
+
+
+# ------------------------------------------------------------------------------------------ roofline.traffic is stamped, never stale
+def test_bench_refuses_a_pmc_record_taken_on_other_sources(tmp_path):
+    """bench.py's roofline.traffic is read from a committed PMC record (the counters cannot be collected inside the timed process): the
+    record must carry the hash of the sources of the library being timed and name the actor pass; anything else leaves traffic null."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from cleanmarl_amd.build import source_hash
+    good = dict(kernel="void (anonymous namespace)::k_mlp<1, 2, 1, 1, 2, false, true>((anonymous namespace)::MlpArgs)",
+                hbm_bytes_per_launch=1.03e9, mfma_busy_frac=0.66, source="x", workload="cfg3", source_hash=source_hash())
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps(good))
+    rec, why = bench.load_pmc(str(p))
+    assert why is None and rec["hbm_bytes_per_launch"] == 1.03e9
+    for patch, word in ((dict(source_hash="0123456789abcdef"), "stale"), (dict(source_hash=None), "stale"),
+                        (dict(kernel="k_critic_fused<6>"), "kernel"), (dict(workload="cfg4"), "workload")):
+        p.write_text(json.dumps(dict(good, **patch)))
+        rec, why = bench.load_pmc(str(p))
+        assert rec is None and word in why, (patch, why)
+    p.write_text("{not json")
+    assert bench.load_pmc(str(p))[0] is None
+    assert bench.load_pmc(str(tmp_path / "missing.json"))[0] is None
+    # the committed record is either current or refused -- never silently used for other kernels
+    rec, why = bench.load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
+    assert (rec is None) != (why is None)

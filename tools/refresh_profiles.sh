@@ -16,7 +16,7 @@ mkdir -p $O/pmc
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc/pmc_mfma -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
-python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
+python $R/tools/pmc_summary.py $O/pmc --emit $O/pmc_dominant_kernel.json "profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" > $O/pmc_summary.txt 2>&1
 find $O/pmc -name "*.csv" -size +2M -delete
 # ---- per-kernel durations of the per-GPU share (512 envs) and of the other BASELINE configs
 for w in "cfg3 --envs 512" "cfg2" "cfg4" "cfg5"; do
