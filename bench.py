@@ -365,6 +365,15 @@ def main():
         # HBM bytes of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read
         # live here); tools/pmc_summary.py writes them to profiles/pmc_dominant_kernel.json
         out["roofline"]["algorithmic_bytes_per_launch"] = wk["actor"]["bytes"]
+        if w.actor_kind == "mlp":
+            # what the kernel ISSUES on the matrix pipe (tile padding included: Do -> 64-column chunks in dW0, K -> 16 head rows ...) beside the
+            # algorithmic flop the fraction above is quoted on: issued / algorithmic is the padding, issued_frac the pipe's share of nominal peak
+            per_row = N.load().cm_ppo_actor_issued_flop_per_row(w.aspec.din, w.aspec.hidden, w.aspec.n_layers, w.aspec.dout)
+            if per_row > 0 and r["actor_ms"] > 0:
+                issued = per_row * wk["rows_a"]
+                out["roofline"]["issued_flop_per_launch"] = issued
+                out["roofline"]["issued_over_algorithmic"] = issued / wk["actor"]["flop"]
+                out["roofline"]["issued_frac"] = issued / (r["actor_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
         if args.workload == "cfg3" and not args.envs and world == 1:
             pmc, why = load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
             if pmc is not None:

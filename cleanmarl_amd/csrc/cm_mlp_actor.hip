@@ -88,3 +88,26 @@ extern "C" int cm_ppo_actor_fwd_bwd(const float* obs, const uint8_t* avail, cons
     return cm_ppo_actor_fwd_bwd_ld(obs, din, avail, action, logp_old, adv, ep_len, E, A, T, din, hidden, n_hidden_layers, n_actions, params, ppo_clip,
                                    entropy_coef, grad_and_stats, ws, ws_bytes, stream);
 }
+
+/* MFMA work the fused actor pass ISSUES per row (flop), padding included -- next to the algorithmic 2 P_a + 2 P_a + 2 (P_a - Do H) of
+ * SURVEY.md 8(d) that bench.py's roofline is quoted on.  Counted from the tile schedule of k_mlp<NCH, M_ACTOR> (cm_mlp_kernel.h), per
+ * 64-row tile and wave, 4 waves per tile: forward layer 0 ceil(w / 8) k-steps x 4 v_mfma_f32_32x32x2 per 64-column chunk of width w,
+ * 32 per hidden layer; logits and dWout on v_mfma_f32_16x16x4, 16 each per 16 padded head rows (K <= 8 -> 16 rows, else 32); dZ_L
+ * 4 x 32x32x2 per 8 padded head columns (K <= 8 -> 8, else 32); per hidden layer 32 (weight gradient) + 32 (data path); layer-0 weight
+ * gradient 32 per 64-column chunk (the chunk's padding columns included).  32x32x2 = 4096 flop, 16x16x4 = 2048 flop.  0 for shapes that
+ * run on the layered schedule. */
+extern "C" double cm_ppo_actor_issued_flop_per_row(int din, int hidden, int n_hidden_layers, int n_actions) {
+    if (wide_shape(hidden, n_hidden_layers, n_actions) || hidden > HP || n_hidden_layers > LMAX || n_actions > KMAX || din <= 0) return 0.0;
+    const int nch = (din + KC - 1) / KC;
+    const int KP = n_actions <= 8 ? 8 : KMAX, WR = n_actions <= 8 ? 16 : KMAX;
+    long m32 = 0, m16 = 0;
+    for (int c = 0; c < nch; ++c) {
+        const int w = (din - c * KC) < KC ? (din - c * KC) : KC;
+        m32 += 4 * ((w + 7) >> 3);   // forward layer 0, chunk c
+        m32 += 32;                   // dW0, chunk c
+    }
+    m32 += (long)n_hidden_layers * (32 + 32 + 32);  // forward, weight gradient, data path of every hidden layer
+    m16 += 2 * 16 * (WR / 16);       // logits + dWout
+    m32 += 4 * (KP / 8);             // dZ_L
+    return (double)(4 * (m32 * 4096 + m16 * 2048)) / (double)TM;
+}

@@ -37,6 +37,7 @@ namespace {
 
 constexpr float DAMP = 0.25f, DT = 0.1f, ACCEL = 5.0f, COLLIDE = 0.3f;
 
+constexpr int SPREAD_K = 5;  // actions of the synthetic spread env (cm_env.hip: no-op + four accelerations); the launcher sets a.K to it
 struct RolloutArgs {
     float* env_state;  // [E][6A]: pos(2A) vel(2A) landmarks(2A) -- written at the end (state after step T-1)
     int E, A, T, agent_ids;
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_spread(const RolloutArgs a
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
-    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    constexpr int K = SPREAD_K;  // compile-time: the samplers' k < 8 loops then evaluate 5 exponentials, not 8 selected ones
+    const int A = a.A, T = a.T, H = a.H, L = a.L, din = a.din;
     const int EPT = TM / A, RT = EPT * A;  // envs / valid rows per tile
     const int Ds = 6 * A * A;
     // LDS carve
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void k_rollout_spread16(const RolloutA
     const Offsets off = make_offsets(a.din, a.H, a.L, a.K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, g16 = lane >> 4;
-    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    constexpr int K = SPREAD_K;  // compile-time: the samplers' k < 8 loops then evaluate 5 exponentials, not 8 selected ones
+    const int A = a.A, T = a.T, H = a.H, L = a.L, din = a.din;
     const int EPT = TS / A, RT = EPT * A;  // envs / valid rows per tile
     const int Ds = 6 * A * A;
     float* Xs = smem;                     // [TS][LDT] obs tile; aliased by H1 once layer 0 has consumed it
@@ -790,7 +793,8 @@ __global__ __launch_bounds__(NT_SW, 2) void k_rollout_spread16s(const RolloutArg
     const bool writer = wave == 4, scorer = wave == 5;
     if (wave < 4) ROLLOUT_WAVE_PRIO();  // the chain only: writer and scorer have slack and leave their issue slots to co-resident kernels
     const int n16 = lane & 15, g16 = lane >> 4;
-    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    constexpr int K = SPREAD_K;  // compile-time: the samplers' k < 8 loops then evaluate 5 exponentials, not 8 selected ones
+    const int A = a.A, T = a.T, H = a.H, L = a.L, din = a.din;
     const int EPT = TS / A, RT = EPT * A;  // envs / valid rows per tile
     float* Xs = smem;                     // [TS][LDT] obs tile; aliased by H1 once layer 0 has consumed it
     float* H0 = Xs + TS * LDT;            // [TS][LDT]
@@ -1106,7 +1110,8 @@ __global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArg
     const bool writer = wave == 4, scorer = wave == 5;
     if (wave < 4) ROLLOUT_WAVE_PRIO();
     const int wm = (wave >> 1) & 1, wn = wave & 1, h = lane >> 5, lc = lane & 31;
-    const int A = a.A, T = a.T, K = a.K, H = a.H, L = a.L, din = a.din;
+    constexpr int K = SPREAD_K;  // compile-time: the samplers' k < 8 loops then evaluate 5 exponentials, not 8 selected ones
+    const int A = a.A, T = a.T, H = a.H, L = a.L, din = a.din;
     const int EPT = TM / A, RT = EPT * A;  // envs / valid rows per tile
     // LDS carve (two workgroups per CU: 2 x 81.7 KB)
     float* Xs = smem;                    // obs tile; aliased by H1 once layer 0 has consumed it
@@ -1454,7 +1459,7 @@ static int rollout_spread(float* env_state, int E, int A, int T, int agent_ids, 
     RolloutArgs a = {};
     a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed; a.act_eps = eps;
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0);
-    a.H = hidden; a.L = n_hidden_layers; a.K = 5;
+    a.H = hidden; a.L = n_hidden_layers; a.K = SPREAD_K;
     a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
     a.obs_ld = obs_ld ? obs_ld : a.din; a.state_ld = state_ld ? state_ld : 6 * A * A;
     CM_REQUIRE(a.obs_ld >= a.din && a.state_ld >= 6 * A * A, "cm_rollout_spread: leading dimensions %ld / %ld below the widths %d / %d", a.obs_ld, a.state_ld, a.din, 6 * A * A);

@@ -177,12 +177,23 @@ def test_bench_two_rank_launch_on_one_gpu():
     assert out["roofline"]["frac"] > 0
     # extras at N > 1: the two all-reduce messages timed alone (in the line, which is printed BEFORE the next leg so that leg can never
     # cost the headline record) and a short weak-scaling run (96 envs on EVERY rank) reported on stderr, tagged
-    assert len(out["allreduce_us"]) == 2 and all(v > 0 for v in out["allreduce_us"].values())
+    # both exchanges of an optimiser step timed alone: RCCL(here: gloo) all-reduce and the stand-alone step launch behind it, and the one-shot
+    # peer exchange fused with the step (hipIpc mailboxes between the two processes on this one GPU), per message; + the exposure in the iteration
+    lat = out["allreduce_us"]
+    assert set(lat) == {"rccl", "optimizer_step", "peer_exchange_plus_step"}, lat
+    for kind in lat.values():
+        assert len(kind) == 2 and all(isinstance(v, float) and v > 0 for v in kind.values()), lat
+    assert out["config"]["allreduce"] == "rccl" and "actor_stream_per_epoch_outside_the_pass" in out["comm_exposure_us"]
     assert "weak_scaling" not in out
     legs = [json.loads(ln.split("[bench extra leg] ", 1)[1]) for ln in p.stderr.splitlines() if "[bench extra leg] " in ln]
     assert len(legs) == 1 and legs[0]["leg"] == "weak_scaling" and legs[0]["n_gpus"] == 2
     wk = legs[0]
     assert wk["global_envs"] == 192 and abs(wk["value"] - 192 * 3 * 128 / (wk["ms_per_step"] * 1e-3)) < 1e-6 * wk["value"]
+    # the same run with the peer exchange selected (rank-invariant flag): same work, same record shape
+    p = subprocess.run(cmd + ["--allreduce", "peer", "--no-extras"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_p = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out_p["config"]["allreduce"] == "peer" and out_p["value"] > 0 and out_p["config"]["global_envs"] == 96
     cmd[cmd.index("--envs") + 1:cmd.index("--envs") + 2] = ["96", "--scaling", "weak", "--no-extras"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
