@@ -26,10 +26,11 @@ const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRoll
 const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};
 const char* const kWideN[] = {"auto", "fused", "layered"};       const int kWideV[] = {0, 1, 2};
 const char* const kDw0N[] = {"auto", "8", "4"};                  const int kDw0V[] = {0, 8, 4};
+const char* const kGridN[] = {"auto", "512", "384", "256", "192", "128", "64"}; const int kGridV[] = {0, 512, 384, 256, 192, 128, 64};
 const OptDef kOpts[CM_OPTION_COUNT] = {
     {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 3}, {"gru_tile", kGruN, kGruV, 4},
     {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}, {"wide_schedule", kWideN, kWideV, 3},
-    {"dw0_batch", kDw0N, kDw0V, 3}};
+    {"dw0_batch", kDw0N, kDw0V, 3}, {"dw0_grid", kGridN, kGridV, 7}, {"train_grid", kGridN, kGridV, 7}};
 std::atomic<int> g_opt[CM_OPTION_COUNT];  // zero-initialised: every option starts at its first value
 }  // namespace
 

@@ -18,7 +18,7 @@ void cm_set_error(const char* fmt, ...);
 #define CM_REQUIRE(cond, ...) do { if (!(cond)) CM_FAIL(-1, __VA_ARGS__); } while (0)
 
 // options set through cm_set_option (cm_api.hip); values are the ints listed there (0 = the default / "auto")
-enum { CM_OPTION_MLP_FORMS = 0, CM_OPTION_CRITIC_SCHEDULE, CM_OPTION_GRU_TILE, CM_OPTION_ROLLOUT_TILE, CM_OPTION_MFMA, CM_OPTION_WIDE_SCHEDULE, CM_OPTION_DW0_BATCH, CM_OPTION_COUNT };
+enum { CM_OPTION_MLP_FORMS = 0, CM_OPTION_CRITIC_SCHEDULE, CM_OPTION_GRU_TILE, CM_OPTION_ROLLOUT_TILE, CM_OPTION_MFMA, CM_OPTION_WIDE_SCHEDULE, CM_OPTION_DW0_BATCH, CM_OPTION_DW0_GRID, CM_OPTION_TRAIN_GRID, CM_OPTION_COUNT };
 int cm_option(int which);
 
 // fold per-workgroup partial gradient rows and apply the optimiser step in one launch (cm_optim.hip); part2 / isplit: a second partial

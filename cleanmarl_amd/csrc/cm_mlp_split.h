@@ -96,7 +96,9 @@ inline bool use_split(int din) { return (din + KC - 1) / KC > CM_WG2_MAX_NCH; }
 template <bool GEN = false>
 inline int stream_dw(const float* dz0, const float* x, long rows, int din, int H, float* part2, float* out, hipStream_t s, const char* who,
                      int ldz = HP, long ldx = 0, int* grid2_out = nullptr) {
-    long rpw = (rows + DW0_GRID - 1) / DW0_GRID;
+    const int gopt = cm_option(CM_OPTION_DW0_GRID);  // A/B: workgroups of the streaming kernel (each writes an H x din partial row)
+    const int gmax = gopt ? gopt : DW0_GRID;
+    long rpw = (rows + gmax - 1) / gmax;
     rpw = (rpw + 2 * RB - 1) / (2 * RB) * (2 * RB);
     const int grid2 = (int)((rows + rpw - 1) / rpw);
     const int PS2 = H * din;
@@ -153,7 +155,8 @@ inline int run_train(MlpArgs a, float* grad_and_stats, void* ws, size_t ws_bytes
     float* own = (float*)ws + (size_t)MAX_GRID * a.PS + w0_image_floats(a.din, a.H);
     if (!a.dz0) a.dz0 = own;  // the caller may want dZ0 for its own use (COMA's factored critic input)
     float* part2 = own + (size_t)a.rows * HP;
-    const int grid = grid_for(a.rows, 0);
+    int grid = grid_for(a.rows, 0);
+    if (const int gopt = cm_option(CM_OPTION_TRAIN_GRID)) grid = grid < gopt ? grid : gopt;  // A/B: persistent workgroups of the split schedule's fused kernel
     launch_variant<0, MODE>(a, grid, lds_bytes, s);
     CM_CHECK_LAUNCH(who);
     if (opt) {  // both partial sets folded by the optimiser-step launch
