@@ -39,6 +39,9 @@ constexpr int NTHREADS = 256;
 #define CM_WG2_MAX_NCH 2
 #endif
 constexpr int wgs_per_cu(int nch) { return nch <= CM_WG2_MAX_NCH ? 2 : 1; }
+#ifndef CM_HEAD_WP
+#define CM_HEAD_WP 1  // wave-private head backward (head_bwd_wave); 0 = the workgroup-wide products of rounds 1 - 3, kept for A/B builds
+#endif
 
 // COMA (cleanmarl/coma_multienvs.py): M_QCRITIC = MSE on the Q of the TAKEN action of a K-output critic (:620-631),
 // M_COMA_ACTOR = counterfactual policy gradient -log(pi_a + 1e-8) * adv - c * mean_k entropy (:649-676)
@@ -507,6 +510,50 @@ __device__ __forceinline__ void colred_head16(f32x4& acc, const float* ls, int k
     }
 }
 
+// ---- wave-private head backward (CM_HEAD_WP, round 4).  The head's three backward products used to span the workgroup: dWout contracted
+// over all 64 rows of the tile per wave (16 hidden columns each) and dZ_L was a 32 x 32 tile per wave, so the dlogits of every wave had to be
+// published behind a workgroup barrier, and the in-place relu' write of dZ_L waited behind a second one (other waves still read H_L for
+// dWout).  Here every wave finishes ITS 16 rows alone: dWout_w[k][all 64 c] over its own rows (four 16-column tiles: 16 accumulator
+// registers per 16 head rows instead of 4, summed over the waves once per launch), dZ_L for its own rows on the 16x16x4 MFMA (result lane
+// (c, g) = rows 4g .. 4g+3: written in place at once -- nobody else reads these rows before the barrier that precedes the hidden layers'
+// backward), the head bias gradient from the lanes' own registers.  Two of the tile's eleven workgroup barriers go, and the waves of a
+// CU drift apart through the head (one wave's products under another's softmax).  Same MFMA count (16 + 8 x KP / 8 16x16x4 per wave).
+template <int KP, int NQ, bool BF = false>
+__device__ __forceinline__ void head_bwd_wave(f32x4 (&accWo)[NQ][4], const float* lsw /* ls + 16 * wave * KP */, float* HLw /* H_L + 16 * wave * LDT */,
+                                              const float* wouts) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    // ---- dWout_w[16 q + k][16 ct + c] += sum over the wave's 16 rows of dlogits[row][16 q + k] * H_L[row][16 ct + c]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        float hv[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) hv[ct] = dec<BF>(HLw[(4 * kk + g) * LDT + 16 * ct + n]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float av = (16 * q + n < KP) ? lsw[(4 * kk + g) * KP + 16 * q + n] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) accWo[q][ct] = mfma16(av, hv[ct], accWo[q][ct]);
+        }
+    }
+    // ---- dZ_L[row][c] = sum_k dlogits[row][k] * Wout[k][c] for the wave's rows, then .* relu'(H_L) in place
+    f32x4 dz[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dz[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KP / 4; ++j) {
+        const float av = lsw[n * KP + 4 * j + g];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) dz[ct] = mfma16(av, wouts[(4 * j + g) * WLD + 16 * ct + n], dz[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* p = HLw + (4 * g + r) * LDT + 16 * ct + n;
+            *p = enc<BF>((dec<BF>(*p) > 0.0f) ? dz[ct][r] : 0.0f);
+        }
+}
+
 // acc[32 rows x 32 cols] = dlogits[32 rows][KP] * Wout[KP][32 cols]   (backward through the head, K = KP)
 template <int KP>
 __device__ __forceinline__ void head_bwd_mfma(f32x16& acc, const float* ls_r0, const float* wts_c0) {
@@ -698,7 +745,13 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // ---- persistent accumulators (training)
     f32x16 accW0[NC];
     f32x16 accWl[LCAP];
-    f32x4 accWo[WR / 16];  // dWout[k (16 per tile) x 16 hidden cols]: wave w owns hidden columns 16w..16w+15
+    // wave-private head backward where its 12 extra accumulator registers fit (K <= 8 heads, one input chunk or the split schedule, <= 1
+    // hidden->hidden layer: 208 -> 219 registers for the actor pass of config 3); K > 8 heads (+ 24 .. 32 registers) and two-chunk / deep
+    // instantiations sit at the 256-register limit of two workgroups per CU and would spill (config 4's actor: 4 -> 64 spilled registers)
+    constexpr bool WP = (CM_HEAD_WP != 0) && KJ == 2 && NCH <= 1 && LCAP == 1;
+    f32x4 accWoW[WP ? WR / 16 : 1][4];  // WP: dWout partial of THIS wave's rows, [k (16 per q)][16 hidden cols per ct]; summed over the waves at the end
+    float dboW[KJ];                     // WP: head bias gradient from this lane's dlogits (k = 4 j + hq), summed over lanes and waves at the end
+    f32x4 accWo[WR / 16];  // !WP: dWout[k (16 per tile) x 16 hidden cols]: wave w owns hidden columns 16w..16w+15
     float dbo = 0.0f;
     float dbh[LCAP + 1];
     float st_pg = 0.f, st_ent = 0.f, st_kl = 0.f, st_clip = 0.f, st_vl = 0.f, st_cnt = 0.f;
@@ -711,6 +764,12 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         for (int l = 0; l < LCAP; ++l)
 #pragma unroll
             for (int g = 0; g < 16; ++g) accWl[l][g] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < (WP ? WR / 16 : 1); ++q)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) accWoW[q][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) dboW[j] = 0.0f;
 #pragma unroll
         for (int q = 0; q < WR / 16; ++q) accWo[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1077,6 +1136,19 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 }
                 ls[hrow * lstride] = d;
             }
+            if constexpr (WP) {
+            // head bias gradient from the dlogits this lane just wrote (k = 4 j + hq; M_CRITIC: only lane hq == 0 wrote, slot 0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < KJ; ++j)
+                if (4 * j + hq < dout) dboW[j] += ls[hrow * lstride + 4 * j + hq];
+            PH(4);
+            // dWout, dZ_L and the in-place relu' write for this wave's 16 rows (same-wave LDS hand-off: DS ops of a wave execute in order)
+            head_bwd_wave<KP, (WP ? WR / 16 : 1), BF>(accWoW, ls + 16 * wave * KP, HL + 16 * wave * LDT, wouts);
+            PH(5);
+            __syncthreads();
+            PH(6);
+            } else {
             __syncthreads();
             PH(4);
             // ---- dWout, dbout (contraction over the tile's rows; reads HL before it is overwritten)
@@ -1106,6 +1178,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
             __syncthreads();
             PH(6);
+            }
             // ================= backward through hidden layers =================
 #pragma unroll
             for (int l = LCAP; l >= 1; --l) {
@@ -1212,6 +1285,34 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 }
             }
         }
+        if constexpr (WP) {   // dWout: every wave holds a [WR x 64] partial over ITS rows -- lane (n, g): k = 16q + 4g + r, column 16ct + n; summed over the
+            // four waves in wave order through LDS (the tile buffers are dead), one 16-row block of k at a time
+            const int n = lane & 15, g4 = lane >> 4;
+            float* wsum = smem + lds.Xs;  // [4 waves][16 k][64 c] = 16 KB of the (dead) X | W0 tile buffers
+#pragma unroll
+            for (int q = 0; q < WR / 16; ++q) {
+                __syncthreads();
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wsum[(wave * 16 + 4 * g4 + r) * HP + 16 * ct + n] = accWoW[q][ct][r];
+                __syncthreads();
+                for (int i = tid; i < 16 * HP; i += NTHREADS) {
+                    const int k = 16 * q + i / HP, c = i % HP;
+                    if (k < dout && c < H) out[off.Wout + k * H + c] = ((wsum[i] + wsum[16 * HP + i]) + wsum[2 * 16 * HP + i]) + wsum[3 * 16 * HP + i];
+                }
+            }
+            // dbout: lanes with the same hq over the wave's 16 rows (xor 4 .. 32), then the four waves
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                float v = dboW[j];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane < 4) red[wave * KMAX + 4 * j + lane] = v;
+            }
+            __syncthreads();
+            if (tid < dout) out[off.bout + tid] = ((red[tid] + red[KMAX + tid]) + red[2 * KMAX + tid]) + red[3 * KMAX + tid];
+        } else
         {   // dWout: lane (n = lane & 15, g = lane >> 4) of wave w holds k = 16q + 4g + r (r = 0..3), column 16w + n
             const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
