@@ -785,6 +785,16 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     Tile16 px, pw;
     Tile16 pn;  // NCH == 1 training kernels: the NEXT tile's X, requested mid-tile (px is busy holding this tile's X for dW0)
     constexpr bool EARLY_NEXT = TRAIN && NCH == 1;
+#ifndef CM_XMERGE
+#define CM_XMERGE 1
+#endif
+    constexpr bool XMERGE = EARLY_NEXT && (CM_XMERGE != 0);  // X re-staged for dW0 under the last in-place phase (see there)
+#ifndef CM_XKEEP
+#define CM_XKEEP 1
+#endif
+    // single-chunk training kernels used to RE-LOAD the tile they had just stored to LDS into the same prefetch registers (an L2 hit, 1 GB per
+    // launch at config 3) to have it back for the layer-0 weight gradient; tile_store does not consume the registers, so they simply keep it
+    constexpr bool XKEEP = EARLY_NEXT && (CM_XKEEP != 0);
     float w0ra[W0REG ? 32 : 1], w0rb[W0REG ? 32 : 1];  // W0REG: this wave's 32 output columns of W0, both input chunks, for the whole launch
     if constexpr (W0REG) {
         w0_regs_load(w0ra, a.params + off.W0, 32 * wn, H, din, 0, din);
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 if (W0REG) {  // chunk c of the NEXT tile into the buffer that was just emptied
                     if (c == 0) tile_load<(VEC != 0)>(px, a.x, next_row0, a.rows, a.x_stride, 0, KC);
                     else tile_load<(VEC != 0)>(pw, a.x, next_row0, a.rows, a.x_stride, KC, din - KC);
-                } else
+                } else if (!(XKEEP && L >= 1))  // XKEEP: px already holds this tile and keeps it until the layer-0 weight gradient re-stages it
                 tile_load<(VEC != 0)>(px, a.x, r0n, a.rows, a.x_stride, cn * KC, wn_);
                 if (!w0_resident && !W0REG && !(last && TRAIN && NCH > 0)) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, cn * KC, wn_);
             }
@@ -1210,6 +1220,13 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                         float* p = Hm + row * LDT + 32 * wn + lc;
                         *p = enc<BF>((dec<BF>(*p) > 0.0f) ? acc[g] : 0.0f);
                     }
+                    if (XMERGE && l == 1) {
+                        // the tile's X goes back into its buffer HERE (single-chunk inputs): Xs held dZ_1, whose last readers (this
+                        // layer's two products) finished at the barrier above -- the separate barrier pair of the layer-0 weight gradient
+                        // (wait for those readers, store, publish) folds into the one that publishes dZ_0: two barriers fewer per tile
+                        tile_store<(VEC != 0), BF>(Xs, px);
+                        px = pn;  // the next tile's X, in flight since the head phase (EARLY_NEXT)
+                    }
                     __syncthreads();
                     PH(8);
                 }
@@ -1242,7 +1259,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
                 }
 #pragma unroll
                 for (int c = 0; c < (NCH > 0 ? NCH : 0); ++c) {
-                    if (NCH > 1 || L >= 1) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
+                    if (NCH > 1 || (L >= 1 && !XMERGE)) {  // X chunks are re-streamed (L2 / MALL hits) through the same prefetch registers
                         __syncthreads();
                         tile_store<(VEC != 0), BF>(Xs, px);
                         const bool last = (c + 1 == NCH);
