@@ -1287,12 +1287,16 @@ __global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArg
                 if (t > 0) partials(0, jh);
                 PH(15);
                 __syncthreads();  // B1
+                if (t > 0) partials(jh, A);
+                __syncthreads();  // B2
+                // the sums and the flush run in the B2 .. B3 interval (layer 1 of the compute waves), not before B2: with both halves of
+                // the partials AND the serial sums before B2 this wave reached that barrier ~2.4 k cycles after the compute waves had
+                // finished layer 0 (profiles/r04_phase_rollout64s_before.txt: "c: wait B2" 15.5 % of the step).  rscr (= the logit buffer) and the
+                // action / log-prob ring are idle until the head phase after B3
                 if (t > 0) {
-                    partials(jh, A);
                     reward_store(t - 1);
                     if ((t & 3) == 0) flush_alog(t - 4, 4);  // ring entries of steps t-4 .. t-1; slot 0 is rewritten after B3
                 }
-                __syncthreads();  // B2
                 __syncthreads();  // B3
                 draw(t + 4);      // slot t & 3 was consumed before B1 of this step; under the compute waves' head + sampling phase
             }
