@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""A/B library for same-box comparisons: compiles the csrc/ of a git revision (default HEAD) into cleanmarl_amd/libcleanmarl_hip_ab.so, which
+bench.py / the tools load through CM_LIB_PATH (tools/gpu/r04_e.sh, r04_g.sh run the working tree's build and this one alternately)."""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rev = sys.argv[1] if len(sys.argv) > 1 else "HEAD"
+flags = sys.argv[2:]
+subprocess.check_call(f"rm -rf /tmp/ab_src && mkdir -p /tmp/ab_src && git -C {ROOT} archive {rev} cleanmarl_amd/csrc include | tar -x -C /tmp/ab_src", shell=True)
+srcs = sorted(glob.glob("/tmp/ab_src/cleanmarl_amd/csrc/*.hip"))
+
+
+def comp(s):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"] + flags + ["-c", s, "-o", s + ".o"])
+    return s + ".o"
+
+
+with ThreadPoolExecutor(8) as ex:
+    objs = list(ex.map(comp, srcs))
+out = os.path.join(ROOT, "cleanmarl_amd", "libcleanmarl_hip_ab.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+print("built", out, "from", rev, flags)

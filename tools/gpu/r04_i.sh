@@ -1,0 +1,14 @@
+# quick rollout A/B (working tree vs libcleanmarl_hip_ab.so) at 4096 / 2048 envs + rollout parity
+set -x
+O=$GRAFT_REPO_ROOT/gpurun_out/${TAG:-r04i}
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rollout" > $O/parity.txt 2>&1; tail -2 $O/parity.txt
+ab() { label=$1; shift
+  for lib in "" $GRAFT_REPO_ROOT/cleanmarl_amd/libcleanmarl_hip_ab.so "" $GRAFT_REPO_ROOT/cleanmarl_amd/libcleanmarl_hip_ab.so; do
+    CM_LIB_PATH=$lib timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-extras "$@" 2>/dev/null | python -c "
+import json,sys
+o=json.loads(sys.stdin.read()); p=o['phase_ms']
+print('$label', 'old' if '$lib' else 'new', 'ms/step %.4f rollout %.4f value %.3f actor_k %.4f' % (o['ms_per_step'], p['rollout'], p['value_pass_scan'], o['kernel_ms']['actor_fwd_bwd']))"
+  done; }
+( ab cfg3; ab cfg3_2048 --envs 2048; ab cfg3_1024 --envs 1024 ) 2>/dev/null | tee $O/ab.txt
