@@ -795,6 +795,12 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // single-chunk training kernels used to RE-LOAD the tile they had just stored to LDS into the same prefetch registers (an L2 hit, 1 GB per
     // launch at config 3) to have it back for the layer-0 weight gradient; tile_store does not consume the registers, so they simply keep it
     constexpr bool XKEEP = EARLY_NEXT && (CM_XKEEP != 0);
+#ifndef CM_ROWIN_LATE
+#define CM_ROWIN_LATE 1
+#endif
+    // measured (gpurun_out/r04k): with the hand-ordered product forms (actor passes above 2^21 rows) 1.729 -> 1.697 ms at config 3; with the
+    // compiler-scheduled forms the late requests cost 2 % (512-env share 0.281 -> 0.288 ms per pass, config 2 0.212 -> 0.215): HAND only
+    constexpr bool ROWIN_LATE = XKEEP && HAND && (CM_ROWIN_LATE != 0);
     float w0ra[W0REG ? 32 : 1], w0rb[W0REG ? 32 : 1];  // W0REG: this wave's 32 output columns of W0, both input chunks, for the whole launch
     if constexpr (W0REG) {
         w0_regs_load(w0ra, a.params + off.W0, 32 * wn, H, din, 0, din);
@@ -832,31 +838,44 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         }
         const int grow = (int)row0 + hrow;  // this lane-group's global row (host guarantees rows < 2^31)
         const bool rvalid = grow < (int)a.rows;
+        // per-row head inputs of the tile (availability bytes, action / old log-prob / advantage / return, episode length): requested at the top
+        // of the tile, consumed in the head phase.  The SAME statements in three places, chosen at compile time -- each placement was measured on
+        // the instantiations it applies to (gpurun_out/r04k, r04l; a semantically neutral refactoring of this block moved the actor pass by 2 %
+        // either way, see the end of DESIGN.md 8b):
+        //   * training passes with the hand-ordered product forms and a kept tile (ROWIN_LATE: the actor pass above 2^21 rows): AFTER the
+        //     barrier, under the layer-0 products, instead of in the zero-MFMA interval between the two barriers: 1.729 -> 1.697 ms at config 3;
+        //   * the other training passes: inline before the tile prefetch (the compiler turns them into booleans right after the layer-0 loop;
+        //     vmcnt waits are in issue order, so behind the prefetch they would drag it along) -- the late form cost them 2 %;
+        //   * forward / act passes: the same place, through a lambda (config 4's act pass 1.75 -> 1.71 ms with the code the compiler makes of it)
+#define CM_FETCH_ROW_INPUTS() do { \
+                const bool use_avail = (MODE == M_ACTOR || MODE == M_COMA_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr); \
+                if (rvalid && use_avail) { \
+                    const uint8_t* ap = a.avail + (long)grow * a.avail_stride; \
+_Pragma("unroll") \
+                    for (int j = 0; j < KJ; ++j) \
+                        if (4 * j + hq < dout) ri.avb[j] = ap[4 * j + hq]; \
+                } \
+                if (TRAIN && rvalid) { \
+                    const int seq = grow / a.T; \
+                    ri.t = grow - seq * a.T; \
+                    ri.e = seq / Aseq; \
+                    ri.ag = seq - ri.e * Aseq; \
+                    ri.eplen = a.ep_len[ri.e]; \
+                    if (MODE == M_ACTOR) { ri.act = a.action[grow]; ri.lpo = a.logp_old[grow]; ri.adv = a.adv[grow]; } \
+                    else if (MODE == M_COMA_ACTOR) { ri.act = a.action[grow]; ri.adv = a.adv[grow]; } \
+                    else if (MODE == M_QCRITIC) { ri.act = a.action[grow]; ri.ret = a.ret[grow]; } \
+                    else if (a.per_agent) ri.ret = a.ret[grow]; \
+                } \
+        } while (0)
+        auto fetch_row_inputs = [&]() { CM_FETCH_ROW_INPUTS(); };
         for (int c = 0; c < nch; ++c) {
             __syncthreads();  // previous readers of Xs / W0s are done
             if (W0REG && c == 1) tile_store<(VEC != 0), BF>(Xs, pw); else tile_store<(VEC != 0), BF>(Xs, px);
             if (!w0_resident && !W0REG) tile_store<(VEC == 1), BF>(W0s, pw);
             if (c == 0) {
-                // per-row head inputs: issued here, BEFORE the tile prefetch below (the compiler turns them into booleans right
-                // after the layer-0 loop; vmcnt waits are in issue order, so behind the prefetch they would drag it along)
-                const bool use_avail = (MODE == M_ACTOR || MODE == M_COMA_ACTOR) || ((MODE == M_ACT || MODE == M_FWD) && a.avail != nullptr);
-                if (rvalid && use_avail) {
-                    const uint8_t* ap = a.avail + (long)grow * a.avail_stride;
-#pragma unroll
-                    for (int j = 0; j < KJ; ++j)
-                        if (4 * j + hq < dout) ri.avb[j] = ap[4 * j + hq];
-                }
-                if (TRAIN && rvalid) {
-                    const int seq = grow / a.T;
-                    ri.t = grow - seq * a.T;
-                    ri.e = seq / Aseq;
-                    ri.ag = seq - ri.e * Aseq;
-                    ri.eplen = a.ep_len[ri.e];
-                    if (MODE == M_ACTOR) { ri.act = a.action[grow]; ri.lpo = a.logp_old[grow]; ri.adv = a.adv[grow]; }
-                    else if (MODE == M_COMA_ACTOR) { ri.act = a.action[grow]; ri.adv = a.adv[grow]; }
-                    else if (MODE == M_QCRITIC) { ri.act = a.action[grow]; ri.ret = a.ret[grow]; }
-                    else if (a.per_agent) ri.ret = a.ret[grow];
-                }
+                if constexpr (!TRAIN) fetch_row_inputs();
+                else if constexpr (!ROWIN_LATE) CM_FETCH_ROW_INPUTS();
+                else if (L < 1) CM_FETCH_ROW_INPUTS();
             }
             // issue the next chunk's loads now; they land while the MFMAs below (and, for the last chunk,
             // the whole rest of the tile) execute
@@ -875,6 +894,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
             }
             __syncthreads();
             PH(0);
+            if constexpr (ROWIN_LATE) { if (c == 0 && L >= 1) CM_FETCH_ROW_INPUTS(); }
             const int w = min(KC, din - c * KC);
             if constexpr (W0REG) { if (c == 0) rowpar_regb(acc, Xs + 32 * wm * LDT, w0ra, (w + 7) >> 3); else rowpar_regb(acc, Xs + 32 * wm * LDT, w0rb, (w + 7) >> 3); }
             else if (BF) rowpar_nt_bf<HAND>(acc, Xs + 32 * wm * LDT, W0s + 32 * wn * LDT, (w + 15) >> 4);  // BF instantiations: HAND = single-pass bf16
@@ -1277,6 +1297,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         }
     }
     PH_FLUSH;
+#undef CM_FETCH_ROW_INPUTS
 
     // ================= write this workgroup's partial gradient + stats =================
     if (TRAIN) {

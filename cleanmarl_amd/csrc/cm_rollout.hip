@@ -1280,7 +1280,10 @@ __global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArg
                     }
                 }
             };
-            const int jh = (A + 1) / 2;  // A <= 10: two halves of at most five agents
+            // A <= 10: two parts of at most five agents.  The first part runs beside the compute waves' obs build (few issue conflicts), the
+            // second beside their layer-0 products, where this wave gets about half the issue rate (profiles/r04_phase_rollout64s.txt: the
+            // same four agents took 2.4 k cycles before B1 and ~4.5 k after it): the larger share goes first (A = 8: 5 + 3)
+            const int jh = max(A - 5, min(5, (5 * A + 7) / 8));
             for (int t = 0; t < T; ++t) {
                 __syncthreads();  // B0: positions after the physics of step t-1; the logit buffer (= rscr) is idle until after B3
                 PH(14);
