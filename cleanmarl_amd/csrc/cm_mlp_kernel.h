@@ -777,11 +777,6 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     }
 
     const long ntiles = (a.rows + TM - 1) / TM;
-#ifdef CM_ANTIPHASE
-    // experiment: the two workgroups of a CU run the same phases; if they run them at the same TIME they contend for the matrix pipe in the
-    // product phases and leave it idle in the others.  Start the second resident set half a tile late.
-    if (TRAIN && HAND && blockIdx.x >= 256) { for (int i = 0; i < CM_ANTIPHASE; ++i) __builtin_amdgcn_s_sleep(127); }
-#endif
     PH_DECL
     const int hrow = tid >> 2, hq = tid & 3;  // head mapping: 4 lanes per row, 16 hidden columns per lane
     const int Aseq = (MODE == M_CRITIC && !a.per_agent) ? 1 : a.A;
