@@ -186,6 +186,8 @@ class ComaArgs:
     env_workers: int = 0
     checkpoint: str = ""
     checkpoint_every: int = 0
+    greedy_eval: bool = False
+    """ [build] evaluate with argmax actions instead of sampling with eps = 0 (the reference samples, coma_multienvs.py:703-709)"""
 
 
 # per-script default overrides (SURVEY.md Appendix B)

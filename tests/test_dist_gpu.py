@@ -596,3 +596,39 @@ def test_two_rank_cli_run_with_host_envs_matches_the_single_process_run(tmp_path
     for tag in ("train/actor_loss", "train/critic_loss", "train/entropy", "train/actor_gradients", "train/critic_gradients"):
         assert abs(first(h1, tag) - first(h2, tag)) <= 1e-4 * (1 + abs(first(h1, tag))), tag
     assert [s for t, v, s in h1 if t == "train/num_updates"] == [s for t, v, s in h2 if t == "train/num_updates"]
+
+
+@pytest.mark.parametrize("env_type,script_name", [("synthetic_cpu", "mappo_multienvs"), ("synthetic", "mappo_multienvs"),
+                                                  ("synthetic", "mappo_lstm_multienvs"), ("synthetic_cpu", "coma_multienvs")])
+def test_two_rank_evaluation_equals_the_single_process_evaluation(env_type, script_name, tmp_path):
+    """Evaluation at N > 1 (cleanmarl_amd/evaluate.py): host envs -- the num_eval_ep episodes are dealt to the ranks in contiguous blocks and
+    gathered; device envs -- rank 0 plays them as one rollout on its evaluation stream while no rank waits.  Either way the first
+    evaluation (the policy after the first update differs between the 1- and 2-rank runs only by fp32 re-association of the gradient
+    sums) logs the episode statistics of the one-process run: same episode lengths, returns within the tolerance of a re-associated update."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mod = "coma_driver" if script_name.startswith("coma") else "driver"
+    prog = ("import json, os, sys; sys.path.insert(0, %r); from cleanmarl_amd.%s import run; "
+            "out = run(%r, ['--env_type=%s', '--batch_size=6', '--synthetic_agents=3', '--synthetic_steps=9', "
+            "'--total_timesteps=108', '--eval_steps=1', '--num_eval_ep=5', '--log_every=1', '--greedy_eval']); "
+            "print('HIST ' + json.dumps(out['history'])) if os.environ.get('RANK', '0') == '0' else None") % (root, mod, script_name, env_type)
+    env = dict(os.environ, CM_DIST_BACKEND="gloo")
+    script = str(tmp_path / "run_cli.py")
+    open(script, "w").write(prog + "\n")
+    one = subprocess.run([sys.executable, script], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), script], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    hist = lambda p: json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("HIST ")][0][5:])
+    h1, h2 = hist(one), hist(two)
+    ev = lambda h, tag: [(v, s) for t, v, s in h if t == tag]
+    for tag in ("eval/ep_reward", "eval/std_ep_reward", "eval/ep_length"):
+        a, b = ev(h1, tag), ev(h2, tag)
+        assert len(a) == len(b) >= 2 and [s for _, s in a] == [s for _, s in b], tag  # same evaluation rounds at the same env-step x values
+    assert [v for v, _ in ev(h2, "eval/ep_length")] == [9.0] * len(ev(h2, "eval/ep_length"))
+    # greedy evaluation after the FIRST update: an argmax flips only if two logits are within the re-association error of that update
+    a, b = ev(h1, "eval/ep_reward")[0][0], ev(h2, "eval/ep_reward")[0][0]
+    assert abs(a - b) <= 2e-2 * (1 + abs(a)), (a, b)
