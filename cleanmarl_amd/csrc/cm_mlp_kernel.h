@@ -1508,7 +1508,7 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
     // the critic stream: nothing runs beside it).  cm_set_option("mlp_forms", "hand"|"loop") forces one form wherever both are compiled (A/B runs, tests).
     if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH <= 0)) {
         const int f = cm_option(CM_OPTION_MLP_FORMS);  // 0 auto, 1 hand, 2 loop
-        const bool big = MODE == M_FWD || a.rows > (1L << 21);
+        const bool big = MODE == M_FWD || a.rows >= (1L << 21);  // >=: the learner's one-stream schedule starts AT 2^21 rows (learner.overlap_critic) -- nothing runs beside the pass there
         const bool hand = f ? (f == 1) : big;
         if (vec && l1 && k8 && hand) { launch_one<NCH, MODE, 1, 1, 2, false, true>(a, grid, lds_bytes, s); return; }
     }
