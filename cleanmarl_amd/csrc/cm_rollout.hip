@@ -1355,15 +1355,29 @@ __global__ __launch_bounds__(NT_SW, 4) void k_rollout_spread64s(const RolloutArg
                 if (live) {
                     const float* pos = epos + el * 2 * A; const float* vel = evel + el * 2 * A; const float* lm = elm + el * 2 * A;
                     const float px = pos[2 * i], py = pos[2 * i + 1];
+                    // entities j = hq, hq + 4, hq + 8 (7 A <= 64: at most three per lane): ALL their positions are requested before the first
+                    // store -- the runtime-bounded loop was a chain of dependent LDS round trips (read, wait, seven stores, read ...)
+                    float lx[3], ly[3], qx[3], qy[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int j = hq + 4 * u;
+                        const bool ok = j < A;
+                        lx[u] = ok ? lm[2 * j] : 0.0f; ly[u] = ok ? lm[2 * j + 1] : 0.0f;
+                        qx[u] = ok ? pos[2 * j] : 0.0f; qy[u] = ok ? pos[2 * j + 1] : 0.0f;
+                    }
                     if (hq == 0) { xr[0] = vel[2 * i]; xr[1] = vel[2 * i + 1]; xr[2] = px; xr[3] = py; }
-                    for (int j = hq; j < A; j += 4) {
-                        xr[4 + 2 * j] = lm[2 * j] - px; xr[5 + 2 * j] = lm[2 * j + 1] - py;
-                        if (j != i) {
-                            const int jj = j < i ? j : j - 1;
-                            xr[4 + 2 * A + 2 * jj] = pos[2 * j] - px; xr[5 + 2 * A + 2 * jj] = pos[2 * j + 1] - py;
-                            xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int j = hq + 4 * u;
+                        if (j < A) {
+                            xr[4 + 2 * j] = lx[u] - px; xr[5 + 2 * j] = ly[u] - py;
+                            if (j != i) {
+                                const int jj = j < i ? j : j - 1;
+                                xr[4 + 2 * A + 2 * jj] = qx[u] - px; xr[5 + 2 * A + 2 * jj] = qy[u] - py;
+                                xr[2 + 4 * A + 2 * jj] = 0.0f; xr[3 + 4 * A + 2 * jj] = 0.0f;  // comm channel
+                            }
+                            if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
                         }
-                        if (a.agent_ids) xr[6 * A + j] = (j == i) ? 1.0f : 0.0f;
                     }
                     for (int c = din + hq; c < KC; c += 4) xr[c] = 0.0f;  // MFMA chunk padding (H1 recycles this buffer)
                 } else {
