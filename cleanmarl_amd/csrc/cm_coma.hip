@@ -229,7 +229,14 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
 //   per-wave partials [nwaves][Da][HP] and reduced in a fixed order by k_reduce_partials.
 constexpr int OH_MAXA = 32;
 constexpr int OH_NWAVES = 8192;  // upper bound of gather waves (= partial tables)
-template <int VW>
+constexpr int OH_LDS = 80 * 1024;  // LDS of one gather block: two blocks per CU
+// Round 4: the pass is a stream over dZ0 (2.1 GB at config-3 shapes and 128 units) and ran at 1.25 TB/s -- every (e,t) paid a full HBM
+// round trip (one request batch in flight per wave, six waves per CU) and a chain of dependent LDS read-modify-writes.  Now THREE (e,t)
+// records rotate through registers (two in flight under the one being folded; AMAX = 8 keeps a record at 8 VW registers), the table
+// reads of one record are all issued before its adds and writes (see fold; ds_add_f32 was tried and is 2.7x SLOWER: LDS float atomics
+// retire a lane at a time), the table is [column][VW][64] (each plane contiguous across the lanes: no bank conflicts), and four waves per
+// block / two blocks per CU fit 80 KB.
+template <int VW, int AMAX>
 __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict__ dz0, const int* __restrict__ action, int E, int A, int T,
                                                          int K, int waves_per_block, float* __restrict__ dS, float* __restrict__ part,
                                                          int h0, long ldz, long ldS) {
@@ -237,55 +244,115 @@ __global__ __launch_bounds__(256) void k_coma_bwd_gather(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int Da = (A - 1) * K;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool active = w < waves_per_block;
-    float* mine = tab + (size_t)(active ? w : 0) * Da * HW;
-    if (active)
-        for (int i = lane; i < Da * HW; i += 64) mine[i] = 0.0f;
+    if (w >= waves_per_block) return;  // no workgroup barrier below: the tables are wave-private
+    float* mine = tab + (size_t)w * Da * HW;
+    for (int i = lane; i < Da * HW; i += 64) mine[i] = 0.0f;
     const long net = (long)E * T;
     const long nw = (long)gridDim.x * waves_per_block;
-    if (active) {
-        for (long et = (long)blockIdx.x * waves_per_block + w; et < net; et += nw) {
-            const long e = et / T;
-            const int t = (int)(et - e * T);
-            const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
-            float z[OH_MAXA][VW];
-            float tot[VW];
+    struct Rec { float z[AMAX][VW]; int u; };
+    auto fetch = [&](Rec& r, long et) {
+        if (et >= net) return;
+        const long e = et / T;
+        const int t = (int)(et - e * T);
+        r.u = action[(e * A + (lane < A ? lane : 0)) * T + t];
 #pragma unroll
-            for (int q = 0; q < VW; ++q) tot[q] = 0.0f;
-#pragma unroll
-            for (int a = 0; a < OH_MAXA; ++a) {
-#pragma unroll
-                for (int q = 0; q < VW; ++q) z[a][q] = 0.0f;
-                if (a < A) {
-                    const float* zp = dz0 + ((e * A + a) * T + t) * ldz + h0 + VW * lane;
-                    if constexpr (VW == 2) { const float2 q2 = *reinterpret_cast<const float2*>(zp); z[a][0] = q2.x; z[a][1] = q2.y; }
-                    else z[a][0] = zp[0];
-#pragma unroll
-                    for (int q = 0; q < VW; ++q) tot[q] += z[a][q];
-                }
+        for (int a = 0; a < AMAX; ++a) {
+            if (a < A) {
+                const float* zp = dz0 + ((e * A + a) * T + t) * ldz + h0 + VW * lane;
+                if constexpr (VW == 2) { const float2 q2 = *reinterpret_cast<const float2*>(zp); r.z[a][0] = q2.x; r.z[a][1] = q2.y; }
+                else r.z[a][0] = zp[0];
             }
-            float* sp = dS + et * ldS + h0 + VW * lane;
-            if constexpr (VW == 2) *reinterpret_cast<float2*>(sp) = make_float2(tot[0], tot[1]);
-            else sp[0] = tot[0];
-            float pre[VW];  // sum_{a<j}
+        }
+    };
+    auto fold = [&](const Rec& r, long et) {
+        float tot[VW];
 #pragma unroll
-            for (int q = 0; q < VW; ++q) pre[q] = 0.0f;
+        for (int q = 0; q < VW; ++q) tot[q] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < OH_MAXA; ++j) {
-                if (j < A) {
-                    const int uj = __shfl(u, j, 64);
+        for (int a = 0; a < AMAX; ++a)
+            if (a < A) {
 #pragma unroll
-                    for (int q = 0; q < VW; ++q) {
-                        if (j > 0) mine[((j - 1) * K + uj) * HW + VW * lane + q] += pre[q];
-                        const float suf = tot[q] - pre[q] - z[j][q];  // sum_{a>j}
-                        if (j < A - 1) mine[(j * K + uj) * HW + VW * lane + q] += suf;
-                        pre[q] += z[j][q];
-                    }
+                for (int q = 0; q < VW; ++q) tot[q] += r.z[a][q];
+            }
+        float* sp = dS + et * ldS + h0 + VW * lane;
+        if constexpr (VW == 2) *reinterpret_cast<float2*>(sp) = make_float2(tot[0], tot[1]);
+        else sp[0] = tot[0];
+        // Column block s (s = 0 .. A-2) receives two sums per (e,t): sum_{a>s} dZ0 at column s K + u_s (agent s seen by the agents behind it)
+        // and sum_{a<=s} dZ0 at column s K + u_{s+1} (agent s+1 seen by the agents before it).  Different blocks never alias, the two
+        // updates of one block alias exactly when u_s == u_{s+1} (wave-uniform) -- so ALL table reads are issued first, then the adds (in
+        // the order "behind" then "before", the order of the round-3 kernel), then the writes: no chain of dependent LDS round trips.
+        float rb[AMAX - 1][VW], rf[AMAX - 1][VW];
+#pragma unroll
+        for (int sl = 0; sl < AMAX - 1; ++sl) {
+            if (sl < A - 1) {
+                const int us = __builtin_amdgcn_readlane(r.u, sl), un = __builtin_amdgcn_readlane(r.u, sl + 1);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) {
+                    rb[sl][q] = mine[((sl * K + us) * VW + q) * 64 + lane];
+                    rf[sl][q] = mine[((sl * K + un) * VW + q) * 64 + lane];
                 }
             }
         }
-        float* o = part + ((size_t)blockIdx.x * waves_per_block + w) * Da * HW;
-        for (int i = lane; i < Da * HW; i += 64) o[i] = mine[i];
+        float pre[VW];  // sum_{a<=sl}
+#pragma unroll
+        for (int q = 0; q < VW; ++q) pre[q] = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < AMAX - 1; ++sl) {
+            if (sl < A - 1) {
+                const int us = __builtin_amdgcn_readlane(r.u, sl), un = __builtin_amdgcn_readlane(r.u, sl + 1);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) {
+                    const float suf = tot[q] - pre[q] - r.z[sl][q];  // sum_{a>sl}
+                    pre[q] += r.z[sl][q];
+                    float* pb = mine + ((sl * K + us) * VW + q) * 64 + lane;
+                    if (us == un) pb[0] = (rb[sl][q] + suf) + pre[q];
+                    else { pb[0] = rb[sl][q] + suf; mine[((sl * K + un) * VW + q) * 64 + lane] = rf[sl][q] + pre[q]; }
+                }
+            }
+        }
+    };
+    Rec r0, r1, r2;
+    long et = (long)blockIdx.x * waves_per_block + w;
+    fetch(r0, et);
+    fetch(r1, et + nw);
+    while (true) {
+        if (et >= net) break;
+        fetch(r2, et + 2 * nw); fold(r0, et); et += nw;
+        if (et >= net) break;
+        fetch(r0, et + 2 * nw); fold(r1, et); et += nw;
+        if (et >= net) break;
+        fetch(r1, et + 2 * nw); fold(r2, et); et += nw;
+    }
+    float* o = part + ((size_t)blockIdx.x * waves_per_block + w) * Da * HW;  // [column][HW], unit VW lane + q
+    for (int c = 0; c < Da; ++c)
+#pragma unroll
+        for (int q = 0; q < VW; ++q) o[c * HW + VW * lane + q] = mine[(c * VW + q) * 64 + lane];
+}
+
+// launch geometry of the gather pass: waves per block within OH_LDS, blocks capped at the resident set (more would only add partial tables)
+struct GatherGeom { int wpb; long blocks; size_t lds; };
+inline GatherGeom gather_geom(long et, size_t per_wave, int vw) {
+    GatherGeom g;
+    g.wpb = (int)(OH_LDS / per_wave);
+    g.wpb = g.wpb > 4 ? 4 : (g.wpb < 1 ? 1 : g.wpb);
+    g.lds = per_wave * g.wpb;
+    long per_cu = (160 * 1024) / (long)g.lds;
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    g.blocks = (et + g.wpb - 1) / g.wpb;
+    const long resident = 256 * per_cu, cap = (OH_NWAVES / vw) / g.wpb;
+    if (g.blocks > resident) g.blocks = resident;
+    if (g.blocks > cap) g.blocks = cap;
+    return g;
+}
+template <int VW>
+inline void gather_launch(const GatherGeom& g, int A, hipStream_t s, const float* dz0, const int* action, int E, int T, int K, float* dS, float* part,
+                          int h0, long ldz, long ldS) {
+    if (A <= 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coma_bwd_gather<VW, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, OH_LDS);
+        hipLaunchKernelGGL((k_coma_bwd_gather<VW, 8>), dim3((int)g.blocks), dim3(256), g.lds, s, dz0, action, E, A, T, K, g.wpb, dS, part, h0, ldz, ldS);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coma_bwd_gather<VW, OH_MAXA>), hipFuncAttributeMaxDynamicSharedMemorySize, OH_LDS);
+        hipLaunchKernelGGL((k_coma_bwd_gather<VW, OH_MAXA>), dim3((int)g.blocks), dim3(256), g.lds, s, dz0, action, E, A, T, K, g.wpb, dS, part, h0, ldz, ldS);
     }
 }
 
@@ -448,39 +515,29 @@ inline int coma_wide_critic_fwd_bwd(const float* state, const float* obs, const 
     if (int rc = wide_train<M_QCRITIC>(a, wsf + w.gc, wsf + w.train, (w.total - w.train) * sizeof(float), s, who, &dz0)) return rc;
     const size_t per_wave = (size_t)DaP * HP * sizeof(float);
     CM_REQUIRE(per_wave <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the LDS table", who, Da);
-    int wpb = (int)((64 * 1024) / per_wave);
-    wpb = wpb > 4 ? 4 : wpb;
-    long blocks = (et + wpb - 1) / wpb;
-    const long cap = OH_NWAVES / wpb;
-    if (blocks > cap) blocks = cap;
+    const GatherGeom g1 = gather_geom(et, per_wave, 1);
     float* gpart = wsf + w.part;
-    float* gred = gpart + (size_t)blocks * wpb * DaP * HP;
+    float* gred = gpart + (size_t)g1.blocks * g1.wpb * DaP * HP;
     const bool one_pass = w.Hs == 2 * HP && 2 * per_wave <= 64 * 1024;  // 65..128 units: both slabs per lane (float2)
     if (one_pass) {
-        int wpb2 = (int)((64 * 1024) / (2 * per_wave));
-        wpb2 = wpb2 > 4 ? 4 : wpb2;
-        long blocks2 = (et + wpb2 - 1) / wpb2;
-        const long cap2 = (OH_NWAVES / 2) / wpb2;
-        if (blocks2 > cap2) blocks2 = cap2;
-        float* gred2 = gpart + (size_t)blocks2 * wpb2 * DaP * 2 * HP;
-        hipLaunchKernelGGL(k_coma_bwd_gather<2>, dim3((int)blocks2), dim3(256), 2 * per_wave * wpb2, s, dz0, action, E, A, T, K, wpb2, wsf + w.dS, gpart, 0,
-                           (long)w.Hs, (long)w.Hs);
+        const GatherGeom g2 = gather_geom(et, 2 * per_wave, 2);
+        float* gred2 = gpart + (size_t)g2.blocks * g2.wpb * DaP * 2 * HP;
+        gather_launch<2>(g2, A, s, dz0, action, E, T, K, wsf + w.dS, gpart, 0, (long)w.Hs, (long)w.Hs);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * 2 * HP;
-            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks2 * wpb2), n, 0, n, gred2);
+            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(g2.blocks * g2.wpb), n, 0, n, gred2);
             hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred2, H, Da, wsf + w.ga, 2 * HP);
             CM_CHECK_LAUNCH(who);
         }
     }
     for (int h0 = 0; h0 < H && !one_pass; h0 += 64) {
         const int hn = min(64, H - h0);
-        hipLaunchKernelGGL(k_coma_bwd_gather<1>, dim3((int)blocks), dim3(256), per_wave * wpb, s, dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, h0,
-                           (long)w.Hs, (long)w.Hs);
+        gather_launch<1>(g1, A, s, dz0, action, E, T, K, wsf + w.dS, gpart, h0, (long)w.Hs, (long)w.Hs);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * HP;
-            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(blocks * wpb), n, 0, n, gred);
+            hipLaunchKernelGGL(k_reduce_partials, dim3((n + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, gpart, (int)(g1.blocks * g1.wpb), n, 0, n, gred);
             hipLaunchKernelGGL(k_transpose_ga, dim3(16), dim3(256), 0, s, gred, hn, Da, wsf + w.ga + (size_t)h0 * Da, HP);
             CM_CHECK_LAUNCH(who);
         }
@@ -652,14 +709,11 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
         const int DaP = Da > 0 ? Da : 1;
         const size_t per_wave = (size_t)DaP * HP * sizeof(float);
         CM_REQUIRE(per_wave <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the LDS table", who, Da);
-        int wpb = (int)((64 * 1024) / per_wave);  // waves (= private tables) per block within 64 KB of LDS
-        wpb = wpb > 4 ? 4 : wpb;
-        long blocks = (et + wpb - 1) / wpb;
-        const long cap = OH_NWAVES / wpb;
-        if (blocks > cap) blocks = cap;
-        float* gpart = wsf + w.part;                       // [blocks * wpb][Da][HP]
-        float* gred = gpart + (size_t)blocks * wpb * DaP * HP;  // [Da][HP]
-        hipLaunchKernelGGL(k_coma_bwd_gather<1>, dim3((int)blocks), dim3(256), per_wave * wpb, s, wsf + w.dz0, action, E, A, T, K, wpb, wsf + w.dS, gpart, 0, (long)HP, (long)HP);
+        const GatherGeom g1 = gather_geom(et, per_wave, 1);
+        float* gpart = wsf + w.part;                                    // [blocks * wpb][Da][HP]
+        float* gred = gpart + (size_t)g1.blocks * g1.wpb * DaP * HP;    // [Da][HP]
+        const long blocks = g1.blocks; const int wpb = g1.wpb;
+        gather_launch<1>(g1, A, s, wsf + w.dz0, action, E, T, K, wsf + w.dS, gpart, 0, (long)HP, (long)HP);
         CM_CHECK_LAUNCH(who);
         if (Da > 0) {
             const int n = Da * HP;
