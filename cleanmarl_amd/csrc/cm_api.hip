@@ -24,12 +24,12 @@ const char* const kCriticN[] = {"auto", "fused", "split"};       const int kCrit
 const char* const kGruN[] = {"auto", "64", "32", "8w"};          const int kGruV[] = {0, 64, 32, 8};
 const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRollV[] = {0, 64, 16, 17, 65};
 const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};
-const char* const kWideN[] = {"auto", "fused", "layered"};       const int kWideV[] = {0, 1, 2};
+const char* const kWideN[] = {"auto", "fused", "layered", "fused_r3"}; const int kWideV[] = {0, 1, 2, 3};
 const char* const kDw0N[] = {"auto", "8", "4"};                  const int kDw0V[] = {0, 8, 4};
 const char* const kGridN[] = {"auto", "512", "384", "256", "192", "128", "64"}; const int kGridV[] = {0, 512, 384, 256, 192, 128, 64};
 const OptDef kOpts[CM_OPTION_COUNT] = {
     {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 3}, {"gru_tile", kGruN, kGruV, 4},
-    {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}, {"wide_schedule", kWideN, kWideV, 3},
+    {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}, {"wide_schedule", kWideN, kWideV, 4},
     {"dw0_batch", kDw0N, kDw0V, 3}, {"dw0_grid", kGridN, kGridV, 7}, {"train_grid", kGridN, kGridV, 7}};
 std::atomic<int> g_opt[CM_OPTION_COUNT];  // zero-initialised: every option starts at its first value
 }  // namespace

@@ -196,26 +196,42 @@ __global__ __launch_bounds__(256) void k_coma_z0_add(const float* __restrict__ S
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long net = (long)E * T;
-    for (long et = (long)blockIdx.x * 4 + w; et < net; et += (long)gridDim.x * 4) {
-        const long e = et / T;
-        const int t = (int)(et - e * T);
-        const int u = action[(e * A + (lane < A ? lane : 0)) * T + t];
-        float sv[VW];
-        if constexpr (VW == 2) { const float2 q = *reinterpret_cast<const float2*>(S + et * ldS + h0 + 2 * lane); sv[0] = q.x; sv[1] = q.y; }
-        else sv[0] = S[et * ldS + h0 + lane];
-        for (int a = 0; a < A; ++a) {
-            float v[VW];
+    // a wave takes runs of ZR consecutive (e,t): the ZR action / S requests of a run are in flight together, and its stores to one agent's
+    // rows are ZR adjacent segments (the four waves of a block: 4 ZR adjacent segments per agent -- longer bursts per DRAM page)
+    constexpr int ZR = 4;
+    const long nrun = (net + ZR - 1) / ZR;
+    for (long run = (long)blockIdx.x * 4 + w; run < nrun; run += (long)gridDim.x * 4) {
+        int u[ZR];
+        float sv[ZR][VW];
 #pragma unroll
-            for (int q = 0; q < VW; ++q) v[q] = sv[q];
-            for (int slot = 0; slot < A - 1; ++slot) {
-                const int j = slot < a ? slot : slot + 1;
-                const float* tp = tab + (slot * K + __shfl(u, j, 64)) * HW + VW * lane;
+        for (int i = 0; i < ZR; ++i) {
+            const long et = min(run * ZR + i, net - 1);
+            const long e = et / T;
+            const int t = (int)(et - e * T);
+            u[i] = action[(e * A + (lane < A ? lane : 0)) * T + t];
+            if constexpr (VW == 2) { const float2 q = *reinterpret_cast<const float2*>(S + et * ldS + h0 + 2 * lane); sv[i][0] = q.x; sv[i][1] = q.y; }
+            else sv[i][0] = S[et * ldS + h0 + lane];
+        }
 #pragma unroll
-                for (int q = 0; q < VW; ++q) v[q] += tp[q];
+        for (int i = 0; i < ZR; ++i) {
+            const long et = run * ZR + i;
+            if (et >= net) break;
+            const long e = et / T;
+            const int t = (int)(et - e * T);
+            for (int a = 0; a < A; ++a) {
+                float v[VW];
+#pragma unroll
+                for (int q = 0; q < VW; ++q) v[q] = sv[i][q];
+                for (int slot = 0; slot < A - 1; ++slot) {
+                    const int j = slot < a ? slot : slot + 1;
+                    const float* tp = tab + (slot * K + __shfl(u[i], j, 64)) * HW + VW * lane;
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) v[q] += tp[q];
+                }
+                float* op = out + ((e * A + a) * T + t) * ldo + h0 + VW * lane;
+                if constexpr (VW == 2) *reinterpret_cast<float2*>(op) = make_float2(v[0], v[1]);
+                else op[0] = v[0];
             }
-            float* op = out + ((e * A + a) * T + t) * ldo + h0 + VW * lane;
-            if constexpr (VW == 2) *reinterpret_cast<float2*>(op) = make_float2(v[0], v[1]);
-            else op[0] = v[0];
         }
     }
 }
@@ -422,7 +438,7 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
     CM_REQUIRE(A <= 64, "%s: n_agents=%d > 64 is not supported by the factored critic input", who, A);
-    const long g = (et + 3) / 4;
+    const long g = (et + 15) / 16;  // runs of four (e,t) per wave, four waves per block
     hipLaunchKernelGGL(k_coma_z0_add<1>, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? tab_bytes : 4, s, wsf + w.S, action, params, E, A, T, H,
                        Dc, Ds, Do, K, wsf + w.z0, 0, (long)HP, (long)HP);
     CM_CHECK_LAUNCH(who);
@@ -467,7 +483,7 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
     const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
     CM_REQUIRE(A <= OH_MAXA, "%s: n_agents=%d > %d is not supported by the factored critic input", who, A, OH_MAXA);
-    const long g = (et + 3) / 4;
+    const long g = (et + 15) / 16;  // runs of four (e,t) per wave, four waves per block
     if (w.Hs == 2 * HP && 2 * tab_bytes <= 64 * 1024) {  // 65..128 units: both slabs in one pass, float2 per lane
         hipLaunchKernelGGL(k_coma_z0_add<2>, dim3((int)(g < 4096 ? g : 4096)), dim3(256), tab_bytes > 0 ? 2 * tab_bytes : 8, s, wsf + w.S, action, params, E,
                            A, T, H, Dc, Ds, Do, K, wsf + w.z0, 0, (long)w.Hs, (long)w.Hs);

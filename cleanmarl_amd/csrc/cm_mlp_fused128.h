@@ -472,6 +472,220 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Forward only (M_FWD), round 4.  The training kernel's forward (above, MODE = M_FWD: kept as wide_schedule=fused_r3 for A/B runs) spends
+// 23 k cycles per 64-row tile for 13 k of MFMA: one workgroup per CU (160 KB of LDS), three phases with a barrier each, and a head phase
+// that keeps four of the eight waves busy with one dependent chain of 32 products.  This kernel computes the TRANSPOSED products
+// (A = the wave's weight rows, B = the activation rows): the result of a 16x16x4 product then leaves lane (row c, group g) holding the
+// four units 16 w + 4 g + r of tile row c, and
+//   * H0 goes to LDS as one b128 per lane, the z0 addend arrives as one 16-byte load per lane and row block;
+//   * H1 never goes to LDS: the four registers of a layer-1 result ARE the B operand of the head's product over the wave's own 16 units
+//     (A = Wout[j][16 w + 4 g' + r], four products per row block on every wave), and the eight waves' partial logits are summed in a
+//     fixed order (wave 0..7, then the bias) by one thread per (row, output) after the second barrier;
+//   * W0 lives in registers too (16 per lane), X needs ONE buffer (the next tile's X is parked after the first barrier), so a workgroup
+//     needs 68 KB of LDS at K <= 8 and TWO workgroups share a CU (four waves per SIMD, <= 128 registers): one's barriers and LDS
+//     round trips hide under the other's products.  Two barriers per tile.
+__host__ __device__ inline int f128f_ks(int K, int ncols) { const int m = K > ncols ? K : ncols; return (m + 3) & ~3; }
+__host__ __device__ inline int f128f_lds_floats(bool ext0, int ks) { return (ext0 ? 0 : F_TM * F_LDX) + F_TM * F_LDH + 8 * F_TM * ks + KMAX; }
+
+template <bool EXT0>
+__global__ __launch_bounds__(F_NT, 4) void k_mlp128_fwd(const MlpArgs a, const F128X e, const int KS) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* H0s = smem + (EXT0 ? 0 : F_TM * F_LDX);
+    float* Ps = H0s + F_TM * F_LDH;       // [8 waves][64 rows][KS] partial logits
+    float* bouts = Ps + 8 * F_TM * KS;    // [KMAX]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lc = lane & 15, kq = lane >> 4;
+    const int H = a.H, din = a.din, K = a.dout;
+    const Offsets off = make_offsets(din, H, 1, K);
+    const float* __restrict__ P = a.params;
+    const int n = 16 * w + lc;    // the unit whose weight rows this lane supplies (A operand)
+    const bool nok = n < H;
+    const int u0 = 16 * w + 4 * kq;  // the first of the four units this lane holds of a product's result
+    const long ntiles = (a.rows + F_TM - 1) / F_TM;
+
+    float w1f[32], w0r[16], b0r[4], b1r[4], woA[2][4];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int k = 32 * kq + s;
+        const float v = P[off.Wl(0) + min(n, H - 1) * H + min(k, H - 1)];
+        w1f[s] = (nok && k < H) ? v : 0.0f;
+    }
+    if constexpr (!EXT0) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 16 * kq + s;
+            const float v = P[off.W0 + min(n, H - 1) * din + min(k, din - 1)];
+            w0r[s] = (nok && k < din) ? v : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int u = u0 + r;
+        b0r[r] = u < H ? P[off.b0 + u] : 0.0f;
+        b1r[r] = u < H ? P[off.bl(0) + u] : 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int j = 16 * cb + lc;
+            woA[cb][r] = (j < K && u < H) ? P[off.Wout + min(j, K - 1) * H + min(u, H - 1)] : 0.0f;
+        }
+    }
+    if (tid < KMAX) bouts[tid] = tid < K ? P[off.bout + tid] : 0.0f;
+    const bool vecz = e.z0 && e.ldz0 >= F_HP && (e.ldz0 & 3) == 0 && (reinterpret_cast<uintptr_t>(e.z0) & 15) == 0;
+
+    // ---- X tile loader: thread -> (row tid / 8, columns 8 (tid % 8) .. + 7)
+    const int xr = tid >> 3, xc = (tid & 7) * 8;
+    float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+    auto load_x = [&](long tile) {
+        xa = make_float4(0.f, 0.f, 0.f, 0.f); xb = xa;
+        const long row = tile * F_TM + xr;
+        if (tile < ntiles && row < a.rows) {
+            const float* p = a.x + row * a.x_stride + xc;
+            if (e.vecx) {
+                if (xc < din) xa = *reinterpret_cast<const float4*>(p);
+                if (xc + 4 < din) xb = *reinterpret_cast<const float4*>(p + 4);
+            } else {
+                if (xc < din) xa.x = p[0];
+                if (xc + 1 < din) xa.y = p[1];
+                if (xc + 2 < din) xa.z = p[2];
+                if (xc + 3 < din) xa.w = p[3];
+                if (xc + 4 < din) xb.x = p[4];
+                if (xc + 5 < din) xb.y = p[5];
+                if (xc + 6 < din) xb.z = p[6];
+                if (xc + 7 < din) xb.w = p[7];
+            }
+            if (xc + 1 >= din) xa.y = 0.f;
+            if (xc + 2 >= din) xa.z = 0.f;
+            if (xc + 3 >= din) xa.w = 0.f;
+            if (xc + 5 >= din) xb.y = 0.f;
+            if (xc + 6 >= din) xb.z = 0.f;
+            if (xc + 7 >= din) xb.w = 0.f;
+        }
+    };
+    auto store_x = [&]() {
+        float* d = Xs + xr * F_LDX + xc;
+        *reinterpret_cast<float4*>(d) = xa;
+        *reinterpret_cast<float4*>(d + 4) = xb;
+    };
+    // z0 addend of (row 16 rb + c, units u0 .. u0 + 3): requested one tile ahead (under layer 1), consumed as the accumulators' initial value
+    float4 zq[4];
+    auto load_z = [&](long tile) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const long row = tile * F_TM + 16 * rb + lc;
+            zq[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.z0 && tile < ntiles && row < a.rows) {
+                const float* zp = e.z0 + row * e.ldz0 + u0;
+                if (vecz) zq[rb] = *reinterpret_cast<const float4*>(zp);
+                else {
+                    if (u0 < H) zq[rb].x = zp[0];
+                    if (u0 + 1 < H) zq[rb].y = zp[1];
+                    if (u0 + 2 < H) zq[rb].z = zp[2];
+                    if (u0 + 3 < H) zq[rb].w = zp[3];
+                }
+            }
+        }
+    };
+    load_z(blockIdx.x);
+    if constexpr (!EXT0) { load_x(blockIdx.x); store_x(); }
+    __syncthreads();
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * F_TM;
+        if constexpr (!EXT0) load_x(tile + gridDim.x);  // in flight under layer 0, parked behind its barrier
+
+        // ---- layer 0 (transposed): lane (row c, g) <- units u0 .. u0 + 3 of row 16 rb + c; the accumulators start at b0 + z0 (requested a tile ahead)
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{b0r[0] + zq[rb].x, b0r[1] + zq[rb].y, b0r[2] + zq[rb].z, b0r[3] + zq[rb].w};
+        if constexpr (!EXT0) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float* bp = Xs + (16 * rb + lc) * F_LDX + 16 * kq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * q);
+                    acc[rb] = mfma16(w0r[4 * q], bv.x, acc[rb]);
+                    acc[rb] = mfma16(w0r[4 * q + 1], bv.y, acc[rb]);
+                    acc[rb] = mfma16(w0r[4 * q + 2], bv.z, acc[rb]);
+                    acc[rb] = mfma16(w0r[4 * q + 3], bv.w, acc[rb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            float4 h;
+            h.x = (u0 < H) ? fmaxf(acc[rb][0], 0.0f) : 0.0f;
+            h.y = (u0 + 1 < H) ? fmaxf(acc[rb][1], 0.0f) : 0.0f;
+            h.z = (u0 + 2 < H) ? fmaxf(acc[rb][2], 0.0f) : 0.0f;
+            h.w = (u0 + 3 < H) ? fmaxf(acc[rb][3], 0.0f) : 0.0f;
+            *reinterpret_cast<float4*>(H0s + (16 * rb + lc) * F_LDH + u0) = h;
+        }
+        __syncthreads();  // B1: H0 complete; X and the partial-logit slabs free
+
+        if constexpr (!EXT0) store_x();
+        load_z(tile + gridDim.x);
+        // ---- layer 1 (transposed) + this wave's share of the head, per row block
+#pragma unroll 2
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4 c1 = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
+            const float* bp = H0s + (16 * rb + lc) * F_LDH + 32 * kq;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * q);
+                c1 = mfma16(w1f[4 * q], bv.x, c1);
+                c1 = mfma16(w1f[4 * q + 1], bv.y, c1);
+                c1 = mfma16(w1f[4 * q + 2], bv.z, c1);
+                c1 = mfma16(w1f[4 * q + 3], bv.w, c1);
+            }
+            float h1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[r] = fmaxf(c1[r], 0.0f);  // units >= H: zero weights and bias
+            float* pp = Ps + ((w * F_TM + 16 * rb + lc) * KS + 4 * kq);
+            f32x4 hq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hq = mfma16(woA[0][r], h1[r], hq);  // lane (row c, g) <- outputs 4 g .. 4 g + 3
+            if (4 * kq < KS) *reinterpret_cast<float4*>(pp) = make_float4(hq[0], hq[1], hq[2], hq[3]);
+            if (K > 16) {
+                f32x4 hr = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hr = mfma16(woA[1][r], h1[r], hr);
+                if (16 + 4 * kq < KS) *reinterpret_cast<float4*>(pp + 16) = make_float4(hr[0], hr[1], hr[2], hr[3]);
+            }
+        }
+        __syncthreads();  // B2: partial logits complete
+
+        // ---- logits: one thread per (row, output), the eight partial sums in wave order, then the bias
+        for (int o = tid; o < F_TM * KS; o += F_NT) {
+            const int rl = o / KS, j = o - rl * KS;
+            const long row = row0 + rl;
+            float v = 0.0f;
+            if (j < K) {
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) v += Ps[(ww * F_TM + rl) * KS + j];
+                v += bouts[j];
+                if (a.avail && row < a.rows && !a.avail[row * a.avail_stride + j]) v = -1e9f;  // masked_fill(~avail, -1e9)
+            }
+            if (row < a.rows && j < e.ncols) e.y[row * e.ldy + j] = v;
+        }
+    }
+}
+
+inline void fused128_fwd_launch(bool ext0, const MlpArgs& a, const F128X& e, hipStream_t s) {
+    const int ks = f128f_ks(a.dout, e.ncols);
+    const size_t lds = (size_t)f128f_lds_floats(ext0, ks) * sizeof(float);
+    const long nt = (a.rows + F_TM - 1) / F_TM;
+    const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;
+    const int grid = (int)(nt < per_cu * F_GRID ? nt : per_cu * F_GRID);
+    if (ext0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp128_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_mlp128_fwd<true>), dim3(grid), dim3(F_NT), lds, s, a, e, ks);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp128_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_mlp128_fwd<false>), dim3(grid), dim3(F_NT), lds, s, a, e, ks);
+    }
+}
+
 // the shapes this kernel serves (cm_set_option("wide_schedule", "layered") keeps everything on the layered schedule: A/B runs, tests)
 inline bool fused128_shape(int H, int L) { return H > HP && H <= F_HP && L == 1 && cm_option(CM_OPTION_WIDE_SCHEDULE) != 2; }
 inline int fused128_grid(long rows) { const long nt = (rows + F_TM - 1) / F_TM; return (int)(nt < F_GRID ? nt : F_GRID); }
@@ -488,6 +702,7 @@ inline void fused128_launch_k(const MlpArgs& a, const F128X& e, hipStream_t s) {
 }
 template <int MODE, bool EXT0>
 inline void fused128_launch(const MlpArgs& a, const F128X& e, hipStream_t s) {
+    if constexpr (MODE == M_FWD) { if (cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) { fused128_fwd_launch(EXT0, a, e, s); return; } }
     // the actor heads exist in a K <= 8 form (the softmax / gradient loops of wide_loss_row over 8 instead of 32 outputs)
     if constexpr (MODE == M_ACTOR || MODE == M_COMA_ACTOR) { if (a.dout <= 8) { fused128_launch_k<MODE, EXT0, 8>(a, e, s); return; } }
     fused128_launch_k<MODE, EXT0, KMAX>(a, e, s);

@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04coma2
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -x -q -k "coma" 2>&1 | tail -5 | tee $O/tests.txt
+python -m pytest tests -m gpu -x -q -k "coma or wide or 128 or fused" 2>&1 | tail -5 | tee $O/tests.txt
 for w in 64 128; do
   python tools/bench_coma.py --critic-hidden $w --no-cpu-baseline > $O/coma$w.json 2> $O/coma$w.err || tail -5 $O/coma$w.err
   python - <<PY
