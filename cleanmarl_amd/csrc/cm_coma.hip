@@ -478,6 +478,13 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
     CM_CHECK_LAUNCH(who);
     const long et = (long)E * T;
+    if (A <= COMA_EPI_MAXA && (size_t)(A - 1) * K * w.Hs * sizeof(float) <= 64 * 1024 && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {
+        // one launch: S = state W0s^T stays in the GEMM's tile, its epilogue writes the A rows of z0 per (e,t) (cm_mlp_wide.h, EPI_COMA)
+        const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
+        wide_gemm<EPI_COMA>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, w.Hs, w.Hs, s, nullptr, nullptr, &cx);
+        CM_CHECK_LAUNCH(who);
+        return 0;
+    }
     wide_gemm<EPI_NONE>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.S, w.Hs, w.Hs, s);  // S = state W0s^T
     CM_CHECK_LAUNCH(who);
     const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);

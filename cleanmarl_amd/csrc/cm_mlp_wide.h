@@ -28,7 +28,12 @@ constexpr int WT_TPR = WT_K / 4;   // loader threads per row (one float4 each)
 constexpr int WT_RPP = NTHREADS / WT_TPR;  // rows per loader pass
 constexpr int WT_XP = WT_M / WT_RPP;       // loader passes over the X tile
 constexpr int WIDE_HMAX = 256;
-enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_ADD = 4 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend; ADD: product + gate, nothing else
+enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_ADD = 4, EPI_COMA = 5 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend; ADD: product + gate, nothing else
+// EPI_COMA (cm_coma.hip, the factored critic input): the product's rows are S[e,t] = state W0s^T; the epilogue writes the A rows
+// z0[(e,a,t)] = S[e,t] + sum_{j != a} W0a[:, slot(j,a) K + u_j] straight from the staged tile -- S never reaches HBM and the separate
+// k_coma_z0_add pass (one more 2 GB stream at config-3 shapes and 128 units) is gone.  The sums run in k_coma_z0_add's order (bit-identical).
+struct WideComa { const int* action; const float* W0; int A, T, Kact, Dc, col0, H; };
+constexpr int COMA_EPI_MAXA = 8;
 
 #define WIDE_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -46,10 +51,19 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                                                            const float* __restrict__ bias, const uint8_t* __restrict__ avail, long lda,
                                                            const float* __restrict__ gate, long ldg,
                                                            float* __restrict__ Y, long ldy, int ncols, int vecx, int vecw,
-                                                           int vecy, int vecg, float* __restrict__ colsum_part) {
+                                                           int vecy, int vecg, float* __restrict__ colsum_part, const WideComa cx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* Ws = smem + WT_M * WT_LD;
+    constexpr int TLD = 32 * NJ;  // EPI_COMA: row stride of the transposed action block of W0, parked behind the operand / staging area
+    float* tabs = smem + (((WT_M + 32 * NJ) * WT_LD > 64 * (32 * NJ + 8)) ? (WT_M + 32 * NJ) * WT_LD : 64 * (32 * NJ + 8));
+    if constexpr (EPI == EPI_COMA) {
+        const int Da = (cx.A - 1) * cx.Kact;
+        for (int i = threadIdx.x; i < Da * TLD; i += NTHREADS) {
+            const int c = i / TLD, hh = i - c * TLD;
+            tabs[i] = hh < cx.H ? cx.W0[(long)hh * cx.Dc + cx.col0 + c] : 0.0f;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 31, h = lane >> 5;
     const int lr = tid / WT_TPR, lk = 4 * (tid % WT_TPR);  // loader: row lr + WT_RPP i, floats lk..lk+3 of the chunk
     constexpr int WP = 32 * NJ / WT_RPP;                   // loader passes over the W tile
@@ -154,6 +168,42 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                         const long row = row0 + 32 * wave + 16 * p + rl;
                         if (row < rows) {
                             const float4 t = *reinterpret_cast<const float4*>(stg + rl * SLD + 4 * c4);
+                            if constexpr (EPI == EPI_COMA) {
+                                const int A_ = cx.A, T_ = cx.T, Ka = cx.Kact;
+                                const long e_ = row / T_;
+                                const int t_ = (int)(row - e_ * T_);
+                                int u[COMA_EPI_MAXA];
+#pragma unroll
+                                for (int j = 0; j < COMA_EPI_MAXA; ++j) u[j] = j < A_ ? cx.action[(e_ * A_ + j) * T_ + t_] : 0;
+                                const float* tb = tabs + 4 * c4;
+                                float4 Q[COMA_EPI_MAXA - 1];  // Q[j-1]: agent j's action in the column block the agents before it see
+#pragma unroll
+                                for (int j = 1; j < COMA_EPI_MAXA; ++j)
+                                    Q[j - 1] = j < A_ ? *reinterpret_cast<const float4*>(tb + ((j - 1) * Ka + u[j]) * TLD) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                float4 pre = t;  // S + the blocks of the agents 0 .. a-1 (as the agents behind them see them)
+#pragma unroll
+                                for (int ag = 0; ag < COMA_EPI_MAXA; ++ag) {
+                                    if (ag < A_) {
+                                        float4 z = pre;
+#pragma unroll
+                                        for (int j = 1; j < COMA_EPI_MAXA; ++j)
+                                            if (j > ag && j < A_) { z.x += Q[j - 1].x; z.y += Q[j - 1].y; z.z += Q[j - 1].z; z.w += Q[j - 1].w; }
+                                        float* yp = Y + ((e_ * A_ + ag) * T_ + t_) * ldy + 4 * c4;
+                                        if (vecy && 4 * c4 + 3 < ncols) *reinterpret_cast<float4*>(yp) = z;
+                                        else {
+                                            if (4 * c4 < ncols) yp[0] = z.x;
+                                            if (4 * c4 + 1 < ncols) yp[1] = z.y;
+                                            if (4 * c4 + 2 < ncols) yp[2] = z.z;
+                                            if (4 * c4 + 3 < ncols) yp[3] = z.w;
+                                        }
+                                        if (ag < A_ - 1) {
+                                            const float4 pa = *reinterpret_cast<const float4*>(tb + (ag * Ka + u[ag]) * TLD);
+                                            pre.x += pa.x; pre.y += pa.y; pre.z += pa.z; pre.w += pa.w;
+                                        }
+                                    }
+                                }
+                                continue;
+                            }
                             float v[4] = {t.x, t.y, t.z, t.w};
                             float gt[4] = {0.f, 0.f, 0.f, 0.f};
                             const bool has_g = (EPI == EPI_GATE) || ((EPI == EPI_BIAS_RELU || EPI == EPI_ADD) && gate != nullptr);
@@ -216,8 +266,10 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <int EPI>
 inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W, int ldw, int N, const float* bias,
                       const uint8_t* avail, long lda, const float* gate, long ldg, float* Y, long ldy, int ncols, hipStream_t s,
-                      float* colsum_part = nullptr, float* colsum_out = nullptr) {
+                      float* colsum_part = nullptr, float* colsum_out = nullptr, const WideComa* coma = nullptr) {
     const int nj = (max(N, ncols) + 31) / 32;
+    const WideComa cx = coma ? *coma : WideComa{};
+    const size_t tab_bytes = coma ? (size_t)(cx.A - 1) * cx.Kact * 32 * nj * sizeof(float) : 0;
     const int vecx = (ldx % 4 == 0 && K % 4 == 0 && al16(X)) ? 1 : 0;
     const int vecw = (ldw % 4 == 0 && K % 4 == 0 && al16(W)) ? 1 : 0;
     const int vecy = (ldy % 4 == 0 && al16(Y)) ? 1 : 0;
@@ -226,20 +278,20 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     const int grid = (int)min(ntiles, 512L);
 #define CM_WIDE_CASE(NJ)                                                                                                        \
     case NJ: {                                                                                                                  \
-        const size_t lds = wide_gemm_lds(NJ);                                                                                   \
+        const size_t lds = wide_gemm_lds(NJ) + tab_bytes;                                                                       \
         if (lds > 64 * 1024)                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_gemm<NJ, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_wide_gemm<NJ, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail, \
-                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part);                                      \
+                           lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part, cx);                                  \
     } break;
     switch (nj) {
         CM_WIDE_CASE(1) CM_WIDE_CASE(2) CM_WIDE_CASE(3) CM_WIDE_CASE(4) CM_WIDE_CASE(5) CM_WIDE_CASE(6) CM_WIDE_CASE(7)
         default: { constexpr int NJ8 = 8;
-            const size_t lds = wide_gemm_lds(NJ8);
+            const size_t lds = wide_gemm_lds(NJ8) + tab_bytes;
             if (lds > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_gemm<NJ8, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_wide_gemm<NJ8, EPI>), dim3(grid), dim3(NTHREADS), lds, s, X, ldx, rows, K, W, ldw, N, bias, avail,
-                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part);
+                               lda, gate, ldg, Y, ldy, ncols, vecx, vecw, vecy, vecg, colsum_part, cx);
         } break;
     }
 #undef CM_WIDE_CASE
