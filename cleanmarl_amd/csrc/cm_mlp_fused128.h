@@ -228,6 +228,7 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
         __syncthreads();  // B1: H0 complete
         PH(1);
 
+        if constexpr (!EXT0 && TRAIN) load_x(tile + gridDim.x);  // training: requested a whole layer before it is parked in LDS (behind the loss barrier)
         // ---- layer 1: H1 = relu(H0 W1^T + b1).  The row-block loops from here on are ROLLED (runtime rb): an unrolled phase lets the
         // compiler hoist every operand read of the phase above its first MFMA and spill the persistent accumulators to scratch
         // (measured: 127 spilled registers, dW1 / dW0 phases 30 % / 100 % slower); one row block per iteration bounds the live set.
@@ -252,7 +253,6 @@ __global__ __launch_bounds__(F_NT) void k_mlp128(const MlpArgs a, const F128X e)
         __syncthreads();  // B2: H1 complete
         PH(3);
 
-        if constexpr (!EXT0 && TRAIN) load_x(tile + gridDim.x);  // training: requested here, parked in LDS after the loss barrier (8 registers less in the forward products)
         // ---- head: wave (hrb, hcb) -> 16 rows x 16 outputs
         {
             f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -71,9 +71,11 @@ int cm_version(void);
  *                                              (3 MFMAs per product, ~3e-6 of sum|a b|, inside the 1e-4 parity bar); single-pass bf16
  *                                              (1 MFMA per product, operands rounded to 8 bits: ~4e-3, its own looser parity tier);
  *                                              fp32 accumulate either way -- DESIGN.md section 8
- *   "wide_schedule"    auto | fused | layered  MLPs of 65 .. 128 hidden units with one hidden->hidden layer (the reference's COMA critic
+ *   "wide_schedule"    auto | fused | layered | fused_r3
+ *                                              MLPs of 65 .. 128 hidden units with one hidden->hidden layer (the reference's COMA critic
  *                                              default, cleanmarl/coma_multienvs.py:35): one-launch fused tile (csrc/cm_mlp_fused128.h, the
- *                                              default) vs the layer-by-layer schedule every wider / deeper shape runs (csrc/cm_mlp_wide.h)
+ *                                              default) vs the layer-by-layer schedule every wider / deeper shape runs (csrc/cm_mlp_wide.h);
+ *                                              fused_r3 = the fused tile with round 3's forward kernel and COMA's separate S / z0 launches (A/B runs)
  *   "dw0_batch"        auto | 8 | 4            rows in flight per lane of the streaming layer-0 weight-gradient product of the split
  *                                              critic schedule (csrc/cm_mlp_split.h): 16 rows (234 registers) or 8 rows (fits one wave on
  *                                              every SIMD beside the six-wave rollout the two-stream schedule runs it under); auto = 8 rows

@@ -330,6 +330,43 @@ def test_mlp_forward_matches_oracle():
                                          N.stream_ptr()) != 0 and b"workspace too small" in lib.cm_last_error()
 
 
+def test_fused_128_forward_transposed_kernel_matches_oracle_and_the_round3_forward(monkeypatch):
+    """k_mlp128_fwd (csrc/cm_mlp_fused128.h, round 4: transposed products, H1 in registers, partial logits summed in wave order, two
+    workgroups per CU) against the oracle and against the forward of the training tile it replaced (option wide_schedule = fused_r3):
+    inputs inside (<= 64 columns) and outside (k_wide_gemm -> z0) the launch, 65 / 96 / 128 units, heads of 1 .. 32 outputs (one and two
+    column blocks, partial-slab strides 4 .. 32), ragged last tiles, more tiles than resident workgroups."""
+    from oracle import restatement as R
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    differ = 0
+    for (rows, din, H, dout) in [(1000, 384, 128, 1), (777, 56, 128, 5), (513, 33, 96, 17), (70, 64, 65, 32), (40000, 56, 128, 5), (129, 7, 128, 16)]:
+        spec = NetSpec(din, H, 1, dout)
+        p = init_params_like_torch(spec)
+        x = torch.randn(rows, din)
+        avail = torch.rand(rows, dout) < 0.7
+        d_x, d_p, d_a = x.to(dev), flatten_params(p, dev), avail.to(torch.uint8).to(dev)
+        need = lib.cm_mlp_forward_workspace_bytes(rows, din, H, 1, dout)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        ys = []
+        for sched in ("fused", "fused_r3"):
+            monkeypatch.setenv("CM_WIDE_SCHEDULE", sched)
+            N.sync_env_options()
+            assert lib.cm_get_option(b"wide_schedule") == sched.encode()
+            y = torch.full((rows, dout), float("nan"), device=dev)
+            N.check(lib.cm_mlp_forward_ws(N.ptr(d_x), rows, din, H, 1, dout, N.ptr(d_p), N.ptr(d_a), N.ptr(y), N.ptr(ws), need, N.stream_ptr()), "fwd_ws")
+            ys.append(y.cpu())
+        ref = R.actor_logits(p, x, avail)
+        for y in ys:
+            assert _err(y.numpy(), ref.numpy()) <= TOL
+        differ += int(not torch.equal(ys[0], ys[1]))
+    assert differ > 0  # the option really switched kernels (different summation orders)
+    monkeypatch.delenv("CM_WIDE_SCHEDULE")
+    N.sync_env_options()
+
+
 def test_unknown_optimizer_fails_loudly():
     from cleanmarl_amd import _native as N
     from cleanmarl_amd.learner import HParams, NetSpec, PPOLearner
