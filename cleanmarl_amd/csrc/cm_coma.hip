@@ -432,6 +432,12 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
     CM_CHECK_LAUNCH(who);
     const long et = (long)E * T;
+    if (A <= COMA_EPI_MAXA && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {  // one launch: S in the GEMM's tile, z0's A rows from its epilogue (cm_mlp_wide.h, EPI_COMA)
+        const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
+        wide_gemm<EPI_COMA>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, HP, HP, s, nullptr, nullptr, &cx);
+        CM_CHECK_LAUNCH(who);
+        return 0;
+    }
     const long nt = (et + TM - 1) / TM;
     hipLaunchKernelGGL(k_linear_nt, dim3((int)(nt < 512 ? nt : 512)), dim3(NTHREADS), 0, s, state, et, (long)Ds, Ds, params, (long)Dc, H, wsf + w.S);
     CM_CHECK_LAUNCH(who);
