@@ -149,6 +149,15 @@ __global__ __launch_bounds__(256) void k_coma_compact_params(const float* __rest
     }
 }
 
+// ws[h][c] = W0[h][c] for the state block (c < Ds), row stride ldp (a multiple of 4 floats): the torch-order rows (stride Dc, 475 floats at
+// config-3 shapes) are not 16-byte aligned, and k_wide_gemm then loads its weight tile with four predicated scalar loads per float4
+__global__ __launch_bounds__(256) void k_coma_pack_w0s(const float* __restrict__ full, int H, int Dc, int Ds, int ldp, float* __restrict__ ws) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * ldp; i += gridDim.x * 256) {
+        const int h = i / ldp, c = i - h * ldp;
+        ws[i] = c < Ds ? full[(long)h * Dc + c] : 0.0f;
+    }
+}
+
 // out[rows][HP] = X[rows][ncols] * W[H][ncols]^T (W row stride w_stride); columns >= H are zero
 __global__ __launch_bounds__(NTHREADS, 2) void k_linear_nt(const float* __restrict__ x, long rows, long x_stride, int ncols,
                                                            const float* __restrict__ W, long w_stride, int H, float* __restrict__ out) {
@@ -434,7 +443,9 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     const long et = (long)E * T;
     if (A <= COMA_EPI_MAXA && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {  // one launch: S in the GEMM's tile, z0's A rows from its epilogue (cm_mlp_wide.h, EPI_COMA)
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
-        wide_gemm<EPI_COMA>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, HP, HP, s, nullptr, nullptr, &cx);
+        const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
+        hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
+        wide_gemm<EPI_COMA>(state, Ds, et, Ds, wsf + w.S, ldp, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, HP, HP, s, nullptr, nullptr, &cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }
@@ -487,7 +498,9 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
     if (A <= COMA_EPI_MAXA && (size_t)(A - 1) * K * w.Hs * sizeof(float) <= 64 * 1024 && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {
         // one launch: S = state W0s^T stays in the GEMM's tile, its epilogue writes the A rows of z0 per (e,t) (cm_mlp_wide.h, EPI_COMA)
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
-        wide_gemm<EPI_COMA>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, w.Hs, w.Hs, s, nullptr, nullptr, &cx);
+        const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
+        hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
+        wide_gemm<EPI_COMA>(state, Ds, et, Ds, wsf + w.S, ldp, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, w.Hs, w.Hs, s, nullptr, nullptr, &cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }
