@@ -1506,7 +1506,7 @@ inline void launch_variant(const MlpArgs& a, int grid, size_t lds_bytes, hipStre
     // hand-ordered LDS reads (see rowpar_nt): the single-chunk actor pass of a batch too large to share the GPU with the critic's
     // epochs (learner.overlap_critic's 2^21-row limit), and every forward pass (the value pass follows the rollout and the join with
     // the critic stream: nothing runs beside it).  cm_set_option("mlp_forms", "hand"|"loop") forces one form wherever both are compiled (A/B runs, tests).
-    if constexpr ((MODE == M_ACTOR && NCH == 1) || (MODE == M_FWD && NCH <= 0)) {
+    if constexpr (((MODE == M_ACTOR || MODE == M_COMA_ACTOR || MODE == M_QCRITIC) && NCH == 1) || (MODE == M_FWD && NCH <= 0)) {
         const int f = cm_option(CM_OPTION_MLP_FORMS);  // 0 auto, 1 hand, 2 loop
         const bool big = MODE == M_FWD || a.rows >= (1L << 21);  // >=: the learner's one-stream schedule starts AT 2^21 rows (learner.overlap_critic) -- nothing runs beside the pass there
         const bool hand = f ? (f == 1) : big;
