@@ -441,11 +441,11 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
     CM_CHECK_LAUNCH(who);
     const long et = (long)E * T;
-    if (A <= COMA_EPI_MAXA && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {  // one launch: S in the GEMM's tile, z0's A rows from its epilogue (cm_mlp_wide.h, EPI_COMA)
+    if (coma_epi_fits(A, K, HP) && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {  // one launch: S in the GEMM's tile, z0's A rows from its epilogue (cm_mlp_wide.h, EPI_COMA)
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
         const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
         hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
-        wide_gemm<EPI_COMA>(state, Ds, et, Ds, wsf + w.S, ldp, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, HP, HP, s, nullptr, nullptr, &cx);
+        wide_gemm_coma(state, Ds, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, HP, HP, s, cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }
@@ -495,12 +495,12 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
     CM_CHECK_LAUNCH(who);
     const long et = (long)E * T;
-    if (A <= COMA_EPI_MAXA && (size_t)(A - 1) * K * w.Hs * sizeof(float) <= 64 * 1024 && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {
+    if (coma_epi_fits(A, K, w.Hs) && cm_option(CM_OPTION_WIDE_SCHEDULE) != 3) {
         // one launch: S = state W0s^T stays in the GEMM's tile, its epilogue writes the A rows of z0 per (e,t) (cm_mlp_wide.h, EPI_COMA)
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
         const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
         hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
-        wide_gemm<EPI_COMA>(state, Ds, et, Ds, wsf + w.S, ldp, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.z0, w.Hs, w.Hs, s, nullptr, nullptr, &cx);
+        wide_gemm_coma(state, Ds, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, w.Hs, w.Hs, s, cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }

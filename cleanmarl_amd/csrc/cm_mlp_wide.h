@@ -28,12 +28,12 @@ constexpr int WT_TPR = WT_K / 4;   // loader threads per row (one float4 each)
 constexpr int WT_RPP = NTHREADS / WT_TPR;  // rows per loader pass
 constexpr int WT_XP = WT_M / WT_RPP;       // loader passes over the X tile
 constexpr int WIDE_HMAX = 256;
-enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_ADD = 4, EPI_COMA = 5 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend; ADD: product + gate, nothing else
+enum WideEpi { EPI_BIAS_RELU = 0, EPI_BIAS = 1, EPI_GATE = 2, EPI_NONE = 3, EPI_ADD = 4, EPI_COMA = 5, EPI_COMA16 = 6 };  // BIAS_RELU adds `gate` (if set) as a pre-activation addend; ADD: product + gate, nothing else
 // EPI_COMA (cm_coma.hip, the factored critic input): the product's rows are S[e,t] = state W0s^T; the epilogue writes the A rows
 // z0[(e,a,t)] = S[e,t] + sum_{j != a} W0a[:, slot(j,a) K + u_j] straight from the staged tile -- S never reaches HBM and the separate
 // k_coma_z0_add pass (one more 2 GB stream at config-3 shapes and 128 units) is gone.  The sums run in k_coma_z0_add's order (bit-identical).
 struct WideComa { const int* action; const float* W0; int A, T, Kact, Dc, col0, H; };
-constexpr int COMA_EPI_MAXA = 8;
+constexpr int COMA_EPI_MAXA = 16;  // EPI_COMA serves up to 8 agents, EPI_COMA16 up to 16 (twice the registers and unrolled guards per row)
 
 #define WIDE_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
     float* Ws = smem + WT_M * WT_LD;
     constexpr int TLD = 32 * NJ;  // EPI_COMA: row stride of the transposed action block of W0, parked behind the operand / staging area
     float* tabs = smem + (((WT_M + 32 * NJ) * WT_LD > 64 * (32 * NJ + 8)) ? (WT_M + 32 * NJ) * WT_LD : 64 * (32 * NJ + 8));
-    if constexpr (EPI == EPI_COMA) {
+    constexpr bool COMA = EPI == EPI_COMA || EPI == EPI_COMA16;
+    constexpr int CMAXA = EPI == EPI_COMA16 ? 16 : 8;
+    if constexpr (COMA) {
         const int Da = (cx.A - 1) * cx.Kact;
         for (int i = threadIdx.x; i < Da * TLD; i += NTHREADS) {
             const int c = i / TLD, hh = i - c * TLD;
@@ -168,25 +170,25 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                         const long row = row0 + 32 * wave + 16 * p + rl;
                         if (row < rows) {
                             const float4 t = *reinterpret_cast<const float4*>(stg + rl * SLD + 4 * c4);
-                            if constexpr (EPI == EPI_COMA) {
+                            if constexpr (COMA) {
                                 const int A_ = cx.A, T_ = cx.T, Ka = cx.Kact;
                                 const long e_ = row / T_;
                                 const int t_ = (int)(row - e_ * T_);
-                                int u[COMA_EPI_MAXA];
+                                int u[CMAXA];
 #pragma unroll
-                                for (int j = 0; j < COMA_EPI_MAXA; ++j) u[j] = j < A_ ? cx.action[(e_ * A_ + j) * T_ + t_] : 0;
+                                for (int j = 0; j < CMAXA; ++j) u[j] = j < A_ ? cx.action[(e_ * A_ + j) * T_ + t_] : 0;
                                 const float* tb = tabs + 4 * c4;
-                                float4 Q[COMA_EPI_MAXA - 1];  // Q[j-1]: agent j's action in the column block the agents before it see
+                                float4 Q[CMAXA - 1];  // Q[j-1]: agent j's action in the column block the agents before it see
 #pragma unroll
-                                for (int j = 1; j < COMA_EPI_MAXA; ++j)
+                                for (int j = 1; j < CMAXA; ++j)
                                     Q[j - 1] = j < A_ ? *reinterpret_cast<const float4*>(tb + ((j - 1) * Ka + u[j]) * TLD) : make_float4(0.f, 0.f, 0.f, 0.f);
                                 float4 pre = t;  // S + the blocks of the agents 0 .. a-1 (as the agents behind them see them)
 #pragma unroll
-                                for (int ag = 0; ag < COMA_EPI_MAXA; ++ag) {
+                                for (int ag = 0; ag < CMAXA; ++ag) {
                                     if (ag < A_) {
                                         float4 z = pre;
 #pragma unroll
-                                        for (int j = 1; j < COMA_EPI_MAXA; ++j)
+                                        for (int j = 1; j < CMAXA; ++j)
                                             if (j > ag && j < A_) { z.x += Q[j - 1].x; z.y += Q[j - 1].y; z.z += Q[j - 1].z; z.w += Q[j - 1].w; }
                                         float* yp = Y + ((e_ * A_ + ag) * T_ + t_) * ldy + 4 * c4;
                                         if (vecy && 4 * c4 + 3 < ncols) *reinterpret_cast<float4*>(yp) = z;
@@ -298,6 +300,18 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     if (colsum_part)  // EPI_GATE only: fold the per-workgroup column sums (fixed order)
         hipLaunchKernelGGL(k_reduce_partials, dim3((N + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_GROUPS), 0, s, colsum_part, grid, 32 * nj, 0, N,
                            colsum_out);
+}
+
+// whether the one-launch S + z0 GEMM serves a COMA critic of A agents, Kact actions and row stride hs (LDS: operand tiles + the action table)
+inline bool coma_epi_fits(int A, int Kact, int hs) {
+    const int nj = (hs + 31) / 32;
+    return A <= COMA_EPI_MAXA && nj <= 8 && wide_gemm_lds(nj) + (size_t)(A - 1) * Kact * 32 * nj * sizeof(float) <= 160 * 1024;
+}
+template <int DUMMY = 0>
+inline void wide_gemm_coma(const float* X, long ldx, long rows, int K, const float* W, int ldw, int N, float* Y, long ldy, int ncols, hipStream_t s,
+                           const WideComa& cx) {
+    if (cx.A <= 8) wide_gemm<EPI_COMA>(X, ldx, rows, K, W, ldw, N, nullptr, nullptr, 0, nullptr, 0, Y, ldy, ncols, s, nullptr, nullptr, &cx);
+    else wide_gemm<EPI_COMA16>(X, ldx, rows, K, W, ldw, N, nullptr, nullptr, 0, nullptr, 0, Y, ldy, ncols, s, nullptr, nullptr, &cx);
 }
 
 // Wt[k][n] = W[n][k] (n < N, k < K), row stride ldt >= N, columns N..ldt-1 zeroed

@@ -201,9 +201,10 @@ def test_coma_reference_default_critic_width_runs_and_wider_than_256_fails_loudl
                                                   (5, 1, 7, 12, 12, 4, 32, 0), (4, 10, 6, 115, 243, 17, 64, 1),
                                                   # layered schedule (csrc/cm_mlp_wide.h): the factoring runs once per 64-unit slab
                                                   (9, 3, 11, 10, 14, 5, 128, 1), (6, 5, 9, 40, 200, 12, 96, 3), (7, 4, 8, 21, 54, 5, 256, 0),
-                                                  # 128 units at config-3 shapes (one-launch S + z0 GEMM epilogue, two-slab gather), and with more than 8 agents
-                                                  # (separate k_coma_z0_add<2>, the 32-agent form of the gather)
-                                                  (10, 8, 16, 56, 384, 5, 128, 1), (4, 10, 6, 30, 60, 5, 128, 1),
+                                                  # 128 units at config-3 shapes (one-launch S + z0 GEMM epilogue, two-slab gather); 9 .. 16 agents (the
+                                                  # 16-agent form of that epilogue, the 32-agent form of the gather); 17 agents (separate S GEMM + k_coma_z0_add)
+                                                  (10, 8, 16, 56, 384, 5, 128, 1), (4, 10, 6, 30, 60, 5, 128, 1), (3, 16, 5, 20, 40, 5, 128, 1),
+                                                  (2, 17, 4, 12, 30, 4, 64, 1), (2, 17, 4, 12, 30, 4, 128, 1),
                                                   (5, 3, 6, 12, 30, 4, 48, 3)])
 def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
     """cm_coma_q_forward / cm_coma_critic_fwd_bwd (W0 x = W0o obs + state GEMM + gathered action columns) vs the literal
