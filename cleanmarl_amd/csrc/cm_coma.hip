@@ -375,6 +375,9 @@ inline void gather_launch(const GatherGeom& g, int A, hipStream_t s, const float
     if (A <= 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coma_bwd_gather<VW, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, OH_LDS);
         hipLaunchKernelGGL((k_coma_bwd_gather<VW, 8>), dim3((int)g.blocks), dim3(256), g.lds, s, dz0, action, E, A, T, K, g.wpb, dS, part, h0, ldz, ldS);
+    } else if (A <= 16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coma_bwd_gather<VW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, OH_LDS);
+        hipLaunchKernelGGL((k_coma_bwd_gather<VW, 16>), dim3((int)g.blocks), dim3(256), g.lds, s, dz0, action, E, A, T, K, g.wpb, dS, part, h0, ldz, ldS);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coma_bwd_gather<VW, OH_MAXA>), hipFuncAttributeMaxDynamicSharedMemorySize, OH_LDS);
         hipLaunchKernelGGL((k_coma_bwd_gather<VW, OH_MAXA>), dim3((int)g.blocks), dim3(256), g.lds, s, dz0, action, E, A, T, K, g.wpb, dS, part, h0, ldz, ldS);
