@@ -101,7 +101,7 @@ out = {"metric": "env-steps/sec (agents x envs x steps), COMA full iteration", "
        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "dtype": "f32",
        "data": "synthetic", "config": {"workload": f"COMA synthetic-MPE {E} envs x {A} agents x {T} steps, actor 2x64, critic input {Dc} -> 2x{Hc} -> {K}"},
        "phase_ms": {"rollout_eps_mixed": ph[0], "targets": ph[1], "update": ph[2]}, "kernel_ms": k,
-       "roofline": {"kernel": "cm_coma_critic_fwd_bwd (k_linear_nt + k_coma_z0_add + k_mlp<1,M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)" if Hc <= 64 else "cm_coma_critic_fwd_bwd (k_wide_gemm + k_coma_z0_add + k_mlp128<M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)", "bound": "mfma", "achieved": ach,
+       "roofline": {"kernel": "cm_coma_critic_fwd_bwd (k_wide_gemm<EPI_COMA> (S + z0 in one launch) + k_mlp<1,M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)" if Hc <= 64 else "cm_coma_critic_fwd_bwd (k_wide_gemm<EPI_COMA> (S + z0 in one launch) + k_mlp128<M_QCRITIC> + k_coma_bwd_gather + k_dw0_stream)", "bound": "mfma", "achieved": ach,
                     "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "flop_per_launch": flop, "reference_schedule_flop": flop_ref,
                     "reference_schedule_equiv_tflops": flop_ref / (k["critic_fwd_bwd"] * 1e-3) / 1e12,
                     "algorithmic_bytes_per_launch": rows * (4 * Do + 12) + E * T * 4 * Ds}}
