@@ -418,7 +418,8 @@ inline ComaWs coma_ws(int E, int A, int T, int Ds, int Do, int K, int H, int L, 
     const size_t Pc = (size_t)cm_mlp_param_count(Do, H, L, K);
     ComaWs w; size_t p = 0;
     w.pc = p; p += al64(Pc);
-    w.S = p; p += al64((size_t)et * HP);
+    // S = state W0s^T of the separate-launch path; the one-launch path (EPI_COMA) parks its aligned copy of W0's state block here instead
+    { const size_t s1 = (size_t)et * HP, s2 = (size_t)H * ((Ds + 3) & ~3); w.S = p; p += al64(s1 > s2 ? s1 : s2); }
     w.z0 = p; p += al64((size_t)rows * HP);
     w.dz0 = w.dS = w.gc = w.gs = w.ga = w.part = w.train = p;
     if (train) {
@@ -475,7 +476,7 @@ inline ComaWideWs coma_wide_ws(int E, int A, int T, int Ds, int Do, int K, int H
     ComaWideWs w; size_t p = 0;
     w.Hs = wide_hs(H);
     w.pc = p; p += al64(Pc);
-    w.S = p; p += al64((size_t)et * w.Hs);
+    { const size_t s1 = (size_t)et * w.Hs, s2 = (size_t)H * ((Ds + 3) & ~3); w.S = p; p += al64(s1 > s2 ? s1 : s2); }  // see coma_ws
     w.z0 = p; p += al64((size_t)rows * w.Hs);
     w.dS = w.gc = w.gs = w.ga = w.part = p;
     if (train) {

@@ -205,6 +205,8 @@ def test_coma_reference_default_critic_width_runs_and_wider_than_256_fails_loudl
                                                   # 16-agent form of that epilogue, the 32-agent form of the gather); 17 agents (separate S GEMM + k_coma_z0_add)
                                                   (10, 8, 16, 56, 384, 5, 128, 1), (4, 10, 6, 30, 60, 5, 128, 1), (3, 16, 5, 20, 40, 5, 128, 1),
                                                   (2, 17, 4, 12, 30, 4, 64, 1), (2, 17, 4, 12, 30, 4, 128, 1),
+                                                  # fewer (env, step) rows than state columns: the aligned copy of W0's state block outgrows the S region it is parked in
+                                                  (2, 8, 4, 56, 384, 5, 64, 1), (2, 8, 4, 56, 384, 5, 128, 1), (1, 3, 2, 10, 201, 5, 64, 1), (2, 8, 100, 56, 384, 5, 64, 1),
                                                   (5, 3, 6, 12, 30, 4, 48, 3)])
 def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
     """cm_coma_q_forward / cm_coma_critic_fwd_bwd (W0 x = W0o obs + state GEMM + gathered action columns) vs the literal
