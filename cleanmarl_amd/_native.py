@@ -110,6 +110,7 @@ SIGNATURES = {
     "cm_rollout_spread": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "cm_gru_rollout_spread_supported": (_i, [_i, _i, _i]),
     "cm_gru_rollout_spread": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "cm_gru_rollout_spread_ld": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "cm_rollout_spread_eps": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
     "cm_ppo_actor_issued_flop_per_row": (_d, [_i, _i, _i, _i]),
     "cm_philox4x32_host": (_i, [_p, _l, _p]),

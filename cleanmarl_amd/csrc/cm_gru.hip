@@ -377,6 +377,7 @@ struct GruRollArgs {
     unsigned long long seed, act_seed; long env_offset, episode;
     const float* params; int din, H, K;
     float* obs; float* state; int* action; float* logp; float* reward;
+    long state_ld;  // row stride of `state` (>= 6 A A; the learner's critic reads 16-byte aligned rows when it is a multiple of 4)
     unsigned long long* prof;  // CM_PHASE_PROF builds only
 };
 constexpr float GR_DAMP = 0.25f, GR_DT = 0.1f, GR_ACCEL = 5.0f, GR_COLLIDE = 0.3f;  // cm_env.hip / cm_rollout.hip constants
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gru32_rollout(const GruRollArgs
     const int tid = threadIdx.x;
     const int hrow = tid >> 2, hq = tid & 3;
     const int A = a.A, T = a.T, K = a.K, H = a.H, din = a.din;
-    const int EPT = T32 / A, RT = EPT * A, Ds = 6 * A * A;
+    const int EPT = T32 / A, RT = EPT * A; const long Ds = a.state_ld;  // row stride of the state buffer
     G2W w;  // the seven weight blocks: this wave's 16 hidden columns in registers for the whole episode (cm_gru_step2.h)
     g2_load_weights<false>(w, a.params, off, din, H);
     for (int i = tid; i < KP * HP; i += NTHREADS) {
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(NT6R, 1) void k_gru32_rollout6(const GruRollArgs a)
     const int hl = tid & 63;                   // lane of a helper wave
     const int hrow = tid >> 2, hq = tid & 3;   // compute waves: four lanes per row
     const int A = a.A, T = a.T, K = a.K, H = a.H, din = a.din;
-    const int EPT = T32 / A, RT = EPT * A, Ds = 6 * A * A;
+    const int EPT = T32 / A, RT = EPT * A; const long Ds = a.state_ld;  // row stride of the state buffer
     G2W w;  // the seven weight blocks: this wave's 16 hidden columns in registers for the whole episode (cm_gru_step2.h)
     if (compute) {
         g2_load_weights<false>(w, a.params, off, din, H);
@@ -1297,16 +1298,26 @@ extern "C" int cm_gru_rollout_spread_supported(int A, int agent_ids, int hidden)
     return (A >= 1 && A <= T32 && din <= KC && hidden <= HP) ? 1 : 0;
 }
 
+extern "C" int cm_gru_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                        int64_t env_offset, int64_t episode, const float* params, int hidden,
+                                        float* obs, float* state, int64_t state_ld, int32_t* action, float* logp, float* reward, cm_stream_t stream);
 extern "C" int cm_gru_rollout_spread(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
                                      int64_t env_offset, int64_t episode, const float* params, int hidden,
                                      float* obs, float* state, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
+    return cm_gru_rollout_spread_ld(env_state, E, A, T, agent_ids, seed, act_seed, env_offset, episode, params, hidden, obs, state, 6L * A * A, action,
+                                    logp, reward, stream);
+}
+extern "C" int cm_gru_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,
+                                        int64_t env_offset, int64_t episode, const float* params, int hidden,
+                                        float* obs, float* state, int64_t state_ld, int32_t* action, float* logp, float* reward, cm_stream_t stream) {
     CM_REQUIRE(E > 0 && T > 0, "cm_gru_rollout_spread: bad dims E=%d T=%d", E, T);
+    CM_REQUIRE(state_ld >= 6L * A * A, "cm_gru_rollout_spread_ld: state_ld=%ld below the state width %d", (long)state_ld, 6 * A * A);
     CM_REQUIRE(cm_gru_rollout_spread_supported(A, agent_ids, hidden),
                "cm_gru_rollout_spread: unsupported shape A=%d hidden=%d (use cm_gru_policy_act + cm_synth_env_step)", A, hidden);
     GruRollArgs a = {};
     a.env_state = env_state; a.E = E; a.A = A; a.T = T; a.agent_ids = agent_ids; a.seed = seed; a.act_seed = act_seed;
     a.env_offset = env_offset; a.episode = episode; a.params = params; a.din = 6 * A + (agent_ids ? A : 0); a.H = hidden; a.K = 5;
-    a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward;
+    a.obs = obs; a.state = state; a.action = action; a.logp = logp; a.reward = reward; a.state_ld = (long)state_ld;
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif

@@ -199,7 +199,9 @@ class GRUSyntheticRollout:
         self.seed, self.env_offset, self.device = int(seed), int(env_offset), torch.device(device)
         # two buffers used alternately: the learner's critic epochs (own stream, learner.py) may still read episode i's states and
         # returns while episode i + 1 is being written
-        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+        # the STATE rows are padded to a multiple of 4 floats (the critic's passes then read 16-byte aligned rows: 150 -> 152 floats at 5 agents,
+        # critic epoch 160 -> 111 us at config 5); the observations stay contiguous (the recurrent kernels read them as such)
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device, pad_state=True) for _ in range(2)]
         for bb in self.batches:
             bb.avail.fill_(1)
             bb.ep_len.fill_(T)
@@ -224,11 +226,21 @@ class GRUSyntheticRollout:
             if not can_fuse:
                 raise N.NativeError("fused GRU rollout requested for an unsupported shape")
             act_seed = (self.seed + (self.episode + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
-            N.check(lib.cm_gru_rollout_spread(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed, self.env_offset,
-                                              self.episode, N.ptr(actor_flat), actor_spec.hidden, N.ptr(b.obs), N.ptr(b.state),
-                                              N.ptr(b.action), N.ptr(b.logp), N.ptr(b.reward), s), "cm_gru_rollout_spread")
+            N.check(lib.cm_gru_rollout_spread_ld(N.ptr(self.env_state), E, A, T, int(self.agent_ids), self.seed, act_seed, self.env_offset,
+                                                 self.episode, N.ptr(actor_flat), actor_spec.hidden, N.ptr(b.obs), N.ptr(b.state), b.state_ld,
+                                                 N.ptr(b.action), N.ptr(b.logp), N.ptr(b.reward), s), "cm_gru_rollout_spread_ld")
             self.episode += 1
             return b
+        if b.state_ld != b.Ds:
+            # the per-step env kernels (cm_synth_env_reset / _step) write contiguous rows: shapes the fused kernel does not cover, greedy
+            # evaluation rollouts and explicit fused=False runs switch this rollout to unpadded buffers, once (rollout.py does the same).
+            # The learner's critic epochs may still read the old buffers on their own stream: wait before their storage is released
+            torch.cuda.synchronize(self.device)
+            self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device) for _ in range(2)]
+            for bb in self.batches:
+                bb.avail.fill_(1)
+                bb.ep_len.fill_(T)
+            self.batch = b = self.batches[self.episode & 1]
         if self.h is None:
             self.h = torch.zeros(E * A, actor_spec.hidden, dtype=torch.float32, device=self.device)
         self.h.zero_()
