@@ -36,8 +36,11 @@ class GRUPPOLearner(PPOLearner):
         # pipelined GRU sweeps -- which have no idle CUs any more -- stretches the first chunk of the actor epoch by ~115 us (forward
         # sweep 67 -> 105 us, backward 80 -> 157); beside the rollout it costs 69 us once, however many epochs follow.  Measured
         # (tools/gpu/r03_gru_critic.sh, two runs each): beside 7.33 / 7.34 ms, defer1 7.20 / 7.23, defer2 7.23 / 7.26 (the value pass starts
-        # to wait), defer3 7.30.  CM_GRU_CRITIC is a Python-side A/B hook, not an option of the C-ABI.
-        self.critic_schedule = os.environ.get("CM_GRU_CRITIC", "defer1")
+        # to wait), defer3 7.30.  Round 4, after the state rows were padded to 16 bytes (one-pass critic, 160 -> 111 us alone: two epochs now
+        # fit under the 0.78 ms rollout without the value pass waiting; tools/gpu/r04_cfg5c.sh, three runs each): defer1 7.15 / 7.18 / 7.15,
+        # defer2 7.12 / 7.11 / 7.10, defer3 7.16 (the value pass waits 0.1 ms).  CM_GRU_CRITIC is a Python-side A/B hook, not an option of
+        # the C-ABI.
+        self.critic_schedule = os.environ.get("CM_GRU_CRITIC", "defer2")
         self._parse_schedule(self.critic_schedule)  # a typo fails here, not in the middle of an update
         self._sched_fixed = None
         self._grecs, self._grec_i = None, 0
