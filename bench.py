@@ -440,7 +440,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras and not args.envs:
         try:
-            # the other BASELINE configs (parity-test cases) and the per-GPU shares of the sharded ones, a few steps each, after the
+            # the other BASELINE configs (parity-test cases) and the per-GPU shares of the sharded ones, 20 steps each, after the
             # timed region of the headline config
             others, shares = {}, {}
             full_ms = {args.workload: out["ms_per_step"]}
@@ -448,7 +448,7 @@ def main():
                 if name == args.workload:
                     continue
                 ww = Workload(name, WORKLOADS[name][0], 0, dev)
-                rr = ww.run(5, 2)
+                rr = ww.run(20, 5)  # 20 steps: a 5-step leg charges the deferred critic epochs' tail (joined at the final sync) to too few steps
                 others[name] = dict(summarize(ww, rr), workload=ww.desc)
                 full_ms[name] = rr["ms_per_step"]
                 ww.close()
