@@ -70,6 +70,9 @@ SIGNATURES = {
     "cm_coma_critic_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "cm_coma_q_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_coma_critic_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_coma_actor_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _p, _p, _sz, _p]),
+    "cm_coma_q_forward_ld": (_i, [_p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_coma_critic_fwd_bwd_ld": (_i, [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "cm_polyak_update": (_i, [_p, _p, _l, _d, _p]),
     "cm_policy_act_greedy": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _p, _p, _l, _p]),
     "cm_policy_act_episode": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p]),

@@ -81,10 +81,10 @@ def run(script, argv=None):
     if args.env_type == "synthetic_shape":
         roll = SyntheticShapeRollout(E, A, args.synthetic_steps, obs_raw=args.synthetic_obs, state_dim=args.synthetic_state,
                                      n_actions=args.synthetic_actions, avail_p=args.synthetic_avail_p, seed=args.seed,
-                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset, pad=False)
+                                     agent_ids=args.agent_ids, device=device, env_offset=env_offset)
     elif device_env:
         roll = SyntheticSpreadRollout(E, A, args.synthetic_steps, seed=args.seed, agent_ids=args.agent_ids, device=device,
-                                      env_offset=env_offset, pad=False)  # COMA's kernels read contiguous rows
+                                      env_offset=env_offset)  # padded rows: the COMA entry points take leading dimensions (round 4)
     elif single_env:
         the_env = environment(**dict(fac, index=env_offset))
     elif args.vector_env == "pipe":

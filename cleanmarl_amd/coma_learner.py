@@ -133,9 +133,9 @@ class COMALearner:
     def _q(self, params, avail, out, b, s):
         """Q[E,A,T,K] of Critic(state, obs, actions) without materialising coma_inputs (factored layer 0, csrc/cm_coma.hip)."""
         cs = self.critic_spec
-        N.check(self.lib.cm_coma_q_forward(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(avail) if avail is not None else None,
-                                           b.E, b.A, b.T, b.Ds, b.Do, b.K, cs.hidden, cs.n_layers, N.ptr(params), N.ptr(out),
-                                           N.ptr(self.ws), self.ws.numel(), s), "cm_coma_q_forward")
+        N.check(self.lib.cm_coma_q_forward_ld(N.ptr(b.state), b.state_ld, N.ptr(b.obs), b.obs_ld, N.ptr(b.action),
+                                              N.ptr(avail) if avail is not None else None, b.E, b.A, b.T, b.Ds, b.Do, b.K, cs.hidden, cs.n_layers,
+                                              N.ptr(params), N.ptr(out), N.ptr(self.ws), self.ws.numel(), s), "cm_coma_q_forward_ld")
 
     # ------------------------------------------------------------------ :553-618
     def compute_targets(self, b):
@@ -167,9 +167,9 @@ class COMALearner:
         cs, a = self.critic_spec, self.actor_spec
         Pa, Pc = self.actor.numel(), self.critic.numel()
         # ---- critic step
-        N.check(lib.cm_coma_critic_fwd_bwd(N.ptr(b.state), N.ptr(b.obs), N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, b.Ds,
-                                           b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic), N.ptr(self.ws),
-                                           self.ws.numel(), s), "cm_coma_critic_fwd_bwd")
+        N.check(lib.cm_coma_critic_fwd_bwd_ld(N.ptr(b.state), b.state_ld, N.ptr(b.obs), b.obs_ld, N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len),
+                                              E, A, T, b.Ds, b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic),
+                                              N.ptr(self.ws), self.ws.numel(), s), "cm_coma_critic_fwd_bwd_ld")
         self._allreduce(self.g_critic)
         self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
         self.training_step += 1
@@ -177,16 +177,16 @@ class COMALearner:
             N.check(lib.cm_polyak_update(N.ptr(self.target), N.ptr(self.critic), Pc, hp.polyak, s), "cm_polyak_update")
         # ---- actor step: Q of the UPDATED critic (no availability mask, :655-657), counterfactual advantage
         self._q(self.critic, None, self.q, b, s)
-        N.check(lib.cm_mlp_forward_ws(N.ptr(b.obs), E * A * T, a.din, a.hidden, a.n_layers, K, N.ptr(self.actor), N.ptr(b.avail),
-                                      N.ptr(self.logits), N.ptr(self.ws), self.ws.numel(), s), "cm_mlp_forward_ws")
+        N.check(lib.cm_mlp_forward_ld(N.ptr(b.obs), b.obs_ld, E * A * T, a.din, a.hidden, a.n_layers, K, N.ptr(self.actor), N.ptr(b.avail),
+                                      N.ptr(self.logits), N.ptr(self.ws), self.ws.numel(), s), "cm_mlp_forward_ld")
         N.check(lib.cm_coma_advantage(N.ptr(self.logits), N.ptr(self.q), N.ptr(b.action), N.ptr(b.ep_len), E, A, T, K, N.ptr(b.adv),
                                       N.ptr(self.tstats), N.ptr(self.ws), self.ws.numel(), s), "cm_coma_advantage")
         if hp.normalize_advantage:
             self._allreduce(self.tstats)
             N.check(lib.cm_coma_normalize_adv(N.ptr(b.adv), N.ptr(self.tstats), E, A, T, s), "cm_coma_normalize_adv")
-        N.check(lib.cm_coma_actor_fwd_bwd(N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.adv), N.ptr(b.ep_len), E, A, T, a.din,
-                                          a.hidden, a.n_layers, K, N.ptr(self.actor), hp.entropy_coef, N.ptr(self.g_actor),
-                                          N.ptr(self.ws), self.ws.numel(), s), "cm_coma_actor_fwd_bwd")
+        N.check(lib.cm_coma_actor_fwd_bwd_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), N.ptr(b.action), N.ptr(b.adv), N.ptr(b.ep_len), E, A, T,
+                                             a.din, a.hidden, a.n_layers, K, N.ptr(self.actor), hp.entropy_coef, N.ptr(self.g_actor),
+                                             N.ptr(self.ws), self.ws.numel(), s), "cm_coma_actor_fwd_bwd_ld")
         self._allreduce(self.g_actor)
         self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
         ent_coef, tstep = hp.entropy_coef, self.training_step

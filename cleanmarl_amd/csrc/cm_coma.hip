@@ -438,8 +438,9 @@ inline ComaWs coma_ws(int E, int A, int T, int Ds, int Do, int K, int H, int L, 
 
 // steps a-c shared by the forward and the training entry points: compact params, S, z0_add
 inline int coma_prepare(const float* state, const float* obs, const int32_t* action, int E, int A, int T, int Ds, int Do, int K, int H,
-                        int L, const float* params, float* wsf, const ComaWs& w, hipStream_t s, const char* who) {
+                        int L, const float* params, float* wsf, const ComaWs& w, hipStream_t s, const char* who, long state_ld = 0) {
     (void)obs;
+    if (state_ld <= 0) state_ld = Ds;  // row stride of `state` (the "_ld" entry points; padding columns hold zeros)
     const int Dc = Ds + Do + (A - 1) * K;
     const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc);
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
@@ -449,12 +450,12 @@ inline int coma_prepare(const float* state, const float* obs, const int32_t* act
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
         const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
         hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
-        wide_gemm_coma(state, Ds, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, HP, HP, s, cx);
+        wide_gemm_coma(state, state_ld, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, HP, HP, s, cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }
     const long nt = (et + TM - 1) / TM;
-    hipLaunchKernelGGL(k_linear_nt, dim3((int)(nt < 512 ? nt : 512)), dim3(NTHREADS), 0, s, state, et, (long)Ds, Ds, params, (long)Dc, H, wsf + w.S);
+    hipLaunchKernelGGL(k_linear_nt, dim3((int)(nt < 512 ? nt : 512)), dim3(NTHREADS), 0, s, state, et, state_ld, Ds, params, (long)Dc, H, wsf + w.S);
     CM_CHECK_LAUNCH(who);
     const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
@@ -493,7 +494,8 @@ inline ComaWideWs coma_wide_ws(int E, int A, int T, int Ds, int Do, int K, int H
 }
 
 inline int coma_wide_prepare(const float* state, const int32_t* action, int E, int A, int T, int Ds, int Do, int K, int H, int L,
-                             const float* params, float* wsf, const ComaWideWs& w, hipStream_t s, const char* who) {
+                             const float* params, float* wsf, const ComaWideWs& w, hipStream_t s, const char* who, long state_ld = 0) {
+    if (state_ld <= 0) state_ld = Ds;
     const int Dc = Ds + Do + (A - 1) * K;
     const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc);
     hipLaunchKernelGGL(k_coma_compact_params, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, Do, rest, wsf + w.pc);
@@ -504,11 +506,11 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
         const WideComa cx = {action, params, A, T, K, Dc, Ds + Do, H};
         const int ldp = (Ds + 3) & ~3;  // aligned copy of the state block of W0 in the (unused) S region
         hipLaunchKernelGGL(k_coma_pack_w0s, dim3(64), dim3(256), 0, s, params, H, Dc, Ds, ldp, wsf + w.S);
-        wide_gemm_coma(state, Ds, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, w.Hs, w.Hs, s, cx);
+        wide_gemm_coma(state, state_ld, et, Ds, wsf + w.S, ldp, H, wsf + w.z0, w.Hs, w.Hs, s, cx);
         CM_CHECK_LAUNCH(who);
         return 0;
     }
-    wide_gemm<EPI_NONE>(state, Ds, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.S, w.Hs, w.Hs, s);  // S = state W0s^T
+    wide_gemm<EPI_NONE>(state, state_ld, et, Ds, params, Dc, H, nullptr, nullptr, 0, nullptr, 0, wsf + w.S, w.Hs, w.Hs, s);  // S = state W0s^T
     CM_CHECK_LAUNCH(who);
     const size_t tab_bytes = (size_t)(A - 1) * K * HP * sizeof(float);
     CM_REQUIRE(tab_bytes <= 64 * 1024, "%s: (n_agents - 1) * n_actions = %d exceeds the 256-column LDS table", who, (A - 1) * K);
@@ -530,31 +532,35 @@ inline int coma_wide_prepare(const float* state, const int32_t* action, int E, i
 
 inline int coma_wide_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
                                int Ds, int Do, int K, int H, int L, const float* params, float* q, void* ws, size_t ws_bytes,
-                               hipStream_t s, const char* who) {
+                               hipStream_t s, const char* who, long obs_ld = 0, long state_ld = 0) {
     if (int rc = wide_check(who, Do, H, L, K)) return rc;
+    if (obs_ld <= 0) obs_ld = Do;
     const ComaWideWs w = coma_wide_ws(E, A, T, Ds, Do, K, H, L, false);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
     float* wsf = (float*)ws;
-    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who)) return rc;
+    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who, state_ld)) return rc;
     MlpArgs a = {};
-    a.x = obs; a.x_stride = Do; a.rows = (long)E * A * T; a.din = Do; a.H = H; a.L = L; a.dout = K;
+    a.x = obs; a.x_stride = obs_ld; a.rows = (long)E * A * T; a.din = Do; a.H = H; a.L = L; a.dout = K;
     a.params = wsf + w.pc; a.avail = avail; a.avail_stride = K; a.y = q; a.z0_add = wsf + w.z0;
     return wide_forward(a, wsf + w.train, (w.total - w.train) * sizeof(float), s, who);
 }
 
 inline int coma_wide_critic_fwd_bwd(const float* state, const float* obs, const int32_t* action, const float* target,
                                     const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int K, int H, int L, const float* params,
-                                    float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
+                                    float* grad_and_stats, void* ws, size_t ws_bytes, hipStream_t s, const char* who, long obs_ld = 0,
+                                    long state_ld = 0) {
     if (int rc = wide_check(who, Do, H, L, K)) return rc;
+    if (obs_ld <= 0) obs_ld = Do;
+    if (state_ld <= 0) state_ld = Ds;
     const long rows = (long)E * A * T, et = (long)E * T;
     if (int rc = check_rows(who, rows)) return rc;
     const ComaWideWs w = coma_wide_ws(E, A, T, Ds, Do, K, H, L, true);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total * sizeof(float));
     float* wsf = (float*)ws;
     const int Da = (A - 1) * K, Dc = Ds + Do + Da, DaP = Da > 0 ? Da : 1;
-    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who)) return rc;
+    if (int rc = coma_wide_prepare(state, action, E, A, T, Ds, Do, K, H, L, params, wsf, w, s, who, state_ld)) return rc;
     MlpArgs a = {};
-    a.x = obs; a.x_stride = Do; a.rows = rows; a.din = Do; a.H = H; a.L = L; a.dout = K;
+    a.x = obs; a.x_stride = obs_ld; a.rows = rows; a.din = Do; a.H = H; a.L = L; a.dout = K;
     a.params = wsf + w.pc; a.action = action; a.ret = target; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
     a.z0_add = wsf + w.z0;
     float* dz0 = nullptr;
@@ -589,7 +595,7 @@ inline int coma_wide_critic_fwd_bwd(const float* state, const float* obs, const 
         }
     }
     for (int h0 = 0; h0 < H; h0 += 64)  // state block: dW0s = dS^T state
-        if (int rc = stream_dw<true>(wsf + w.dS + h0, state, et, Ds, min(64, H - h0), wsf + w.part, wsf + w.gs + (size_t)h0 * Ds, s, who, w.Hs, Ds))
+        if (int rc = stream_dw<true>(wsf + w.dS + h0, state, et, Ds, min(64, H - h0), wsf + w.part, wsf + w.gs + (size_t)h0 * Ds, s, who, w.Hs, state_ld))
             return rc;
     const int rest = (int)(cm_mlp_param_count(Dc, H, L, K) - (int64_t)H * Dc) + CM_NUM_STATS;
     hipLaunchKernelGGL(k_coma_scatter_grads, dim3(128), dim3(256), 0, s, wsf + w.gc, wsf + w.gs, wsf + w.ga, H, Dc, Ds, Do, rest, grad_and_stats);
@@ -680,17 +686,29 @@ extern "C" int cm_qcritic_fwd_bwd(const float* x, const int32_t* action, const f
     return run_train<M_QCRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_qcritic_fwd_bwd");
 }
 
+extern "C" int cm_coma_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action, const float* adv,
+                                        const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                                        const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                        cm_stream_t stream);
 extern "C" int cm_coma_actor_fwd_bwd(const float* obs, const uint8_t* avail, const int32_t* action, const float* adv,
                                      const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
                                      const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
                                      cm_stream_t stream) {
+    return cm_coma_actor_fwd_bwd_ld(obs, din, avail, action, adv, ep_len, E, A, T, din, hidden, n_hidden_layers, n_actions, params, entropy_coef,
+                                    grad_and_stats, ws, ws_bytes, stream);
+}
+extern "C" int cm_coma_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action, const float* adv,
+                                        const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                                        const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                        cm_stream_t stream) {
+    CM_REQUIRE(obs_ld >= din, "cm_coma_actor_fwd_bwd_ld: obs_ld=%ld below the width %d", (long)obs_ld, din);
     const bool wide = wide_shape(hidden, n_hidden_layers);  // layered schedule (cm_mlp_wide.h)
     if (!wide) if (int rc = check_shapes("cm_coma_actor_fwd_bwd", din, hidden, n_hidden_layers, n_actions)) return rc;
     CM_REQUIRE(E > 0 && A > 0 && T > 0, "cm_coma_actor_fwd_bwd: bad dims E=%d A=%d T=%d", E, A, T);
     const long rows = (long)E * A * T;
     if (int rc = check_rows("cm_coma_actor_fwd_bwd", rows)) return rc;
     MlpArgs a = {};
-    a.x = obs; a.x_stride = din; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.x = obs; a.x_stride = (long)obs_ld; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = params; a.avail = avail; a.avail_stride = n_actions; a.action = action; a.adv = adv; a.ep_len = ep_len;
     a.A = A; a.T = T; a.per_agent = 1; a.ent_coef = (float)entropy_coef;
     if (wide) return wide_train<M_COMA_ACTOR>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_coma_actor_fwd_bwd");
@@ -703,21 +721,30 @@ extern "C" size_t cm_coma_critic_workspace_bytes(int E, int A, int T, int Ds, in
     return coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, train != 0).total * sizeof(float);
 }
 
+extern "C" int cm_coma_q_forward_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action,
+                                    const uint8_t* avail, int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
+                                    const float* params, float* q, void* ws, size_t ws_bytes, cm_stream_t stream);
 extern "C" int cm_coma_q_forward(const float* state, const float* obs, const int32_t* action, const uint8_t* avail, int E, int A, int T,
                                  int Ds, int Do, int n_actions, int hidden, int n_hidden_layers, const float* params, float* q, void* ws,
                                  size_t ws_bytes, cm_stream_t stream) {
+    return cm_coma_q_forward_ld(state, Ds, obs, Do, action, avail, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, q, ws, ws_bytes, stream);
+}
+extern "C" int cm_coma_q_forward_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action,
+                                    const uint8_t* avail, int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
+                                    const float* params, float* q, void* ws, size_t ws_bytes, cm_stream_t stream) {
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_q_forward: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    CM_REQUIRE(state_ld >= Ds && obs_ld >= Do, "cm_coma_q_forward_ld: leading dimensions %ld / %ld below the widths %d / %d", (long)state_ld, (long)obs_ld, Ds, Do);
     if (wide_shape(hidden, n_hidden_layers))
         return coma_wide_q_forward(state, obs, action, avail, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, q, ws, ws_bytes,
-                                   (hipStream_t)stream, "cm_coma_q_forward");
+                                   (hipStream_t)stream, "cm_coma_q_forward", (long)obs_ld, (long)state_ld);
     if (int rc = check_shapes("cm_coma_q_forward", Do, hidden, n_hidden_layers, n_actions)) return rc;
     const ComaWs w = coma_ws(E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, false);
     CM_REQUIRE(ws && ws_bytes >= w.total * sizeof(float), "cm_coma_q_forward: workspace too small (%zu < %zu)", ws_bytes, w.total * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     float* wsf = (float*)ws;
-    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, wsf, w, s, "cm_coma_q_forward")) return rc;
+    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params, wsf, w, s, "cm_coma_q_forward", (long)state_ld)) return rc;
     MlpArgs a = {};
-    a.x = obs; a.x_stride = Do; a.rows = (long)E * A * T; a.din = Do; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
+    a.x = obs; a.x_stride = (long)obs_ld; a.rows = (long)E * A * T; a.din = Do; a.H = hidden; a.L = n_hidden_layers; a.dout = n_actions;
     a.params = wsf + w.pc; a.avail = avail; a.avail_stride = n_actions; a.y = q; a.z0_add = wsf + w.z0;
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     launch_infer<M_FWD>(a, grid_for(a.rows), lds_bytes, s);
@@ -725,15 +752,27 @@ extern "C" int cm_coma_q_forward(const float* state, const float* obs, const int
     return 0;
 }
 
+extern "C" int cm_coma_critic_fwd_bwd_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action,
+                                         const float* target, const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
+                                         int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                         cm_stream_t stream);
 extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, const int32_t* action, const float* target,
                                       const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
                                       int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
                                       cm_stream_t stream) {
+    return cm_coma_critic_fwd_bwd_ld(state, Ds, obs, Do, action, target, ep_len, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params,
+                                     grad_and_stats, ws, ws_bytes, stream);
+}
+extern "C" int cm_coma_critic_fwd_bwd_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action,
+                                         const float* target, const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
+                                         int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
+                                         cm_stream_t stream) {
     const char* who = "cm_coma_critic_fwd_bwd";
     CM_REQUIRE(E > 0 && A > 0 && T > 0 && Ds > 0, "cm_coma_critic_fwd_bwd: bad dims E=%d A=%d T=%d Ds=%d", E, A, T, Ds);
+    CM_REQUIRE(state_ld >= Ds && obs_ld >= Do, "cm_coma_critic_fwd_bwd_ld: leading dimensions %ld / %ld below the widths %d / %d", (long)state_ld, (long)obs_ld, Ds, Do);
     if (wide_shape(hidden, n_hidden_layers))
         return coma_wide_critic_fwd_bwd(state, obs, action, target, ep_len, E, A, T, Ds, Do, n_actions, hidden, n_hidden_layers, params,
-                                        grad_and_stats, ws, ws_bytes, (hipStream_t)stream, who);
+                                        grad_and_stats, ws, ws_bytes, (hipStream_t)stream, who, (long)obs_ld, (long)state_ld);
     if (int rc = check_shapes(who, Do, hidden, n_hidden_layers, n_actions)) return rc;
     const long rows = (long)E * A * T;
     if (int rc = check_rows(who, rows)) return rc;
@@ -742,9 +781,9 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
     hipStream_t s = (hipStream_t)stream;
     float* wsf = (float*)ws;
     const int K = n_actions, H = hidden, Da = (A - 1) * K, Dc = Ds + Do + Da;
-    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, K, H, n_hidden_layers, params, wsf, w, s, who)) return rc;
+    if (int rc = coma_prepare(state, obs, action, E, A, T, Ds, Do, K, H, n_hidden_layers, params, wsf, w, s, who, (long)state_ld)) return rc;
     MlpArgs a = {};
-    a.x = obs; a.x_stride = Do; a.rows = rows; a.din = Do; a.H = H; a.L = n_hidden_layers; a.dout = K;
+    a.x = obs; a.x_stride = (long)obs_ld; a.rows = rows; a.din = Do; a.H = H; a.L = n_hidden_layers; a.dout = K;
     a.params = wsf + w.pc; a.action = action; a.ret = target; a.ep_len = ep_len; a.A = A; a.T = T; a.per_agent = 1;
     a.z0_add = wsf + w.z0; a.dz0 = wsf + w.dz0;
     if (int rc = run_train<M_QCRITIC>(a, wsf + w.gc, wsf + w.train, (w.total - w.train) * sizeof(float), s, who)) return rc;
@@ -770,7 +809,7 @@ extern "C" int cm_coma_critic_fwd_bwd(const float* state, const float* obs, cons
         }
     }
     // state block: dW0s = dS^T state
-    if (int rc = stream_dw(wsf + w.dS, state, et, Ds, H, wsf + w.part, wsf + w.gs, s, who)) return rc;
+    if (int rc = stream_dw(wsf + w.dS, state, et, Ds, H, wsf + w.part, wsf + w.gs, s, who, HP, (long)state_ld)) return rc;
     const int rest = (int)(cm_mlp_param_count(Dc, H, n_hidden_layers, K) - (int64_t)H * Dc) + CM_NUM_STATS;
     hipLaunchKernelGGL(k_coma_scatter_grads, dim3(128), dim3(256), 0, s, wsf + w.gc, wsf + w.gs, wsf + w.ga, H, Dc, Ds, Do, rest, grad_and_stats);
     CM_CHECK_LAUNCH(who);

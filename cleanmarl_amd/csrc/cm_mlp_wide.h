@@ -272,8 +272,12 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     const int nj = (max(N, ncols) + 31) / 32;
     const WideComa cx = coma ? *coma : WideComa{};
     const size_t tab_bytes = coma ? (size_t)(cx.A - 1) * cx.Kact * 32 * nj * sizeof(float) : 0;
-    const int vecx = (ldx % 4 == 0 && K % 4 == 0 && al16(X)) ? 1 : 0;
-    const int vecw = (ldw % 4 == 0 && K % 4 == 0 && al16(W)) ? 1 : 0;
+    // 16-byte loads: aligned rows whose last float4 of the contraction stays inside the row -- K a multiple of 4, or a padded leading
+    // dimension (the "_ld" contract: padding columns hold finite values, zeros wherever the library writes them; a tail product is then
+    // 0 x finite, and the operand loaded element-wise is zero-filled beyond K anyway)
+    const long k4 = (K + 3) & ~3;
+    const int vecx = (ldx % 4 == 0 && (K % 4 == 0 || ldx >= k4) && al16(X)) ? 1 : 0;
+    const int vecw = (ldw % 4 == 0 && (K % 4 == 0 || (long)ldw >= k4) && al16(W)) ? 1 : 0;
     const int vecy = (ldy % 4 == 0 && al16(Y)) ? 1 : 0;
     const int vecg = (gate && ldg % 4 == 0 && al16(gate)) ? 1 : 0;
     const long ntiles = (rows + WT_M - 1) / WT_M;

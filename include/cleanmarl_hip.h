@@ -445,6 +445,21 @@ int cm_coma_critic_fwd_bwd(const float* state, const float* obs, const int32_t* 
                            const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden,
                            int n_hidden_layers, const float* params, float* grad_and_stats, void* ws, size_t ws_bytes,
                            cm_stream_t stream);
+/* "_ld" variants of the three COMA entry points that read observations / states: row strides obs_ld >= Do and state_ld >= Ds (floats) instead
+ * of contiguous rows, so that COMA runs on the padded buffers of the device rollouts (cleanmarl_amd.learner.DeviceBatch: leading dimensions
+ * rounded up to 4 floats -- 16-byte aligned rows for every kernel of the path, and the six-wave rollout instead of the four-wave one; at the
+ * reference's default 3-agent simple_spread shapes the rows are 21 / 54 floats).  Padding columns must hold finite values (zeros wherever the
+ * library writes them).  The plain entry points above are these with obs_ld = Do, state_ld = Ds. */
+int cm_coma_q_forward_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action, const uint8_t* avail,
+                         int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers, const float* params, float* q,
+                         void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_coma_critic_fwd_bwd_ld(const float* state, int64_t state_ld, const float* obs, int64_t obs_ld, const int32_t* action, const float* target,
+                              const int32_t* ep_len, int E, int A, int T, int Ds, int Do, int n_actions, int hidden, int n_hidden_layers,
+                              const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_coma_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action, const float* adv,
+                             const int32_t* ep_len, int E, int A, int T, int din, int hidden, int n_hidden_layers, int n_actions,
+                             const float* params, double entropy_coef, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+
 /* soft_update (coma_multienvs.py:266-270): target = polyak * src + (1 - polyak) * target. */
 int cm_polyak_update(float* target, const float* src, int64_t n, double polyak, cm_stream_t stream);
 

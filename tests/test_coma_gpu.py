@@ -16,12 +16,12 @@ def _err(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
-def _learner(batch, ap, cp, hp, dev, reward=None, target=None):
+def _learner(batch, ap, cp, hp, dev, reward=None, target=None, pad=False):
     from cleanmarl_amd.coma_learner import COMAHParams, COMALearner
     from cleanmarl_amd.learner import DeviceBatch, NetSpec, flatten_params
     b = DeviceBatch.from_reference_layout(batch["obs"], batch["actions"], torch.zeros(batch["actions"].shape), 
                                           batch["reward"] if reward is None else reward, batch["states"], batch["avail"],
-                                          batch["mask"], dev)
+                                          batch["mask"], dev, pad=pad)
     H = COMAHParams(gamma=hp["gamma"], td_lambda=hp["td_lambda"], normalize_reward=bool(hp["normalize_reward"]),
                     normalize_advantage=bool(hp["normalize_advantage"]), normalize_return=bool(hp["normalize_return"]),
                     target_network_update_freq=int(hp["target_network_update_freq"]), polyak=hp["polyak"],
@@ -115,6 +115,46 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
         assert _err(rec["actor_grads"].cpu().numpy(), ref["actor_grads"].numpy()) <= TOL, it
         assert _err(L.critic.cpu().numpy(), R.flat(cp).numpy()) <= TOL and _err(L.actor.cpu().numpy(), R.flat(ap).numpy()) <= TOL, it
         assert _err(L.target.cpu().numpy(), R.flat(tp).numpy()) <= TOL, it
+
+
+@pytest.mark.parametrize("E,A,T,Do,Ds,K,Hc", [
+    (33, 3, 16, 21, 54, 5, 64),     # the reference's default simple_spread shapes (3 agents): rows of 21 / 54 floats
+    (33, 3, 16, 21, 54, 5, 128),    # ... with its default 128-wide critic (one-launch S + z0 GEMM on a padded state, fused 128-wide tiles)
+    (12, 5, 9, 35, 150, 5, 64),     # 5 agents: 35 / 150 floats
+    (6, 2, 7, 13, 27, 7, 96),       # odd everything, layered-critic width
+])
+def test_coma_on_padded_rollout_buffers_matches_oracle_and_the_contiguous_run(E, A, T, Do, Ds, K, Hc):
+    """The "_ld" COMA entry points (cm_coma_q_forward_ld / cm_coma_critic_fwd_bwd_ld / cm_coma_actor_fwd_bwd_ld + cm_mlp_forward_ld) on the
+    padded buffers of the device rollouts (leading dimensions rounded up to 4 floats, zero padding): same oracle bar, and the same numbers
+    as the run on contiguous rows (vector vs scalar loads of the same values: only the k_wide_gemm tail group may re-associate)."""
+    from oracle import coma as C
+    from oracle import restatement as R
+    batch, ap, cp, tp = _seeded(E * 3 + K, E, A, T, Do, Ds, K, 64, Hc, 1, 1)
+    hp = dict(gamma=0.99, td_lambda=0.8, normalize_reward=0.0, normalize_advantage=1.0, normalize_return=1.0,
+              target_network_update_freq=1.0, polyak=0.1, entropy_coef=0.01, use_tdlamda=1.0, nsteps=3.0, clip_gradients=0.5,
+              optimizer="Adam", learning_rate_actor=5e-4, learning_rate_critic=5e-4)
+    dev = torch.device("cuda:0")
+    runs = {}
+    for pad in (False, True):
+        L, b = _learner(batch, [p.clone() for p in ap], [p.clone() for p in cp], hp, dev, target=[p.clone() for p in tp], pad=pad)
+        assert (b.obs_ld % 4 == 0 and b.state_ld % 4 == 0) == pad or (Do % 4 == 0 and Ds % 4 == 0)
+        recs = [L.train_iteration(b, keep_grads=True) for _ in range(2)]
+        runs[pad] = (recs, L.critic.clone(), L.actor.clone(), L.target.clone(), b.ret.clone(), b.adv.clone())
+    oa, oc = R.AdamState(ap, 5e-4, "Adam"), R.AdamState(cp, 5e-4, "Adam")
+    ts = 0
+    for it in range(2):
+        ref = C.update(ap, cp, tp, batch, hp, oa, oc, ts)
+        ts = ref["training_step"]
+        for pad in (False, True):
+            rec = runs[pad][0][it]
+            assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, (pad, it)
+            assert _err(rec["critic_grads"].cpu().numpy(), ref["critic_grads"].numpy()) <= TOL, (pad, it)
+            assert _err(rec["actor_grads"].cpu().numpy(), ref["actor_grads"].numpy()) <= TOL, (pad, it)
+    for pad in (False, True):
+        assert _err(runs[pad][1].cpu().numpy(), R.flat(cp).numpy()) <= TOL and _err(runs[pad][2].cpu().numpy(), R.flat(ap).numpy()) <= TOL
+        assert _err(runs[pad][3].cpu().numpy(), R.flat(tp).numpy()) <= TOL
+    for x, y in zip(runs[False][1:], runs[True][1:]):
+        assert _err(x.cpu().numpy(), y.cpu().numpy()) <= 2e-6
 
 
 def test_coma_inputs_and_gather_are_exact():

@@ -31,7 +31,7 @@ ap.add_argument("--critic-hidden", type=int, default=64, help="critic width (the
 args = ap.parse_args()
 E, A, T = args.envs, args.agents, args.T
 dev = torch.device("cuda:0")
-roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev, pad=False)  # COMA's kernels read contiguous rows
+roll = SyntheticSpreadRollout(E, A, T, seed=1, agent_ids=True, device=dev)  # padded rows: the COMA entry points take leading dimensions
 Do, Ds, K = roll.Do, roll.Ds, roll.K
 Dc = coma_critic_input_dim(Do, Ds, A, K)
 Hc = args.critic_hidden
