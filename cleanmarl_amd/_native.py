@@ -98,7 +98,7 @@ SIGNATURES = {
     "cm_peer_mailbox_close": (_i, [_p]),
     "cm_peer_mailbox_free": (_i, [_p]),
     "cm_peer_push": (_i, [_p, _l, _i, _i, C.POINTER(_p), C.c_uint32, _p]),
-    "cm_optimizer_step_peer": (_i, [_p, _l, _p, _i, C.c_uint32, _po, _p]),
+    "cm_optimizer_step_peer": (_i, [_p, _l, _p, _i, C.c_uint32, _po, _d, _p, _p]),
     "cm_gru_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "cm_gru_actor_chunk_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _d, _d,
                                         _p, _p, _sz, _p]),

@@ -100,6 +100,8 @@ class Args:
     """ [build] write the checkpoint every N training iterations (0 = only at the end)"""
     greedy_eval: bool = False
     """ [build] evaluate with argmax actions instead of sampling (MLP actors; the reference always samples)"""
+    eval_live_envs: int = 0
+    """ [build] host-env evaluation: at most this many evaluation envs alive at once per rank, episodes played in waves (0 = all num_eval_ep side by side; 1 = the reference's sequential evaluation, for heavy envs)"""
 
 
 @dataclass
@@ -188,6 +190,8 @@ class ComaArgs:
     checkpoint_every: int = 0
     greedy_eval: bool = False
     """ [build] evaluate with argmax actions instead of sampling with eps = 0 (the reference samples, coma_multienvs.py:703-709)"""
+    eval_live_envs: int = 0
+    """ [build] host-env evaluation: at most this many evaluation envs alive at once per rank (0 = all side by side; 1 = sequential)"""
 
 
 # per-script default overrides (SURVEY.md Appendix B)

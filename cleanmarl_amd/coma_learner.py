@@ -117,9 +117,22 @@ class COMALearner:
         self._shape = shape
 
     def _moments(self, x, ep_len, E, A, T, s):
-        N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.ws), self.ws.numel(), s),
-                "cm_masked_moments")
+        if E == 0:
+            self.moments.zero_()
+        else:
+            N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.ws), self.ws.numel(), s),
+                    "cm_masked_moments")
         dist.merge_moments_(self.moments, self.pg, self.world)
+
+    def _empty_shard(self, b):
+        """A rank of an env-sharded run that owns no environments (fewer envs than ranks): no kernel is launched, its [gradient |
+        statistics] buffers, moment triples and per-time-step advantage sums are zero, every collective and optimiser step still happens
+        (same contract as learner.PPOLearner._empty_shard)."""
+        if b.E > 0:
+            return False
+        if not self._coll or self.world <= 1:
+            raise N.NativeError("empty batch (0 environments): only a rank of an env-sharded run (world size > 1) may own no environments")
+        return True
 
     def _adam(self, params, g, opt, which, s):
         """norm_d + clip_grad_norm_ + optimizer.step() as one launch on the (all-reduced) gradient buffer."""
@@ -141,8 +154,13 @@ class COMALearner:
     def compute_targets(self, b):
         N.sync_env_options()
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
-        self._ensure(b)
         E, A, T, K = b.E, b.A, b.T, b.K
+        if self._empty_shard(b):
+            for on, Am in ((hp.normalize_reward, 1), (hp.normalize_return, A)):
+                if on:
+                    self._moments(None, None, 0, Am, T, s)
+            return
+        self._ensure(b)
         if hp.normalize_reward:  # RolloutBuffer.get_batch, :151-154
             self._moments(b.reward, b.ep_len, E, 1, T, s)
             N.check(lib.cm_normalize(N.ptr(b.reward), N.ptr(b.ep_len), E, 1, T, N.ptr(self.moments), 1e-6, 1, s), "cm_normalize")
@@ -162,10 +180,12 @@ class COMALearner:
     def update(self, b, keep_grads=False):
         N.sync_env_options()
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
-        self._ensure(b)
         E, A, T, K = b.E, b.A, b.T, b.K
         cs, a = self.critic_spec, self.actor_spec
         Pa, Pc = self.actor.numel(), self.critic.numel()
+        if self._empty_shard(b):
+            return self._update_empty(b, keep_grads)
+        self._ensure(b)
         # ---- critic step
         N.check(lib.cm_coma_critic_fwd_bwd_ld(N.ptr(b.state), b.state_ld, N.ptr(b.obs), b.obs_ld, N.ptr(b.action), N.ptr(b.ret), N.ptr(b.ep_len),
                                               E, A, T, b.Ds, b.Do, K, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.g_critic),
@@ -189,6 +209,30 @@ class COMALearner:
                                              N.ptr(self.ws), self.ws.numel(), s), "cm_coma_actor_fwd_bwd_ld")
         self._allreduce(self.g_actor)
         self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
+        return self._records(keep_grads)
+
+    def _update_empty(self, b, keep_grads):
+        """update() of a rank without environments: the same collectives and steps on all-zero contributions."""
+        lib, hp, s = self.lib, self.hp, N.stream_ptr()
+        self.g_critic.zero_()
+        self._allreduce(self.g_critic)
+        self._adam(self.critic, self.g_critic, self.opt_c, 1, s)
+        self.training_step += 1
+        if self.training_step % int(hp.target_network_update_freq) == 0:
+            N.check(lib.cm_polyak_update(N.ptr(self.target), N.ptr(self.critic), self.critic.numel(), hp.polyak, s), "cm_polyak_update")
+        if hp.normalize_advantage:
+            if getattr(self, "tstats", None) is None or self.tstats.shape[0] != b.T:
+                self.tstats = torch.zeros(b.T, 4, dtype=torch.float64, device=self.device)
+            self.tstats.zero_()
+            self._allreduce(self.tstats)
+        self.g_actor.zero_()
+        self._allreduce(self.g_actor)
+        self._adam(self.actor, self.g_actor, self.opt_a, 0, s)
+        return self._records(keep_grads)
+
+    def _records(self, keep_grads):
+        hp = self.hp
+        Pa, Pc = self.actor.numel(), self.critic.numel()
         ent_coef, tstep = hp.entropy_coef, self.training_step
         extra = dict(actor_grads=self.g_actor[:Pa].clone(), critic_grads=self.g_critic[:Pc].clone()) if keep_grads else {}
 

@@ -23,11 +23,13 @@ int cm_option(int which);
 
 // fold per-workgroup partial gradient rows and apply the optimiser step in one launch (cm_optim.hip); part2 / isplit: a second partial
 // set holding columns [0, isplit) (the split critic's streamed dW0), NULL if none
-// peer_tags != NULL (cm_peer.hip): the np1 partial rows are mailbox slots written by peer GPUs; the launch first waits until the np1 tag
-// words equal peer_seq and reads the rows with system-scope loads
+// peer_tags != NULL (cm_peer.hip): the np1 partial rows are mailbox slots written by peer GPUs; the launch first waits (at most
+// peer_timeout_s of wall time; <= 0: 30 s) until the np1 tag words equal peer_seq and reads the rows with system-scope loads; a wait that
+// runs out skips the step and writes peer_seq to *peer_status (optional, host-visible)
 int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
                           float* grad_and_stats, const cm_opt_step_t* opt, hipStream_t s, const char* who,
-                          const unsigned long long* peer_tags = nullptr, unsigned peer_seq = 0);
+                          const unsigned long long* peer_tags = nullptr, unsigned peer_seq = 0, double peer_timeout_s = 0.0,
+                          unsigned* peer_status = nullptr);
 
 // layered GRU schedule (cm_gru_wide.hip): obs wider than 64 columns and / or 65..256 hidden units
 size_t cm_gru_wide_ws_bytes(int64_t R, int chunk_len, int din, int H, int K, int train);

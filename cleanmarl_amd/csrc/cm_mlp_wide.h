@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < rows) {
                     const float* p = X + row * ldx + k0;
-                    if (vecx) { if (k0 < K) v = *reinterpret_cast<const float4*>(p); }
+                    if (vecx) { if (k0 < K) { v = *reinterpret_cast<const float4*>(p); if (k0 + 3 >= K) { if (k0 + 1 >= K) v.y = 0.f; if (k0 + 2 >= K) v.z = 0.f; v.w = 0.f; } } }
                     else {
                         if (k0 < K) v.x = p[0];
                         if (k0 + 1 < K) v.y = p[1];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NTHREADS, (NJ > 6 ? 1 : 2)) void k_wide_gemm(const 
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < N) {
                     const float* p = W + (long)n * ldw + k0;
-                    if (vecw) { if (k0 < K) v = *reinterpret_cast<const float4*>(p); }
+                    if (vecw) { if (k0 < K) { v = *reinterpret_cast<const float4*>(p); if (k0 + 3 >= K) { if (k0 + 1 >= K) v.y = 0.f; if (k0 + 2 >= K) v.z = 0.f; v.w = 0.f; } } }
                     else {
                         if (k0 < K) v.x = p[0];
                         if (k0 + 1 < K) v.y = p[1];
@@ -273,8 +273,8 @@ inline void wide_gemm(const float* X, long ldx, long rows, int K, const float* W
     const WideComa cx = coma ? *coma : WideComa{};
     const size_t tab_bytes = coma ? (size_t)(cx.A - 1) * cx.Kact * 32 * nj * sizeof(float) : 0;
     // 16-byte loads: aligned rows whose last float4 of the contraction stays inside the row -- K a multiple of 4, or a padded leading
-    // dimension (the "_ld" contract: padding columns hold finite values, zeros wherever the library writes them; a tail product is then
-    // 0 x finite, and the operand loaded element-wise is zero-filled beyond K anyway)
+    // dimension.  The lanes of the tail quad beyond K are zeroed AFTER the load (a few v_cndmask in the last chunk only), so the padding
+    // columns of a caller's buffer may hold anything -- torch.empty garbage, Inf, NaN -- without reaching a product
     const long k4 = (K + 3) & ~3;
     const int vecx = (ldx % 4 == 0 && (K % 4 == 0 || ldx >= k4) && al16(X)) ? 1 : 0;
     const int vecw = (ldw % 4 == 0 && (K % 4 == 0 || (long)ldw >= k4) && al16(W)) ? 1 : 0;

@@ -57,6 +57,8 @@ struct StepArgs {
     float lr, bc1, beta1, beta2, eps, wd, grad_scale, bc2_sqrt; int kind;
     float* out_norm; unsigned long long* nword; unsigned long long* slots; unsigned tag;
     const unsigned long long* peer_tags; unsigned peer_seq;
+    unsigned long long peer_timeout;  // wall-clock bound of the wait for the peers' tags, in s_memrealtime ticks (100 MHz)
+    unsigned* peer_status;            // optional host-visible word: set to peer_seq by a launch whose wait ran out (the step is then SKIPPED)
 };
 
 // sum of column i over the np partial rows, in the order of k_reduce_partials: row group g takes rows g, g + 16, g + 32, ... into two
@@ -148,18 +150,25 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
     const int c = threadIdx.x & (STEP_COLS - 1), g = threadIdx.x / STEP_COLS;  // g: wave of the workgroup
     bool peer_lost = false;
     if (PEER) {  // the partial rows are mailbox slots: wait until every rank has published this step's (cm_peer.hip)
-        // BOUNDED: a peer that never publishes (a mapping that silently does not reach this GPU, a dead rank) must not leave a kernel
-        // spinning for ever on a box nobody can reset -- after 2^23 polls (seconds; ranks of a healthy run are microseconds apart) the
-        // launch gives up and poisons the step with NaN (parameters, moments, logged norm: loud, never silent)
+        // BOUNDED BY WALL TIME (s_memrealtime: the constant 100 MHz reference clock, whatever the shader clock does): a peer that never
+        // publishes (a mapping that silently does not reach this GPU, a dead rank) must not leave a kernel spinning for ever on a box
+        // nobody can reset -- but a SLOW peer (rank 0 writing a checkpoint, a host-env stall, a first-launch module load, eight
+        // processes time-slicing one GPU in the tests) is healthy, so the bound is generous (default 30 s, cm_optimizer_step_peer's
+        // timeout_s) and the deadline is checked only every 256 polls.  When it does run out the step is SKIPPED -- parameters, moments and
+        // the gradient buffer stay untouched (round 4 poisoned them with NaN, which the next push then spread to every peer) --
+        // and peer_seq is written to the caller's status word, which dist.PeerAllReduce reads on the host and raises on.
         bool lost = false;
         if (threadIdx.x < a.np1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             unsigned polls = 0;
             while (__hip_atomic_load(a.peer_tags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)a.peer_seq) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++polls > (1u << 23)) { lost = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+                if ((++polls & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > a.peer_timeout) { lost = true; break; }
             }
         }
         peer_lost = __syncthreads_or(lost ? 1 : 0) != 0;
+        if (peer_lost && threadIdx.x == 0 && a.peer_status)
+            __hip_atomic_store(a.peer_status, a.peer_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // acquire at system scope, pairing with the pusher's release store of the tag (cm_peer.hip): the slot loads below are relaxed
         // system-scope loads and must not be satisfied from anything older than the tag that certified them.  One fence per
         // workgroup of the OPT-IN peer path only; the default launches (PEER = false) contain no fence (§3.4 of DESIGN.md: why)
@@ -186,16 +195,21 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
     float N;
     if (blockIdx.x == 0) {
         N = __shfl(t, icnt - slab_n * STEP_COLS, 64);
+        // a lost step is skipped by EVERY workgroup: workgroup 0 hands its verdict on in the N word it publishes anyway (NaN = skip)
+        if (PEER && peer_lost) N = __builtin_nanf("");
         if (c == 0) __hip_atomic_store(a.nword, step_word(a.tag, N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         N = 0.f;
         if (c == 0) N = step_wait(a.nword, a.tag);
         N = __shfl(N, 0, 64);
     }
-    const float scale = (PEER && peer_lost) ? __builtin_nanf("") : ((N > 0.0f) ? a.grad_scale / N : 0.0f);
+    const bool skip = PEER && (peer_lost || !(N == N));  // the hand-off words below are still published: nobody may wait for a workgroup that gave up
+    const float scale = (N > 0.0f) ? a.grad_scale / N : 0.0f;
     const float step_size = a.lr / a.bc1;
     float ss = 0.f;
-    if (i < a.n) {
+    if (skip) {
+        ss = 0.f;  // nothing is read back, nothing is written: parameters, moments and the gradient buffer keep their values
+    } else if (i < a.n) {
         const float gi = __fmul_rn(t, scale);
         ss = __fmul_rn(gi, gi);
         if (UPDATE) {
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
     float tot = 0.f;
     for (int j = c; j < (int)gridDim.x; j += STEP_COLS) tot += step_wait(a.slots + j, a.tag);
     tot = cm_wave_sum(tot);
-    if (c == 0) a.out_norm[0] = sqrtf(tot);
+    if (c == 0) a.out_norm[0] = skip ? __builtin_nanf("") : sqrtf(tot);  // the logged norm of a skipped step is NaN (the status word is the error channel)
 }
 
 // plain fold of the same two partial sets (vectors beyond the fused launch's scratch)
@@ -311,7 +325,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_small(const float* __
 __global__ __launch_bounds__(UPD_THREADS) void k_clip_adam_update(
     float* __restrict__ params, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
     float lr, float beta1, float beta2, float eps, float weight_decay, int opt_kind, float max_norm,
-    float grad_scale, float bc1, float bc2_sqrt, const float* __restrict__ norm_in) {
+    float grad_scale, float bc1, float bc2_sqrt, const float* __restrict__ norm_in, int skip_on_nan_norm) {
+    // the peer step (cm_peer.hip) marks a step whose wait for the peers ran out with a NaN norm: nothing may be applied then
+    if (skip_on_nan_norm && !(norm_in[0] == norm_in[0])) return;
     const float N = g[n + CM_STAT_COUNT];
     const float scale = (N > 0.0f) ? grad_scale / N : 0.0f;
     float coef = 1.0f;
@@ -360,7 +376,7 @@ extern "C" size_t cm_opt_step_scratch_bytes(void) { return STEP_SCRATCH_BYTES; }
 // [part1 | part2] partial rows -> grad_and_stats + optimiser step.  part2 == NULL: every column comes from part1.
 int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* part2, int np2, int PS2, int isplit, int64_t n_params,
                           float* grad_and_stats, const cm_opt_step_t* o, hipStream_t s, const char* who,
-                          const unsigned long long* peer_tags, unsigned peer_seq) {
+                          const unsigned long long* peer_tags, unsigned peer_seq, double peer_timeout_s, unsigned* peer_status) {
     if (int rc = opt_check(who, n_params, o)) return rc;
     const int64_t ntot = n_params + CM_NUM_STATS;
     const int grid = (int)((ntot + STEP_COLS - 1) / STEP_COLS);
@@ -384,13 +400,14 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
     a.wd = (float)o->weight_decay; a.grad_scale = (float)o->grad_scale; a.bc2_sqrt = (float)sqrt(bc2); a.kind = o->opt_kind;
     a.out_norm = o->out_norm; a.nword = (unsigned long long*)o->scratch; a.slots = a.nword + 8;
     a.tag = next_step_tag();
-    a.peer_tags = peer_tags; a.peer_seq = peer_seq;
+    a.peer_tags = peer_tags; a.peer_seq = peer_seq; a.peer_status = peer_status;
+    a.peer_timeout = (unsigned long long)((peer_timeout_s > 0.0 ? peer_timeout_s : 30.0) * 1e8);  // s_memrealtime ticks at 100 MHz
     if (o->max_norm > 0.0) {
         if (peer_tags) hipLaunchKernelGGL((k_reduce_step<false, true>), dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         else hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         const int ugrid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(ugrid), dim3(UPD_THREADS), 0, s, o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq,
-                           (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm);
+                           (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm, peer_tags ? 1 : 0);
     } else {
         if (peer_tags) hipLaunchKernelGGL((k_reduce_step<true, true>), dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         else hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
@@ -418,7 +435,7 @@ extern "C" int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, floa
         const int grid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(grid), dim3(UPD_THREADS), 0, (hipStream_t)stream, params, grad_and_stats,
                            exp_avg, exp_avg_sq, (int)n_params, (float)lr, (float)beta1, (float)beta2, (float)eps,
-                           (float)weight_decay, opt_kind, (float)max_norm, (float)grad_scale, (float)bc1, (float)sqrt(bc2), out_norm);
+                           (float)weight_decay, opt_kind, (float)max_norm, (float)grad_scale, (float)bc1, (float)sqrt(bc2), out_norm, 0);
     }
     else
         hipLaunchKernelGGL(k_grad_norm_clip_adam, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grad_and_stats,

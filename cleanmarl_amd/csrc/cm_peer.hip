@@ -8,7 +8,8 @@
 //   push     one launch: the rank copies its reduced buffer into slot [seq & 1][rank] of EVERY mailbox (its own included; peer writes
 //            travel over xGMI), makes them visible system-wide and then publishes the tag word {seq} of that slot in every mailbox;
 //   step     the optimiser-step launch of cm_optim.hip with the mailbox's `world` slots as its partial rows: it first waits for the
-//            `world` tag words of its own mailbox, then folds the slots IN RANK ORDER (every rank the same order: bit-identical
+//            `world` tag words of its own mailbox (bounded by WALL time: a wait that runs out skips the step and raises a host-visible
+//            status word -- see cm_optim.hip), then folds the slots IN RANK ORDER (every rank the same order: bit-identical
 //            parameters on all ranks), scales by grad_scale / N, takes the norm and applies the update.
 // Two slot sets alternate by seq parity: a peer can be at most one step ahead (its push of step s + 2 needs this rank's push of step
 // s + 1, issued after this rank's step s has read its slots).  No collective library call, no host involvement on the data path.
@@ -95,12 +96,14 @@ extern "C" int cm_peer_push(const float* buf, int64_t n_floats, int rank, int wo
 }
 
 // the step launch: partial rows = the slots of this rank's own mailbox (cm_optim.hip waits for their tag words first)
+// timeout_s: wall-time bound of that wait (<= 0: 30 s).  status: optional word in host-visible (page-locked) or device memory; a launch
+// whose wait ran out SKIPS the step (parameters / moments / gradient buffer untouched, logged norm NaN) and writes seq there.
 extern "C" int cm_optimizer_step_peer(float* grad_and_stats, int64_t n_params, void* own_mailbox, int world, uint32_t seq,
-                                      const cm_opt_step_t* opt, cm_stream_t stream) {
+                                      const cm_opt_step_t* opt, double timeout_s, uint32_t* status, cm_stream_t stream) {
     CM_REQUIRE(grad_and_stats && own_mailbox && world >= 1 && world <= 16 && seq != 0, "cm_optimizer_step_peer: bad arguments");
     const size_t npad = peer_npad(n_params + CM_NUM_STATS);
     const float* slots = reinterpret_cast<const float*>((char*)own_mailbox + PEER_HDR) + (size_t)(seq & 1) * world * npad;
     const unsigned long long* tags = reinterpret_cast<const unsigned long long*>(own_mailbox) + (size_t)(seq & 1) * world;
     return cm_launch_reduce_step(slots, world, (int)npad, nullptr, 0, 0, 0, n_params, grad_and_stats, opt, (hipStream_t)stream,
-                                 "cm_optimizer_step_peer", tags, seq);
+                                 "cm_optimizer_step_peer", tags, seq, timeout_s, status);
 }

@@ -75,15 +75,31 @@ class PeerAllReduce:
                 self.boxes[r] = p
                 self._opened.append(p)
         self.seq = 0
+        # wall-time bound of the step kernel's wait for the peers' tags (CM_PEER_TIMEOUT_S, default 30 s: a slow peer -- checkpoint, host-env
+        # stall, module load -- is healthy) and the page-locked word a step whose wait ran out reports through: the kernel SKIPS that step and
+        # writes its seq here; check() raises on it (no host sync: the word lives in host memory)
+        self.timeout_s = float(os.environ.get("CM_PEER_TIMEOUT_S", "30"))
+        self.status = torch.zeros(1, dtype=torch.int32).pin_memory()
         torch.distributed.barrier(group=process_group)  # every mailbox is mapped everywhere before the first push
+
+    def check(self):
+        """Raise if a step of this mailbox gave up waiting for its peers (the kernel skipped it: this rank's parameters are one step behind
+        the others' -- the run cannot continue; restart from the last checkpoint)."""
+        bad = int(self.status[0])
+        if bad:
+            from . import _native as N
+            raise N.NativeError(f"PeerAllReduce: rank {self.rank} waited more than {self.timeout_s:g} s for the gradient slots of optimiser step "
+                                f"{bad} (a peer died, or its mailbox mapping does not reach this GPU); that step was skipped, the replicas "
+                                "have diverged -- restart from the last checkpoint (CM_PEER_TIMEOUT_S raises the bound)")
 
     def step(self, buf, n_params, opt_step, stream_ptr):
         """push `buf` ([n_params + 8] floats) to every mailbox, then the fused fold + optimiser step on the own mailbox."""
         from . import _native as N
+        self.check()  # a step that gave up earlier: stop before anything else is pushed
         self.seq += 1
         N.check(self.lib.cm_peer_push(N.ptr(buf), self.n, self.rank, self.world, self.boxes, self.seq, stream_ptr), "cm_peer_push")
-        N.check(self.lib.cm_optimizer_step_peer(N.ptr(buf), n_params, self.own, self.world, self.seq, opt_step, stream_ptr),
-                "cm_optimizer_step_peer")
+        N.check(self.lib.cm_optimizer_step_peer(N.ptr(buf), n_params, self.own, self.world, self.seq, opt_step, self.timeout_s,
+                                                N.ptr(self.status), stream_ptr), "cm_optimizer_step_peer")
 
     def close(self):
         """Unmap the peers' mailboxes and free the own one -- after a barrier: nobody may still push into a freed mailbox."""

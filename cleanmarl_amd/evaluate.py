@@ -95,7 +95,12 @@ class DeviceEvaluator:
                                               agent_ids=args.agent_ids, device=device, env_offset=base, pad=actor_spec.kind != "gru")
         elif actor_spec.kind == "gru":
             from .gru import GRUSyntheticRollout
-            self.roll = GRUSyntheticRollout(self.n, n_agents, T, seed=args.seed, agent_ids=args.agent_ids, device=device, env_offset=base)
+            # --greedy_eval rollouts take the per-step act path (the fused recurrent rollout has no argmax sampler): contiguous buffers from
+            # the start, so the first launch() neither synchronises the device nor allocates on the evaluation stream
+            self.roll = GRUSyntheticRollout(self.n, n_agents, T, seed=args.seed, agent_ids=args.agent_ids, device=device, env_offset=base,
+                                            pad_state=not getattr(args, "greedy_eval", False))
+            if getattr(args, "greedy_eval", False):  # the per-step path's hidden-state and workspace buffers, allocated here, not in launch()
+                self.roll.h = torch.zeros(self.n * n_agents, actor_spec.hidden, dtype=torch.float32, device=device)
         else:
             self.roll = SyntheticSpreadRollout(self.n, n_agents, T, seed=args.seed, agent_ids=args.agent_ids, device=device, env_offset=base)
         self.stream = eval_stream(device)
@@ -130,7 +135,13 @@ class DeviceEvaluator:
 
 
 class HostEvaluator:
-    """num_eval_ep evaluation episodes of a host env stepped side by side: one act call per time step for all of this rank's episodes."""
+    """num_eval_ep evaluation episodes of a host env stepped side by side: one act call per time step for all of this rank's episodes.
+
+    Host cost: a rank keeps one in-process env per episode slot it owns (the reference reuses ONE eval env sequentially,
+    cleanmarl/mappo_multienvs.py:614-650).  The envs are created on first use, and ``--eval_live_envs=N`` (N > 0) bounds how many are alive
+    at once: the slots are then played in waves of N and a wave's envs are closed before the next wave is built -- N = 1 is the reference's
+    sequential evaluation for heavy envs (smaclite).  The action keys do not depend on the wave size (row = global slot x agent), so every
+    setting plays the same episodes on the counter-keyed envs."""
 
     def __init__(self, make_env, first_env, host_actor, args, n_agents, recurrent, device, batch_size, rank=0, world=1, pg=None):
         """make_env(index) -> CommonInterface env; first_env: the script's eval_env (index eval_base), reused as episode slot 0."""
@@ -140,51 +151,73 @@ class HostEvaluator:
         self.rank, self.world, self.pg = rank, world, pg
         self.per = (self.n + world - 1) // world
         self.mine = list(range(min(self.n, rank * self.per), min(self.n, (rank + 1) * self.per)))  # a contiguous block of episode slots
-        self.envs = {j: (first_env if j == 0 else make_env(self.base + j)) for j in self.mine}
+        self.make_env, self.first_env = make_env, first_env
+        self.max_live = max(0, int(getattr(args, "eval_live_envs", 0) or 0))
+        self.envs = {}  # slot -> env, created on first use (_env)
         self.smaclite = args.env_type == "smaclite"
-        self.record, self.actions = False, None  # tests: the actions of the last round, [t][slot][agent]
+        self.record, self.actions = False, None  # tests: the actions of the last round, [wave * t][slot of the wave][agent]
 
-    def close(self):
-        for j, e in self.envs.items():
-            if j != 0:  # slot 0 is the caller's eval_env
+    def _env(self, j):
+        if j not in self.envs:
+            self.envs[j] = self.first_env if j == 0 else self.make_env(self.base + j)
+        return self.envs[j]
+
+    def _release(self, slots):
+        for j in slots:
+            e = self.envs.pop(j, None)
+            if e is not None and j != 0:  # slot 0 is the caller's eval_env
                 e.close()
 
-    def run(self, round_index, greedy=False, eps=0.0):
-        """Evaluation round `round_index`: every slot plays one episode.  The act call always carries ALL of this rank's slots (finished
+    def close(self):
+        self._release(list(self.envs))
+
+    def _play(self, slots, round_index, greedy, eps, seed):
+        """One wave: the episodes of `slots` (contiguous) side by side.  The act call always carries ALL of the wave's slots (finished
         episodes ride along with their last observation, their actions are dropped): row (base + j) * A + a of step t is keyed the same
-        whatever the other episodes do and however the slots are dealt over ranks -- and exactly like the device evaluator's rollout."""
-        A, slots = self.A, self.mine
+        whatever the other episodes do, however the slots are dealt over ranks and waves -- exactly like the device evaluator's rollout."""
+        A = self.A
+        envs = {j: self._env(j) for j in slots}
+        for j in slots:
+            if hasattr(envs[j], "episode"):  # the counter-keyed CPU twins: round n IS episode n of env base + j (resume-safe)
+                envs[j].episode = int(round_index) - 1
+        obs = {j: envs[j].reset()[0] for j in slots}
+        ret = {j: 0.0 for j in slots}; length = {j: 0 for j in slots}; info = {j: None for j in slots}
+        alive = set(slots)
+        h, t = None, 0
+        while alive:
+            x = np.stack([np.asarray(obs[j], np.float32) for j in slots])
+            av = np.stack([np.asarray(envs[j].get_avail_actions()) for j in slots])
+            act, _, h = self.actor.act(x, av, h=h, seed=seed, greedy=greedy, eps=eps, t=t, row_offset=(self.base + slots[0]) * A)
+            act = np.asarray(act).reshape(len(slots), A)
+            if self.record:
+                self.actions.append(act.copy())
+            for i, j in enumerate(slots):
+                if j not in alive:
+                    continue
+                o, rew, done, trunc, inf = envs[j].step(act[i])
+                ret[j] += rew; length[j] += 1
+                if done or trunc:
+                    info[j] = inf
+                    alive.discard(j)
+                else:
+                    obs[j] = o
+            t += 1
+        won = [float(info[j]["battle_won"]) if self.smaclite else 0.0 for j in slots]
+        return [ret[j] for j in slots], [float(length[j]) for j in slots], won
+
+    def run(self, round_index, greedy=False, eps=0.0):
+        """Evaluation round `round_index`: every slot of this rank plays one episode (in waves of --eval_live_envs when that is set)."""
+        slots = self.mine
         seed = act_seed(self.seed, round_index)
         r, l, won = [], [], []
-        if slots:
-            for j in slots:
-                if hasattr(self.envs[j], "episode"):  # the counter-keyed CPU twins: round n IS episode n of env base + j (resume-safe)
-                    self.envs[j].episode = int(round_index) - 1
-            obs = {j: self.envs[j].reset()[0] for j in slots}
-            ret = {j: 0.0 for j in slots}; length = {j: 0 for j in slots}; info = {j: None for j in slots}
-            alive = set(slots)
-            h, t = None, 0
-            self.actions = []
-            while alive:
-                x = np.stack([np.asarray(obs[j], np.float32) for j in slots])
-                av = np.stack([np.asarray(self.envs[j].get_avail_actions()) for j in slots])
-                act, _, h = self.actor.act(x, av, h=h, seed=seed, greedy=greedy, eps=eps, t=t, row_offset=(self.base + slots[0]) * A)
-                act = np.asarray(act).reshape(len(slots), A)
-                if self.record:
-                    self.actions.append(act.copy())
-                for i, j in enumerate(slots):
-                    if j not in alive:
-                        continue
-                    o, rew, done, trunc, inf = self.envs[j].step(act[i])
-                    ret[j] += rew; length[j] += 1
-                    if done or trunc:
-                        info[j] = inf
-                        alive.discard(j)
-                    else:
-                        obs[j] = o
-                t += 1
-            won = [float(info[j]["battle_won"]) if self.smaclite else 0.0 for j in slots]
-            r, l = [ret[j] for j in slots], [float(length[j]) for j in slots]
+        self.actions = []
+        step = self.max_live if self.max_live > 0 else max(1, len(slots))
+        for w0 in range(0, len(slots), step):
+            wave = slots[w0:w0 + step]
+            rw, lw, ww = self._play(wave, round_index, greedy, eps, seed)
+            r += rw; l += lw; won += ww
+            if self.max_live > 0 and len(slots) > self.max_live:
+                self._release(wave)  # the next wave's envs take their place
         if self.world > 1:  # every rank played its block: gather (slot order, as if one process had played them all)
             loc = torch.full((3, self.per), float("nan"), dtype=torch.float64, device=self.device)
             if slots:

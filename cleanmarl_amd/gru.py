@@ -65,7 +65,9 @@ class GRUPPOLearner(PPOLearner):
     def update(self, b, keep_grads=False):
         N.sync_env_options()
         hp, s, a = self.hp, N.stream_ptr(), self.actor_spec
-        self._ensure(b)
+        empty = self._empty_shard(b)  # a rank without environments: zero buffers, every collective and step (learner.PPOLearner._empty_shard)
+        if not empty:
+            self._ensure(b)
         Pa, Pc = self.actor.numel(), self.critic.numel()
         T, tb = b.T, int(hp.tbptt)
         chunks = [(t0, min(t0 + tb, T)) for t0 in range(0, T, tb)]
@@ -134,6 +136,10 @@ class GRUPPOLearner(PPOLearner):
                         b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(h_in), N.ptr(h_out),
                         hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), o, s),
                         "cm_gru_actor_chunk_train_step")
+                elif empty:
+                    g.zero_()
+                    self._allreduce(g)
+                    self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:])
                 else:
                     N.check(self.lib.cm_gru_actor_chunk_fwd_bwd(
                         N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
@@ -194,7 +200,9 @@ class GRUSyntheticRollout:
     """Synthetic MPE-like env with the GRU actor: T x (cm_gru_policy_act, cm_synth_env_step), hidden state on
     device (reference rollout: cleanmarl/mappo_lstm_multienvs.py:392-479, h = None at the start of each episode)."""
 
-    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0):
+    def __init__(self, E, A, T, seed=1, agent_ids=True, device="cuda:0", env_offset=0, pad_state=True):
+        """pad_state=False: contiguous state rows from the start -- for rollouts that will only ever take the per-step path (greedy
+        evaluation, evaluate.DeviceEvaluator), which would otherwise re-allocate its buffers behind a device synchronisation on first use."""
         self.lib = N.load()
         self.E, self.A, self.T, self.K = E, A, T, 5
         self.agent_ids = bool(agent_ids)
@@ -204,7 +212,7 @@ class GRUSyntheticRollout:
         # returns while episode i + 1 is being written
         # the STATE rows are padded to a multiple of 4 floats (the critic's passes then read 16-byte aligned rows: 150 -> 152 floats at 5 agents,
         # critic epoch 160 -> 111 us at config 5); the observations stay contiguous (the recurrent kernels read them as such)
-        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device, pad_state=True) for _ in range(2)]
+        self.batches = [DeviceBatch(E, A, T, self.Do, self.Ds, self.K, self.device, pad_state=bool(pad_state)) for _ in range(2)]
         for bb in self.batches:
             bb.avail.fill_(1)
             bb.ep_len.fill_(T)

@@ -305,12 +305,26 @@ class PPOLearner:
 
     def _moments(self, x, ep_len, E, A, T, s):
         """(count, mean, M2) of the agent-mean over valid steps; merged across ranks (Chan et al.)."""
-        need = self.lib.cm_masked_moments_workspace_bytes(E, A, T)
-        if self.mom_ws is None or self.mom_ws.numel() < need:
-            self.mom_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.mom_ws),
-                                           self.mom_ws.numel(), s), "cm_masked_moments")
+        if E == 0:  # an empty env shard (fewer envs than ranks): count 0 -- the merge below is still entered by every rank
+            self.moments.zero_()
+        else:
+            need = self.lib.cm_masked_moments_workspace_bytes(E, A, T)
+            if self.mom_ws is None or self.mom_ws.numel() < need:
+                self.mom_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            N.check(self.lib.cm_masked_moments(N.ptr(x), N.ptr(ep_len), E, A, T, N.ptr(self.moments), N.ptr(self.mom_ws),
+                                               self.mom_ws.numel(), s), "cm_masked_moments")
         dist.merge_moments_(self.moments, self.pg, self.world)
+
+    def _empty_shard(self, b):
+        """True when this rank owns no environments (an env-sharded run with fewer envs than ranks).  Such a rank launches no pass: it
+        contributes all-zero [gradient | statistics] buffers (N = 0) and zero-count moments, but enters EVERY collective and applies
+        every optimiser step, so its replicated parameters stay bit-identical to the other ranks'.  Without collectives an empty batch
+        has no meaning: loud error."""
+        if b.E > 0:
+            return False
+        if not self._coll or self.world <= 1:
+            raise N.NativeError("empty batch (0 environments): only a rank of an env-sharded run (world size > 1) may own no environments")
+        return True
 
     # ------------------------------------------------------------------ a6 / a7
     def compute_targets(self, b):
@@ -319,6 +333,12 @@ class PPOLearner:
         lib, hp, s = self.lib, self.hp, N.stream_ptr()
         E, A, T = b.E, b.A, b.T
         cs = self.critic_spec
+        if self._empty_shard(b):  # nothing to compute; the moment merges of the enabled normalisations are collectives: same count, same order
+            self.wait_critic()
+            for on, Am in ((hp.normalize_reward, 1), (hp.normalize_advantage, A), (hp.normalize_return, A)):
+                if on:
+                    self._moments(None, None, 0, Am, T, s)
+            return
         if hp.normalize_reward:  # RolloutBuffer.get_batch, :143-146
             self._moments(b.reward, b.ep_len, E, 1, T, s)
             N.check(lib.cm_normalize(N.ptr(b.reward), N.ptr(b.ep_len), E, 1, T, N.ptr(self.moments), 1e-6, 1, s), "cm_normalize")
@@ -366,6 +386,8 @@ class PPOLearner:
 
     def _ensure_ws(self, b):
         a, c = self.actor_spec, self.critic_spec
+        if b.E == 0:
+            return
         need = self.lib.cm_critic_workspace_bytes(b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, c.din, c.hidden, c.n_layers)
         need = max(need, self.lib.cm_mlp_forward_workspace_bytes(b.E * b.T * (1 if self.algo == "mappo" else b.A), c.din, c.hidden,
                                                                  c.n_layers, 1))
@@ -398,6 +420,9 @@ class PPOLearner:
         the critic's optimiser step then rides on the pass's reduction launch (cm_critic_train_step_ld; one process only: no all-reduce
         can come between the two)."""
         self.wait_critic()  # a no-op on the critic stream itself; any other caller must not race the epochs still in flight there
+        if self._empty_shard(b):
+            (self.g_critic if g is None else g).zero_()
+            return
         self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
@@ -415,6 +440,9 @@ class PPOLearner:
 
     def actor_pass(self, b, s, g=None, step=None):
         """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor).  step: see critic_pass."""
+        if self._empty_shard(b):
+            (self.g_actor if g is None else g).zero_()
+            return
         self._ensure_ws(b)
         a = self.actor_spec
         if step is not None:
@@ -608,7 +636,11 @@ class PPOLearner:
         nE, ent_coef = int(hp.epochs), hp.entropy_coef
         kept = [(ka[0], kc[0], ka[1], kc[1]) for ka, kc in zip(kept_a, kept_c)]
 
+        peers = [p for p in (self.peer_a, self.peer_c) if p is not None]
+
         def build(r):
+            for p in peers:  # the statistics have arrived, so every step of this update has run: did one give up waiting for its peers?
+                p.check()
             out = []
             for ep in range(nE):
                 st_a, st_c = r[ep, :N.NUM_STATS], r[ep, N.NUM_STATS:2 * N.NUM_STATS]

@@ -236,6 +236,10 @@ int cm_critic_train_step_ld(const float* x, int64_t x_ld, const float* ret, cons
  *   2. cm_peer_push: copies that buffer into slot [seq & 1][rank] of EVERY mailbox and then publishes the slot's tag {seq},
  *   3. cm_optimizer_step_peer: one launch that waits for the `world` tags of its OWN mailbox, folds the slots in rank order (every rank
  *      the same order: bit-identical parameters everywhere), scales by grad_scale / N, takes the norm and applies the update.
+ *      The wait is bounded by WALL time (timeout_s seconds of the 100 MHz reference clock; <= 0: 30 s -- generous on purpose: a peer
+ *      that is slow, e.g. writing a checkpoint, is healthy).  A wait that runs out SKIPS the step: parameters, optimiser state and
+ *      grad_and_stats keep their values, out_norm becomes NaN and `seq` is written to *status (optional; a word in page-locked host
+ *      memory or device memory, zero-initialised by the caller) -- the caller reads it on the host and stops the run.
  * seq: 1, 2, 3, ... per mailbox, the same on every rank (two slot sets alternate by its parity; a peer is never more than one step
  * ahead).  Setup (once): cm_peer_mailbox_alloc -> exchange the cm_peer_handle_bytes() handle bytes by any means (torch.distributed
  * all_gather_object in cleanmarl_amd/dist.py) -> cm_peer_mailbox_open per peer.  At most 16 ranks; ranks may share a device. */
@@ -247,7 +251,7 @@ int cm_peer_mailbox_close(void* mailbox);
 int cm_peer_mailbox_free(void* mailbox);
 int cm_peer_push(const float* buf, int64_t n_floats, int rank, int world, void* const* mailboxes, uint32_t seq, cm_stream_t stream);
 int cm_optimizer_step_peer(float* grad_and_stats, int64_t n_params, void* own_mailbox, int world, uint32_t seq,
-                           const cm_opt_step_t* opt, cm_stream_t stream);
+                           const cm_opt_step_t* opt, double timeout_s, uint32_t* status, cm_stream_t stream);
 
 /* ---- a13 / a14: GRU actor, TBPTT chunk  (cleanmarl/mappo_lstm_multienvs.py:162-184, 562-620) ----
  * Forward + backward-through-time over steps [t0, t1) for all E*A sequences starting from the detached

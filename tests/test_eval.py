@@ -121,11 +121,11 @@ class _FakeActor:
         return a.astype(np.int32), np.zeros(rows, np.float32), None
 
 
-def _host_eval(rank, world, n_ep=5):
+def _host_eval(rank, world, n_ep=5, live=0):
     from cleanmarl_amd.env.vector import environment
     from cleanmarl_amd.evaluate import HostEvaluator, eval_base
     args = parse_args("mappo_multienvs", ["--env_type=synthetic_cpu", "--batch_size=8", "--synthetic_agents=3", "--synthetic_steps=9",
-                                          f"--num_eval_ep={n_ep}", "--seed=5"])
+                                          f"--num_eval_ep={n_ep}", "--seed=5", f"--eval_live_envs={live}"])
     synth = dict(agents=3, steps=9, ragged=True)
     fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=5, synthetic=synth)
     first = environment(**dict(fac, index=eval_base(8)))
@@ -139,10 +139,10 @@ def _host_eval(rank, world, n_ep=5):
     return out
 
 
-def _eval_worker(rank, world, port, path):
+def _eval_worker(rank, world, port, path, n_ep=5):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
-    out = _host_eval(rank, world)
+    out = _host_eval(rank, world, n_ep)
     torch.save(out, f"{path}.{rank}")
     torch.distributed.destroy_process_group()
 
@@ -159,3 +159,48 @@ def test_host_evaluator_deals_episodes_over_ranks_and_gathers_in_slot_order(tmp_
     for (ra, la), (rb, lb) in zip(one, r0):
         assert la == lb and len(la) == 5 and len(set(la)) > 1  # ragged horizons (index % 4), slot order kept
         np.testing.assert_allclose(ra, rb, rtol=0, atol=0)
+
+
+def test_host_evaluator_deals_ten_episodes_over_eight_ranks(tmp_path):
+    """The reference's default num_eval_ep = 10 on the eight ranks of a node: blocks of ceil(10 / 8) = 2 slots, so ranks 5 - 7 play NO
+    episode -- they still enter the gather, and every rank ends up with the ten results of the one-process evaluation, in slot order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "ev8")
+    mp.spawn(_eval_worker, args=(8, port, path, 10), nprocs=8, join=True)
+    one = _host_eval(0, 1, 10)
+    got = [torch.load(f"{path}.{r}") for r in range(8)]
+    assert all(g == got[0] for g in got)
+    for (ra, la), (rb, lb) in zip(one, got[0]):
+        assert la == lb and len(la) == 10
+        np.testing.assert_allclose(ra, rb, rtol=0, atol=0)
+
+
+def test_host_evaluator_waves_bound_the_live_envs_and_play_the_same_episodes():
+    """--eval_live_envs: envs are created on first use, at most N alive at once (waves), N = 1 = the reference's sequential evaluation;
+    the action keys do not depend on the wave size, so every setting returns the episodes of the all-at-once evaluation."""
+    from cleanmarl_amd.env.vector import environment
+    from cleanmarl_amd.evaluate import HostEvaluator, eval_base
+    full = _host_eval(0, 1, 7, live=0)
+    for live in (1, 3, 7, 9):
+        assert _host_eval(0, 1, 7, live=live) == full, live
+    args = parse_args("mappo_multienvs", ["--env_type=synthetic_cpu", "--batch_size=8", "--synthetic_agents=3", "--synthetic_steps=9",
+                                          "--num_eval_ep=7", "--seed=5", "--eval_live_envs=2"])
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=5, synthetic=dict(agents=3, steps=9, ragged=True))
+    made, closed = [], []
+
+    def make(index):
+        e = environment(**dict(fac, index=index))
+        made.append(index)
+        orig = e.close
+        e.close = lambda: (closed.append(index), orig())[1]
+        return e
+    he = HostEvaluator(make, environment(**dict(fac, index=eval_base(8))), _FakeActor(), args, 3, False, torch.device("cpu"), 8)
+    assert he.envs == {} and made == []  # nothing is built before the first round
+    live_max = [0]
+    play = he._play
+    he._play = lambda slots, *a: (live_max.__setitem__(0, max(live_max[0], len(he.envs) + sum(1 for j in slots if j not in he.envs))), play(slots, *a))[1]
+    he.run(0)
+    assert live_max[0] <= 2 and len(made) == 6 and len(closed) == 6  # slots 1..6 built and closed again; slot 0 is the caller's env
+    he.close()
