@@ -360,7 +360,14 @@ def main():
         first, E = rank * E_glob, E_glob
     w = Workload(args.workload, E, first, dev, pg, world)
     w.learner.global_envs = total_envs_of(args, world, E_glob)  # rank-invariant schedule choice (learner._schedule_rows)
+    # the shader clock of the dominant kernel, read by the kernel itself (cm_clock_probe: workgroup 0 of every actor pass leaves s_memtime /
+    # s_memrealtime at entry and exit of its tile loop; the last launch of the timed region is what is read back)
+    clk = torch.zeros(512, 4, dtype=torch.int64, device=dev)
+    N.check(N.load().cm_clock_probe(N.ptr(clk)), "cm_clock_probe")
     r = w.run(args.steps, args.warmup)
+    N.check(N.load().cm_clock_probe(None), "cm_clock_probe")
+    clk_all = clk.cpu()
+    clk = [int(v) for v in clk_all[0]]
     A, T, hp = w.A, w.T, w.hp
     total_envs = E_glob if args.scaling == "strong" else world * E_glob
 
@@ -408,6 +415,21 @@ def main():
                 out["roofline"]["issued_flop_per_launch"] = issued
                 out["roofline"]["issued_over_algorithmic"] = issued / wk["actor"]["flop"]
                 out["roofline"]["issued_frac"] = issued / (r["actor_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        if clk[3] > clk[2] and clk[0] > 0:
+            # s_memtime ticks are shader cycles, s_memrealtime ticks the constant 100 MHz reference: the clock workgroup 0 of the LAST actor
+            # pass of the timed region ran at, and the pass's rate against the fp32 MFMA peak AT THAT CLOCK (256 CUs x 256 flop per cycle) --
+            # `frac` above stays quoted on the nominal 2.4 GHz peak of MI355X_MICROARCH.md
+            ghz = clk[0] / ((clk[3] - clk[2]) / 1e8) / 1e9
+            out["roofline"]["shader_clock_ghz"] = ghz
+            out["roofline"]["probe_workgroup_ms"] = (clk[3] - clk[2]) / 1e5
+            out["roofline"]["frac_of_peak_at_shader_clock"] = achieved / (256 * 256 * ghz * 1e-3)
+            # ramp and tail of the launch from every workgroup's reference-clock stamps (ms relative to the first workgroup's entry)
+            live = clk_all[clk_all[:, 3] > 0].double()
+            t0 = float(live[:, 2].min())
+            st, en = (live[:, 2] - t0) / 1e5, (live[:, 3] - t0) / 1e5
+            out["roofline"]["workgroup_span"] = {"workgroups": int(live.shape[0]), "last_entry_ms": float(st.max()), "first_exit_ms": float(en.min()),
+                                                 "median_exit_ms": float(en.median()), "last_exit_ms": float(en.max()),
+                                                 "mean_busy_ms": float((en - st).mean()), "launch_ms_hip_events": r["actor_ms"]}
         if args.workload == "cfg3" and not args.envs and world == 1:
             pmc, why = load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
             if pmc is not None:

@@ -116,6 +116,7 @@ SIGNATURES = {
     "cm_gru_rollout_spread_ld": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "cm_rollout_spread_eps": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
     "cm_ppo_actor_issued_flop_per_row": (_d, [_i, _i, _i, _i]),
+    "cm_clock_probe": (_i, [_p]),
     "cm_philox4x32_host": (_i, [_p, _l, _p]),
     "cm_philox4x32_device": (_i, [_p, _l, _p, _p]),
 }
@@ -153,8 +154,8 @@ def load():
 # THIS package for A/B runs and tests: they are mapped onto cm_set_option when the library is loaded and again at the entry of every
 # learner update / target computation / rollout (sync_env_options is a few dictionary look-ups; the library is called on a change only).
 ENV_OPTIONS = {"CM_MLP_FORMS": "mlp_forms", "CM_CRITIC_SCHEDULE": "critic_schedule", "CM_GRU_TILE": "gru_tile",
-               "CM_ROLLOUT_TILE": "rollout_tile", "CM_MFMA": "mfma", "CM_WIDE_SCHEDULE": "wide_schedule", "CM_DW0_BATCH": "dw0_batch", "CM_DW0_GRID": "dw0_grid", "CM_TRAIN_GRID": "train_grid"}
-_DEFAULTS = {"mlp_forms": "auto", "critic_schedule": "auto", "gru_tile": "auto", "rollout_tile": "auto", "mfma": "fp32", "wide_schedule": "auto", "dw0_batch": "auto", "dw0_grid": "auto", "train_grid": "auto"}
+               "CM_ROLLOUT_TILE": "rollout_tile", "CM_MFMA": "mfma", "CM_WIDE_SCHEDULE": "wide_schedule", "CM_DW0_BATCH": "dw0_batch", "CM_DW0_GRID": "dw0_grid", "CM_TRAIN_GRID": "train_grid", "CM_TILE_SPLIT": "tile_split"}
+_DEFAULTS = {"mlp_forms": "auto", "critic_schedule": "auto", "gru_tile": "auto", "rollout_tile": "auto", "mfma": "fp32", "wide_schedule": "auto", "dw0_batch": "auto", "dw0_grid": "auto", "train_grid": "auto", "tile_split": "auto"}
 _applied = {}
 _env_seen = {}
 

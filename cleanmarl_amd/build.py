@@ -8,6 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcleanmarl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"]
+INCREMENTAL = False  # set by `python -m cleanmarl_amd.build -i` (development loop); __graft_entry__.build() always compiles everything
 FILE_FLAGS = {}  # per-file extra flags (none: the wave-private actor probe that needed some lives in tools/probes/actor16/)
 
 
@@ -35,15 +36,29 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _fresh(obj, flags):
+    """True when `obj` was compiled with `flags` and is newer than its source and every header the compiler listed for it (-MMD)."""
+    dep, stamp = obj + ".d", obj + ".flags"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(stamp)) or open(stamp).read() != " ".join(flags):
+        return False
+    deps = open(dep).read().replace("\\\n", " ").split(":", 1)[-1].split()
+    t = os.path.getmtime(obj)
+    return all(os.path.exists(d) and os.path.getmtime(d) <= t for d in deps)
+
+
 def _compile(args):
     src, obj, extra, verbose = args
     # -save-temps=obj: the device assembly (<stem>-hip-amdgcn-amd-amdhsa-gfx950.s) lands next to the object for lint_hand_pipelines()
-    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-save-temps=obj"] + extra + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    flags = [f for f in FLAGS if f != "-shared"] + ["-save-temps=obj"] + extra + FILE_FLAGS.get(os.path.basename(src), [])
+    if INCREMENTAL and _fresh(obj, flags):  # python -m cleanmarl_amd.build -i: only the translation units whose sources changed
+        return obj
+    cmd = [HIPCC] + flags + ["-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+    open(obj + ".flags", "w").write(" ".join(flags))
     stem = os.path.join(os.path.dirname(obj), os.path.splitext(os.path.basename(src))[0])
     for junk in glob.glob(stem + "-*.hipi") + glob.glob(stem + "-*.bc") + glob.glob(stem + "-host-*.s") + glob.glob(stem + "-*.out*"):
         os.remove(junk)
@@ -125,4 +140,5 @@ if __name__ == "__main__":
     elif "--prof" in sys.argv:  # phase-profiling build used by tools/phase_prof.py
         print(build_native(force=True, out=os.path.join(HERE, "libcleanmarl_hip_prof.so"), extra_flags=["-DCM_PHASE_PROF"]))
     else:
+        INCREMENTAL = "-i" in sys.argv
         print(build_native(force=True, verbose="-v" in sys.argv))

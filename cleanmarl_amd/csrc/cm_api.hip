@@ -27,10 +27,12 @@ const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfma
 const char* const kWideN[] = {"auto", "fused", "layered", "fused_r3"}; const int kWideV[] = {0, 1, 2, 3};
 const char* const kDw0N[] = {"auto", "8", "4"};                  const int kDw0V[] = {0, 8, 4};
 const char* const kGridN[] = {"auto", "512", "384", "256", "192", "128", "64"}; const int kGridV[] = {0, 512, 384, 256, 192, 128, 64};
+const char* const kSplitN[] = {"auto", "50", "52", "53", "54", "55", "56", "57", "58", "60"}; const int kSplitV[] = {0, 50, 52, 53, 54, 55, 56, 57, 58, 60};
 const OptDef kOpts[CM_OPTION_COUNT] = {
     {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 3}, {"gru_tile", kGruN, kGruV, 4},
     {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}, {"wide_schedule", kWideN, kWideV, 4},
-    {"dw0_batch", kDw0N, kDw0V, 3}, {"dw0_grid", kGridN, kGridV, 7}, {"train_grid", kGridN, kGridV, 7}};
+    {"dw0_batch", kDw0N, kDw0V, 3}, {"dw0_grid", kGridN, kGridV, 7}, {"train_grid", kGridN, kGridV, 7},
+    {"tile_split", kSplitN, kSplitV, 10}};
 std::atomic<int> g_opt[CM_OPTION_COUNT];  // zero-initialised: every option starts at its first value
 }  // namespace
 

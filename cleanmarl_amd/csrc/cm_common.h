@@ -18,7 +18,7 @@ void cm_set_error(const char* fmt, ...);
 #define CM_REQUIRE(cond, ...) do { if (!(cond)) CM_FAIL(-1, __VA_ARGS__); } while (0)
 
 // options set through cm_set_option (cm_api.hip); values are the ints listed there (0 = the default / "auto")
-enum { CM_OPTION_MLP_FORMS = 0, CM_OPTION_CRITIC_SCHEDULE, CM_OPTION_GRU_TILE, CM_OPTION_ROLLOUT_TILE, CM_OPTION_MFMA, CM_OPTION_WIDE_SCHEDULE, CM_OPTION_DW0_BATCH, CM_OPTION_DW0_GRID, CM_OPTION_TRAIN_GRID, CM_OPTION_COUNT };
+enum { CM_OPTION_MLP_FORMS = 0, CM_OPTION_CRITIC_SCHEDULE, CM_OPTION_GRU_TILE, CM_OPTION_ROLLOUT_TILE, CM_OPTION_MFMA, CM_OPTION_WIDE_SCHEDULE, CM_OPTION_DW0_BATCH, CM_OPTION_DW0_GRID, CM_OPTION_TRAIN_GRID, CM_OPTION_TILE_SPLIT, CM_OPTION_COUNT };
 int cm_option(int which);
 
 // fold per-workgroup partial gradient rows and apply the optimiser step in one launch (cm_optim.hip); part2 / isplit: a second partial
@@ -30,6 +30,9 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
                           float* grad_and_stats, const cm_opt_step_t* opt, hipStream_t s, const char* who,
                           const unsigned long long* peer_tags = nullptr, unsigned peer_seq = 0, double peer_timeout_s = 0.0,
                           unsigned* peer_status = nullptr);
+
+unsigned cm_next_step_tag();  // tags of the step's hand-off words: unique per launch within the process, never 0 (cm_optim.hip)
+int cm_opt_check(const char* who, int64_t n_params, const cm_opt_step_t* o);
 
 // layered GRU schedule (cm_gru_wide.hip): obs wider than 64 columns and / or 65..256 hidden units
 size_t cm_gru_wide_ws_bytes(int64_t R, int chunk_len, int din, int H, int K, int train);

@@ -6,6 +6,10 @@ unsigned long long* g_prof = nullptr;
 extern "C" void cm_prof_set_buffer(unsigned long long* p) { g_prof = p; }
 #endif
 
+// production clock probe (include/cleanmarl_hip.h): shader clock of the actor pass, measured by the pass itself
+static unsigned long long* g_clk = nullptr;
+extern "C" int cm_clock_probe(uint64_t* ticks) { g_clk = (unsigned long long*)ticks; return 0; }
+
 extern "C" size_t cm_mlp_train_workspace_bytes(int din, int hidden, int n_hidden_layers, int dout) {
     return train_ws_bytes(din, hidden, n_hidden_layers, dout);
 }
@@ -54,7 +58,9 @@ static int actor_pass(const float* obs, int64_t obs_ld, const uint8_t* avail, co
 #ifdef CM_PHASE_PROF
     a.prof = g_prof;
 #endif
+    a.clk = g_clk;
     const int grid = grid_for(a.rows, (a.din + KC - 1) / KC);
+    set_tile_split(a, grid, (a.din + KC - 1) / KC);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     if (int rc = launch_train<M_ACTOR>(a, grid, lds_bytes, (hipStream_t)stream)) return rc;
     CM_CHECK_LAUNCH("cm_ppo_actor_fwd_bwd");

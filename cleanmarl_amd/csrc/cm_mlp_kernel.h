@@ -39,6 +39,9 @@ constexpr int NTHREADS = 256;
 #define CM_WG2_MAX_NCH 2
 #endif
 constexpr int wgs_per_cu(int nch) { return nch <= CM_WG2_MAX_NCH ? 2 : 1; }
+#ifndef CM_TILE_SPLIT_DEFAULT
+#define CM_TILE_SPLIT_DEFAULT 56  // per cent of the tiles for the first half of a full grid (set_tile_split); 50 = equal
+#endif
 #ifndef CM_HEAD_WP
 #define CM_HEAD_WP 1  // wave-private head backward (head_bwd_wave); 0 = the workgroup-wide products of rounds 1 - 3, kept for A/B builds
 #endif
@@ -66,6 +69,10 @@ struct MlpArgs {
     float* dz0;  // training kernels instantiated with NCH == 0: layer-0 pre-activation gradient [rows][HP] goes to HBM
                  // and the layer-0 weight gradient is computed by the streaming kernel k_dw0_stream instead
     unsigned long long* prof;  // CM_PHASE_PROF builds only: [grid][16] cycle counters
+    long split_tiles;  // > 0: UNEQUAL static split of the tiles over the two workgroups of a CU (set_tile_split): workgroups [0, grid / 2)
+                       // stride over tiles [0, split_tiles), workgroups [grid / 2, grid) over [split_tiles, ntiles)
+    unsigned long long* clk;   // production clock probe (cm_clock_probe; NULL = off): workgroup w of an M_ACTOR launch writes clk[4 w ..] =
+                               // {shader cycles (s_memtime) of its tile loop, XCC_ID << 32 | HW_ID, s_memrealtime at entry, at exit (100 MHz reference ticks)}
     // zero-padded image of W0 with a leading dimension that is a multiple of 4 floats ([H][w0_ld], built per call by prep_w0_image):
     // set when W0 is STREAMED (din > 64) and its rows are not 16-byte aligned (din % 4 != 0) while the input's rows are (*_ld entry
     // points) -- the streamed chunks then come from this image on 16-byte loads instead of 16 4-byte loads per thread and tile
@@ -778,6 +785,10 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
 
     const long ntiles = (a.rows + TM - 1) / TM;
     PH_DECL
+    // clock probe (scalar: a kernel argument): two counter reads at entry, four 8-byte stores at exit of every workgroup
+    const bool clk_on = (MODE == M_ACTOR) && a.clk != nullptr;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int hrow = tid >> 2, hq = tid & 3;  // head mapping: 4 lanes per row, 16 hidden columns per lane
     const int Aseq = (MODE == M_CRITIC && !a.per_agent) ? 1 : a.A;
 
@@ -806,17 +817,26 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         w0_regs_load(w0ra, a.params + off.W0, 32 * wn, H, din, 0, din);
         w0_regs_load(w0rb, a.params + off.W0, 32 * wn, H, din, KC, din);
     }
-    if ((long)blockIdx.x < ntiles) {
-        tile_load<(VEC != 0)>(px, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, 0, min(KC, din));
+    // Tile range of this workgroup.  Default: tiles blockIdx.x, + grid, ...  With a.split_tiles the two halves of the grid own two
+    // CONSECUTIVE tile ranges of unequal size (see set_tile_split): still a static map (the partial sums of a workgroup, and with them the
+    // folded gradient, do not depend on timing), but the half that the CU arbiter favours gets more tiles.
+    long tile_begin = blockIdx.x, tile_stride = gridDim.x, tile_end = ntiles;
+    if (a.split_tiles > 0) {
+        const long half = gridDim.x >> 1;
+        tile_stride = half;
+        if ((long)blockIdx.x < half) tile_end = a.split_tiles; else tile_begin = a.split_tiles + ((long)blockIdx.x - half);
+    }
+    if (tile_begin < tile_end) {
+        tile_load<(VEC != 0)>(px, a.x, tile_begin * TM, a.rows, a.x_stride, 0, min(KC, din));
         if (!w0_resident && !W0REG) tile_load<(VEC == 1)>(pw, W0g, 0, H, w0ld, 0, min(KC, din));
         // W0REG: the W0 staging registers carry the tile's SECOND X chunk instead -- both chunks of a tile are requested a whole tile
         // ahead (one chunk ahead, the second chunk's HBM round trip was exposed behind 2 k cycles of MFMAs)
-        if (W0REG) tile_load<(VEC != 0)>(pw, a.x, (long)blockIdx.x * TM, a.rows, a.x_stride, KC, din - KC);
+        if (W0REG) tile_load<(VEC != 0)>(pw, a.x, tile_begin * TM, a.rows, a.x_stride, KC, din - KC);
     }
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = tile_begin; tile < tile_end; tile += tile_stride) {
         const long row0 = tile * TM;
-        const long next_row0 = (tile + gridDim.x) * TM;  // >= rows when this is the last tile: loads predicate off
+        const long next_row0 = (tile + tile_stride < tile_end) ? (tile + tile_stride) * TM : a.rows;  // last tile of the range: the prefetch loads predicate off
         // ================= forward, layer 0 (input chunks) =================
         f32x16 acc;
 #pragma unroll
@@ -1298,6 +1318,11 @@ _Pragma("unroll") \
     }
     PH_FLUSH;
 #undef CM_FETCH_ROW_INPUTS
+    if (clk_on && tid == 0) {  // the tile loop of this workgroup: what the launch's duration is made of (the partial write below is ~1 % of it)
+        unsigned long long* c = a.clk + 4 * (size_t)blockIdx.x;
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)), hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_REG_XCC_ID, HW_REG_HW_ID
+        c[0] = __builtin_amdgcn_s_memtime() - clk_c0; c[1] = ((unsigned long long)xcc << 32) | hw; c[2] = clk_r0; c[3] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // ================= write this workgroup's partial gradient + stats =================
     if (TRAIN) {
@@ -1440,6 +1465,24 @@ inline int check_shapes(const char* who, int din, int H, int L, int dout) {
 inline int check_rows(const char* who, long rows) {
     CM_REQUIRE(rows < (1L << 31), "%s: %ld rows exceed the 2^31 row limit of one launch", who, rows);
     return 0;
+}
+
+// Unequal static split of a full persistent grid (two workgroups per CU).  Measured with cm_clock_probe on the actor pass of config 3
+// (tools/probes/wg_span.py, round 5): the 512 workgroups finish in TWO groups -- the first 256 (dispatched first, one per CU: the older
+// waves of every SIMD, which the issue arbiter favours) after 1.45 ms, the second 256 after 1.67 ms, the last 0.2 ms with one workgroup per
+// CU.  Handing the favoured half `pct` % of the tiles (a function of the launch's shape only: results stay run-to-run identical) lets
+// both finish together: 1.713 -> 1.691 ms at 55 - 57 % (gpurun_out/r05e; less than the 0.2 ms tail suggests -- a workgroup alone on
+// its CU runs its tiles 1.7 x faster than beside a partner, so the tail was mostly useful work).  option "tile_split": auto | 50 (equal) | 52 .. 60.
+inline void set_tile_split(MlpArgs& a, int grid, int nch) {
+    a.split_tiles = 0;
+    const long nt = (a.rows + TM - 1) / TM;
+    if (wgs_per_cu(nch) != 2 || grid != 512 || nt < 4L * grid) return;  // only a full two-per-CU grid with >= 4 tiles per workgroup
+    const int opt = cm_option(CM_OPTION_TILE_SPLIT);
+    // auto: only launches that have the GPU to themselves (>= 2^21 rows: learner.overlap_critic's one-stream schedule) -- beside the critic's
+    // kernels the favoured half is not the first half of the grid, and a split costs 15 - 25 % (512-env share: 0.28 -> 0.33 - 0.35 ms)
+    const int pct = opt ? opt : (a.rows >= (1L << 21) ? CM_TILE_SPLIT_DEFAULT : 50);
+    if (pct <= 50) return;
+    a.split_tiles = (nt * pct + 50) / 100;
 }
 
 inline int grid_for(long rows, int nch = 0) {

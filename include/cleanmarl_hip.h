@@ -229,6 +229,15 @@ int cm_critic_train_step_ld(const float* x, int64_t x_ld, const float* ret, cons
                             int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                             float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream);
 
+/* ---- measurement aid: the shader clock of the dominant kernel, read by the kernel itself ----
+ * ticks != NULL (device memory, 4 x 512 words): workgroup w of every following cm_ppo_actor_fwd_bwd* / cm_ppo_actor_train_step* launch
+ * (fused shapes; at most 512 workgroups) writes four 64-bit words to ticks[4 w ..]: t[0] = the shader cycles (s_memtime) of its tile
+ * loop, t[1] = HW_REG_XCC_ID << 32 | HW_REG_HW_ID (where it ran), t[2] / t[3] = s_memrealtime at entry / exit of the loop (the constant
+ * 100 MHz reference clock, common to all workgroups).  t[0] / ((t[3] - t[2]) / 1e8) is the shader clock the workgroup ran at; the spread
+ * of t[2] / t[3] over the workgroups is the launch's ramp and tail.  bench.py reports roofline.shader_clock_ghz and roofline.workgroup_span from it.  NULL switches the probe off
+ * (the default; an off probe costs one scalar compare). */
+int cm_clock_probe(uint64_t* ticks);
+
 /* ---- one-shot peer all-reduce of the [gradient | statistics] buffer (csrc/cm_peer.hip) ----
  * The exchange step of an env-sharded run without a collective library on the data path: every rank owns a MAILBOX (fine-grained device
  * memory; 2 x world slots of n floats + one tag word each) that its peers map with hipIpc.  Per optimiser step a rank
