@@ -17,6 +17,7 @@ static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, i
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
     prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);  // no workspace: W0 chunks on 4-byte loads where unaligned
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    set_tile_split(a, grid_for(rows), 0, true);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
     launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_mlp_forward");
     return 0;
@@ -61,6 +62,7 @@ extern "C" int cm_policy_act(const float* x, int64_t x_row_stride, const uint8_t
     a.params = params; a.avail = avail; a.avail_stride = avail_row_stride;
     a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    set_tile_split(a, grid_for(rows), 0);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
     launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act");
     return 0;
@@ -80,6 +82,7 @@ extern "C" int cm_policy_act_eps(const float* x, int64_t x_row_stride, const uin
     a.params = params; a.avail = avail; a.avail_stride = avail_row_stride; a.act_eps = (float)eps;
     a.seed = seed; a.row_offset = row_offset; a.t = t; a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    set_tile_split(a, grid_for(rows), 0);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
     launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_eps");
     return 0;
@@ -96,6 +99,7 @@ extern "C" int cm_policy_act_greedy(const float* x, int64_t x_row_stride, const 
     a.params = params; a.avail = avail; a.avail_stride = avail_row_stride; a.act_eps = -1.0f;
     a.action_out = action; a.logp_out = logp; a.out_stride = out_stride;
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
+    set_tile_split(a, grid_for(rows), 0);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
     launch_infer<M_ACT>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_greedy");
     return 0;
@@ -147,6 +151,7 @@ extern "C" int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint
     prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     CM_SET_PROF(a);
+    set_tile_split(a, grid_for(a.rows), 0);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
     launch_infer<M_ACT>(a, grid_for(a.rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_policy_act_episode");
     return 0;

@@ -1473,14 +1473,15 @@ inline int check_rows(const char* who, long rows) {
 // CU.  Handing the favoured half `pct` % of the tiles (a function of the launch's shape only: results stay run-to-run identical) lets
 // both finish together: 1.713 -> 1.691 ms at 55 - 57 % (gpurun_out/r05e; less than the 0.2 ms tail suggests -- a workgroup alone on
 // its CU runs its tiles 1.7 x faster than beside a partner, so the tail was mostly useful work).  option "tile_split": auto | 50 (equal) | 52 .. 60.
-inline void set_tile_split(MlpArgs& a, int grid, int nch) {
+inline void set_tile_split(MlpArgs& a, int grid, int nch, bool alone = false) {
     a.split_tiles = 0;
     const long nt = (a.rows + TM - 1) / TM;
     if (wgs_per_cu(nch) != 2 || grid != 512 || nt < 4L * grid) return;  // only a full two-per-CU grid with >= 4 tiles per workgroup
     const int opt = cm_option(CM_OPTION_TILE_SPLIT);
     // auto: only launches that have the GPU to themselves (>= 2^21 rows: learner.overlap_critic's one-stream schedule) -- beside the critic's
     // kernels the favoured half is not the first half of the grid, and a split costs 15 - 25 % (512-env share: 0.28 -> 0.33 - 0.35 ms)
-    const int pct = opt ? opt : (a.rows >= (1L << 21) ? CM_TILE_SPLIT_DEFAULT : 50);
+    // (alone: launches that are ordered behind everything else by construction -- the value pass waits for the critic stream first)
+    const int pct = opt ? opt : ((alone || a.rows >= (1L << 21)) ? CM_TILE_SPLIT_DEFAULT : 50);
     if (pct <= 50) return;
     a.split_tiles = (nt * pct + 50) / 100;
 }

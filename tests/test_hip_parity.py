@@ -919,7 +919,10 @@ def test_full_size_update_is_deterministic_and_finite():
 # per-agent critic of width 32 as ippo_multienvs.py:34 defaults) and configs[1] (MAPPO 1024 x 3 x 128, obs 18 + 3 ids) at FULL size, in the
 # storage the product uses (leading dimensions rounded up to 4 floats: the two-chunk k_mlp<2, ...> actor / k_mlp<-2> forward of config 4
 # and the padded 21-wide rows of config 2 are otherwise only ever launched by bench.py)
+# "cfg4_bench": the same config with the 2 x 64 critic that SURVEY.md 8's table and bench.py (Workload: cspec hidden 64) time -- the 64-wide
+# k_critic_fused<2> over 5.2 M rows x 115 columns is 36 % of config 4's iteration and used to be launched at full size by bench.py only
 _FULL = {"cfg4": dict(algo="ippo", E=2048, A=10, T=256, Do=115, Ds=243, K=17, Hc=32, avail_p=0.7, shard=16),
+         "cfg4_bench": dict(algo="ippo", E=2048, A=10, T=256, Do=115, Ds=243, K=17, Hc=64, avail_p=0.7, shard=16),
          "cfg2": dict(algo="mappo", E=1024, A=3, T=128, Do=21, Ds=54, K=5, Hc=64, avail_p=1.0, shard=32)}
 
 
@@ -947,7 +950,7 @@ def _full_size_cfg(name, seed=0):
     return L, b, c
 
 
-@pytest.mark.parametrize("name", ["cfg4", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg4", "cfg4_bench", "cfg2"])
 def test_full_size_other_configs_shard_additivity_and_oracle_shard(name):
     """Configs 4 and 2 at BASELINE size: the sums of uneven env shards add up to the full batch, N = b_mask.sum(), and one shard small
     enough for the CPU restatement (16 / 32 envs) matches it -- gradients of both networks, losses, returns and advantages."""
@@ -995,7 +998,7 @@ def test_full_size_other_configs_shard_additivity_and_oracle_shard(name):
     assert abs(float(first[Pa + 8 + Pc + 4] / n) - scal["critic_loss"]) <= TOL * (1 + abs(scal["critic_loss"]))
 
 
-@pytest.mark.parametrize("name", ["cfg4", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg4", "cfg4_bench", "cfg2"])
 def test_full_size_other_configs_update_is_deterministic_and_finite(name):
     """Two independent full-size iterations (value pass, scan, three epochs on whichever schedule the size selects -- config 2 runs its
     critic epochs on the second stream) leave bit-identical parameters and finite records; the act pass over the whole episode
