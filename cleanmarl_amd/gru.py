@@ -32,12 +32,12 @@ class GRUPPOLearner(PPOLearner):
         #   "low"     the same on the lowest-priority stream;
         #   "deferN"  the last N epochs behind the actor's epochs on the lowest-priority stream: they run under the NEXT rollout and are
         #             joined by the next value pass (wait_critic), the first epochs stay beside the actor's.
-        # Kernel trace of config 5 (tools/gpu/r03_cfg5_trace.sh): a critic epoch (pass 143 + streamed dW0 142 + step 35 us) beside the
+        # Kernel trace of config 5 (rocprofv3 --kernel-trace; today: tools/gpu/run.sh "timeline --workload cfg5"): a critic epoch (pass 143 + streamed dW0 142 + step 35 us) beside the
         # pipelined GRU sweeps -- which have no idle CUs any more -- stretches the first chunk of the actor epoch by ~115 us (forward
         # sweep 67 -> 105 us, backward 80 -> 157); beside the rollout it costs 69 us once, however many epochs follow.  Measured
-        # (tools/gpu/r03_gru_critic.sh, two runs each): beside 7.33 / 7.34 ms, defer1 7.20 / 7.23, defer2 7.23 / 7.26 (the value pass starts
+        # (CM_GRU_CRITIC sweep; today: tools/gpu/run.sh "ab CM_GRU_CRITIC beside defer1 defer2 defer3 -- --workload cfg5", two runs each): beside 7.33 / 7.34 ms, defer1 7.20 / 7.23, defer2 7.23 / 7.26 (the value pass starts
         # to wait), defer3 7.30.  Round 4, after the state rows were padded to 16 bytes (one-pass critic, 160 -> 111 us alone: two epochs now
-        # fit under the 0.78 ms rollout without the value pass waiting; tools/gpu/r04_cfg5c.sh, three runs each): defer1 7.15 / 7.18 / 7.15,
+        # fit under the 0.78 ms rollout without the value pass waiting; the same sweep in round 4, three runs each): defer1 7.15 / 7.18 / 7.15,
         # defer2 7.12 / 7.11 / 7.10, defer3 7.16 (the value pass waits 0.1 ms).  CM_GRU_CRITIC is a Python-side A/B hook, not an option of
         # the C-ABI.
         self.critic_schedule = os.environ.get("CM_GRU_CRITIC", "defer2")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B library for same-box comparisons: compiles the csrc/ of a git revision (default HEAD) into cleanmarl_amd/libcleanmarl_hip_ab.so, which
-bench.py / the tools load through CM_LIB_PATH (tools/gpu/r04_e.sh, r04_g.sh run the working tree's build and this one alternately)."""
+bench.py / the tools load through CM_LIB_PATH (tools/gpu/run.sh "ab CM_LIB_PATH <main .so> <ab .so> -- ..." runs the working tree's build and this one alternately)."""
 import glob
 import os
 import subprocess

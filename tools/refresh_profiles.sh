@@ -1,7 +1,7 @@
 # Regenerates the measurement artefacts of a round on a gpurun box:  bash tools/refresh_profiles.sh r02   (outputs: gpurun_out/<tag>/, copy
 # the summaries to profiles/<tag>_*).  Needs libcleanmarl_hip.so and, for the phase profiles, libcleanmarl_hip_prof.so (python -m cleanmarl_amd.build --prof).
 set -x
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -49,3 +49,9 @@ for w in "cfg3 --envs 512" "cfg2"; do
   rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$n -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python $R/tools/trace_timeline.py $(find /tmp/kt_$n -name "*kernel_trace.csv" | head -1) k_ro 3 > $O/timeline_$n.txt 2>&1
 done
+# ---- round 5: per-workgroup span of the actor pass (cm_clock_probe: shader clock, ramp and tail, who finishes when) at both sizes, equal and shipped split
+python $R/tools/probes/wg_span.py 4096 2>&1 | grep -v amdgpu.ids > $O/wg_span.txt
+CM_TILE_SPLIT=50 python $R/tools/probes/wg_span.py 4096 2>&1 | grep -v amdgpu.ids > $O/wg_span_equal_split.txt
+python $R/tools/probes/wg_span.py 512 2>&1 | grep -v amdgpu.ids > $O/wg_span_envs512.txt
+# ---- the whole GPU suite at these sources
+cd $R && (time timeout 3000 python -m pytest tests -q -m gpu) > $O/gputests.txt 2>&1; tail -5 $O/gputests.txt
