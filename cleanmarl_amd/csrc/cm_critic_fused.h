@@ -16,7 +16,7 @@
 // One workgroup per CU (registers: 2 x 16 x NC + ~230, W0 parked in the accumulation-register file), the next tile's first two X
 // chunks in flight in registers during the backward phases.  Same un-normalised sums and statistic slots as k_mlp<.., M_CRITIC>;
 // summation order differs (tolerance-tested, 1e-4).  Measured at config 3 (524288 rows x 384): 0.576 ms = 71 % of the fp32 MFMA peak,
-// 0.85 GB of HBM traffic for 0.82 GB algorithmic (split schedule: 0.772 ms, 1.95 GB).  DESIGN.md section 3.1b.
+// 0.85 GB of HBM traffic for 0.82 GB algorithmic (split schedule: 0.772 ms, 1.95 GB).  docs/KERNEL_NOTES.md section 3.1b.
 // Shapes: Din = 65 .. 448 (NC = 2 .. 7 chunks of 64) on 16-byte aligned rows, H <= 64, ONE hidden->hidden layer, scalar output, at
 // least CM_FUSED_MIN_ROWS rows (whole CUs per workgroup: small batches and batches overlapped with other kernels keep the split schedule).
 #pragma once
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
     }
 }
 
-constexpr long CM_FUSED_MIN_ROWS = 131072;  // 8 row tiles per CU; below, the split schedule of cm_mlp_split.h is as fast or faster
+constexpr long CM_FUSED_MIN_ROWS = 131072;  // 8 row tiles per CU; below, the split schedule of cm_mlp_split.h is as fast or faster (docs/KERNEL_NOTES.md 3.1)
 inline bool critic_fused_shape(const MlpArgs& a) {
     const int nc = (a.din + KC - 1) / KC;
     return nc >= 2 && nc <= 7 && a.H <= HP && a.L == 1 && a.dout == 1 && x_rows_vec(a) && !mfma_bf16x3();  // 8 chunks: 177 KB of LDS

@@ -6,7 +6,7 @@
 //   M_ACTOR  PPO clipped-surrogate fwd + bwd       (:527-551, :561-582)   -> cm_ppo_actor_fwd_bwd
 //   M_CRITIC value MSE fwd + bwd                   (:554-558, :582)       -> cm_critic_fwd_bwd
 //
-// Design: a workgroup = 4 wavefronts (2 along rows x 2 along hidden columns) owns a tile of
+// Design (docs/KERNEL_NOTES.md §3): a workgroup = 4 wavefronts (2 along rows x 2 along hidden columns) owns a tile of
 // TM = 64 rows and walks the whole network for that tile with every activation resident in LDS; rows
 // never round-trip to HBM between layers or between forward and backward.  All GEMMs run on
 // v_mfma_f32_32x32x2_f32 (exact fp32, == an fmaf chain), so results stay within fp32 round-off of the
@@ -387,7 +387,7 @@ template <bool HAND> __device__ __forceinline__ void colred_sel(f32x16& acc, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Error-compensated bf16 MFMA (opt-in, CM_MFMA=bf16x3).  Every fp32 value that lives in an LDS operand
+// Error-compensated bf16 MFMA (opt-in, CM_MFMA=bf16x3; docs/KERNEL_NOTES.md section 8).  Every fp32 value that lives in an LDS operand
 // tile is stored as a SPLIT WORD  bf16(x) << 16 | bf16(x - bf16(x))  (same 32-bit footprint, same layouts); the three GEMM
 // forms read 8 split words per operand fragment, separate them into a hi and a lo bf16x8 fragment with v_perm_b32 and issue
 // lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, small terms first).  ~17x fp32 round-off per product
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
         // per-row head inputs of the tile (availability bytes, action / old log-prob / advantage / return, episode length): requested at the top
         // of the tile, consumed in the head phase.  The SAME statements in three places, chosen at compile time -- each placement was measured on
         // the instantiations it applies to (gpurun_out/r04k, r04l; a semantically neutral refactoring of this block moved the actor pass by 2 %
-        // either way, see the end of DESIGN.md 8b):
+        // either way, see the end of docs/KERNEL_NOTES.md 8b):
         //   * training passes with the hand-ordered product forms and a kept tile (ROWIN_LATE: the actor pass above 2^21 rows): AFTER the
         //     barrier, under the layer-0 products, instead of in the zero-MFMA interval between the two barriers: 1.729 -> 1.697 ms at config 3;
         //   * the other training passes: inline before the tile prefetch (the compiler turns them into booleans right after the layer-0 loop;
@@ -1522,7 +1522,7 @@ template <int NCH, int MODE, int VEC, int LCAP, int KJ, bool BF = false, bool HA
 inline void launch_one(const MlpArgs& a, int grid, size_t lds_bytes, hipStream_t s) {
 #ifdef CM_PHASE_PROF
     // profiling build only (tools/phase_prof.py): CM_PROF_ONE_WG=1 pads LDS so that ONE workgroup fits a CU and halves the grid --
-    // timing experiment for the occupancy argument of DESIGN.md section 10 (results of such a launch are not meaningful)
+    // timing experiment for the occupancy argument of docs/KERNEL_NOTES.md section 10 (results of such a launch are not meaningful)
     if (const char* e = getenv("CM_PROF_ONE_WG")) {
         if (e[0] == '1') { if (lds_bytes < 100 * 1024) lds_bytes = 100 * 1024; if (grid > 256) grid = 256; }
     }

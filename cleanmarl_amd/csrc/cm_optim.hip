@@ -56,7 +56,7 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
             __hip_atomic_store(a.peer_status, a.peer_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // acquire at system scope, pairing with the pusher's release store of the tag (cm_peer.hip): the slot loads below are relaxed
         // system-scope loads and must not be satisfied from anything older than the tag that certified them.  One fence per
-        // workgroup of the OPT-IN peer path only; the default launches (PEER = false) contain no fence (§3.4 of DESIGN.md: why)
+        // workgroup of the OPT-IN peer path only; the default launches (PEER = false) contain no fence (why)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         __syncthreads();
     }

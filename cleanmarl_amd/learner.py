@@ -263,7 +263,7 @@ class PPOLearner:
         # The critic's epochs only need the returns of THIS batch; the next rollout only needs the updated actor.  update() therefore
         # enqueues the critic epochs on a second stream and does not join it: the join is the first reader of the critic, i.e. the value
         # pass of the next iteration (wait_critic()).  With the rollouts double-buffered (rollout.py) the rollout of iteration i + 1
-        # runs under the critic epochs of iteration i -- it is a latency chain that leaves most of the chip idle.
+        # runs under the critic epochs of iteration i -- it is a latency chain that leaves most of the chip idle (docs/KERNEL_NOTES.md §3.5).
         self._critic_stream = None
         self._critic_done = None
         self._critic_joined = set()  # streams that already wait for _critic_done

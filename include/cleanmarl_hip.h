@@ -14,7 +14,7 @@
  *     scratch take a caller-provided workspace sized by the matching *_workspace_bytes() query.
  *   - all device arithmetic is fp32; scalar hyper-parameters cross the ABI as double so that expressions the
  *     reference evaluates in Python float64 (e.g. 1 - td_lambda, 1 +- ppo_clip) are rounded to fp32 once.
- *     Device data layout, E envs, A agents, T steps:
+ *     Device data layout (docs/KERNEL_NOTES.md §2), E envs, A agents, T steps:
  *       obs     float  [E][A][T][Do]      state  float [E][T][Ds]      reward float [E][T]
  *       avail   uint8  [E][A][T][K]       action int32 [E][A][T]       logp   float [E][A][T]
  *       values  float  [E][Av][T] (Av = 1 MAPPO / A IPPO)   ret, adv float [E][A][T]
@@ -70,7 +70,7 @@ int cm_version(void);
  *   "mfma"             fp32 | bf16x3 | bf16    GEMM arithmetic of the PPO training passes: exact fp32 MFMA; error-compensated bf16
  *                                              (3 MFMAs per product, ~3e-6 of sum|a b|, inside the 1e-4 parity bar); single-pass bf16
  *                                              (1 MFMA per product, operands rounded to 8 bits: ~4e-3, its own looser parity tier);
- *                                              fp32 accumulate either way -- DESIGN.md section 8
+ *                                              fp32 accumulate either way -- docs/KERNEL_NOTES.md section 8
  *   "wide_schedule"    auto | fused | layered | fused_r3
  *                                              MLPs of 65 .. 128 hidden units with one hidden->hidden layer (the reference's COMA critic
  *                                              default, cleanmarl/coma_multienvs.py:35): one-launch fused tile (csrc/cm_mlp_fused128.h, the

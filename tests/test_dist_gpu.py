@@ -439,6 +439,10 @@ def test_bench_contract_single_gpu():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert rf["traffic"] is None or rf["traffic"] > 0.9 * rf["algorithmic_bytes_per_launch"]
+    # the kernel's own clock probe: the shader clock of the last actor pass, its rate against the peak AT that clock, ramp and tail
+    assert 1.5 < rf["shader_clock_ghz"] < 2.6 and rf["frac_of_peak_at_shader_clock"] >= 0.95 * rf["frac"]
+    ws = rf["workgroup_span"]
+    assert ws["workgroups"] == 512 and ws["last_entry_ms"] < 0.05 < ws["first_exit_ms"] <= ws["median_exit_ms"] <= ws["last_exit_ms"] < rf["workgroup_span"]["launch_ms_hip_events"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "envs" in cb["sample"]
     assert out["value"] > 50 * cb["value"]  # north-star: >= 50x the reference-structured CPU path

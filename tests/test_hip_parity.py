@@ -215,7 +215,7 @@ def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
 
 
 def test_bf16x3_opt_in_keeps_the_parity_bar():
-    """CM_MFMA=bf16x3 (error-compensated bf16 MFMA loops; the env var is read once per process, hence the
+    """CM_MFMA=bf16x3 (error-compensated bf16 MFMA loops, docs/KERNEL_NOTES.md section 8; the env var is read once per process, hence the
     subprocess): the config-3-shaped update must stay inside the same 1e-4 bar vs the fp32 oracle, and must really have
     taken the bf16 kernels (cm_mfma_mode() == 1; results differ from the exact-fp32 run in the low bits)."""
     import json
@@ -923,7 +923,9 @@ def test_full_size_update_is_deterministic_and_finite():
 # k_critic_fused<2> over 5.2 M rows x 115 columns is 36 % of config 4's iteration and used to be launched at full size by bench.py only
 _FULL = {"cfg4": dict(algo="ippo", E=2048, A=10, T=256, Do=115, Ds=243, K=17, Hc=32, avail_p=0.7, shard=16),
          "cfg4_bench": dict(algo="ippo", E=2048, A=10, T=256, Do=115, Ds=243, K=17, Hc=64, avail_p=0.7, shard=16),
-         "cfg2": dict(algo="mappo", E=1024, A=3, T=128, Do=21, Ds=54, K=5, Hc=64, avail_p=1.0, shard=32)}
+         "cfg2": dict(algo="mappo", E=1024, A=3, T=128, Do=21, Ds=54, K=5, Hc=64, avail_p=1.0, shard=32),
+         # config 3's shapes (the headline workload) for the tile-split / clock-probe test: 2^22 actor rows, one input chunk
+         "cfg3_probe": dict(algo="mappo", E=4096, A=8, T=128, Do=56, Ds=384, K=5, Hc=64, avail_p=1.0, shard=32)}
 
 
 def _full_size_cfg(name, seed=0):
@@ -1347,3 +1349,44 @@ def test_padded_rollout_buffers_hold_the_same_rollout():
             assert torch.equal(getattr(ba, k), getattr(bb, k)), k
         st = bb.obs.as_strided((bb.E, bb.A, bb.T, bb.obs_ld), (bb.A * bb.T * bb.obs_ld, bb.T * bb.obs_ld, bb.obs_ld, 1))
         assert not st[..., bb.Do:].any()
+
+
+def test_unequal_tile_split_and_clock_probe_at_full_size():
+    """Round 5: (i) the unequal static tile split of full-size launches (cm_mlp_kernel.h::set_tile_split: the first half of a two-per-CU
+    grid takes 56 % of the tiles) is a pure re-mapping of tiles to workgroups -- the value pass (rows independent) is BIT-identical to
+    the equal split, the actor pass's folded gradient differs by fp32 re-association only (different partial sums, <= 1e-5 relative) and is
+    itself run-to-run identical; (ii) cm_clock_probe: every workgroup of the actor pass reports where and how fast it ran."""
+    from cleanmarl_amd import _native as N
+    L, b, c = _full_size_cfg("cfg3_probe")
+    lib, s = N.load(), N.stream_ptr()
+    L.compute_targets(b)
+    outs = {}
+    try:
+        for split in ("50", "auto", "auto"):
+            N.set_option("tile_split", split)
+            L.compute_targets(b)  # value pass + scan (forward kernel, 2^19 rows: split because it runs alone)
+            clk = torch.zeros(512, 4, dtype=torch.int64, device=b.device)
+            N.check(lib.cm_clock_probe(N.ptr(clk)), "cm_clock_probe")
+            L.actor_pass(b, s)
+            torch.cuda.synchronize()
+            N.check(lib.cm_clock_probe(None), "cm_clock_probe")
+            outs.setdefault(split, []).append((L.values.clone(), L.g_actor.clone(), clk.cpu()))
+    finally:
+        N.set_option("tile_split", "auto")
+    (v50, g50, _), = outs["50"]
+    (va, ga, clk), (vb, gb, _) = outs["auto"]
+    assert torch.equal(v50, va) and torch.equal(va, vb)          # forward: same bits whatever the tile -> workgroup map
+    assert torch.equal(ga, gb)                                   # the split is static: run-to-run identical
+    Pa = L.actor.numel()
+    assert not torch.equal(ga[:Pa], g50[:Pa])                    # it IS a different association of the partial sums ...
+    assert (ga[:Pa] - g50[:Pa]).abs().max().item() <= 1e-5 * g50[:Pa].abs().max().item()   # ... and nothing more
+    assert ga[Pa + N.STAT_COUNT].item() == g50[Pa + N.STAT_COUNT].item() == b.ep_len.sum().item()
+    # the probe: 512 workgroups, two per CU on 256 distinct CUs of 8 XCDs, a plausible shader clock, sane stamps
+    live = clk[clk[:, 3] > 0]
+    assert live.shape[0] == 512
+    xcc = (live[:, 1] >> 32) & 0xF
+    assert sorted(set(xcc.tolist())) == list(range(8))
+    ghz = live[:, 0].double() / ((live[:, 3] - live[:, 2]).double() / 1e8) / 1e9
+    assert 1.0 < float(ghz.min()) and float(ghz.max()) < 2.7, (float(ghz.min()), float(ghz.max()))
+    span = (live[:, 3].max() - live[:, 2].min()).item() / 1e5   # ms
+    assert 0.5 < span < 10.0

@@ -6,7 +6,7 @@
 // barrier in the tile loop, so the eight waves of the CU's single workgroup drift apart and fill each other's VALU / LDS phases;
 // the weights are shared in LDS once per CU.  Same arithmetic (exact fp32 products, fp32 accumulation; the order of the k / row
 // sums differs from k_mlp, as k_mlp's differs from the reference's).  Shapes: din <= 64, H <= 64, exactly one hidden->hidden
-// layer, <= 16 actions, 16-byte aligned rows; everything else stays on k_mlp.  DESIGN.md section 10 item 0 has the measurements
+// layer, <= 16 actions, 16-byte aligned rows; everything else stays on k_mlp.  docs/KERNEL_NOTES.md section 10 item 0 has the measurements
 // behind it (tools/probes/wave_private_probe.hip is the skeleton this grew from).
 //
 // MFMA 16x16x4 operand / result layout (lane l: r = l & 15, g = l >> 4): A[m = r][k = g], B[k = g][n = r], D register q holds

@@ -2,7 +2,7 @@
 """Floor of the small-message all-reduce cost over RCCL: ONE rank (the only GPU a test box has), the two message sizes of config 3
 (actor 33 KB, critic 116 KB), asynchronous handles waited for by stream order as PPOLearner.update does.  A one-rank all-reduce moves no
 data between GPUs: what is timed is the library's launch path (enqueue + its kernel), i.e. a lower bound of the per-message latency L in
-DESIGN.md section 6."""
+docs/KERNEL_NOTES.md section 6."""
 import os
 import time
 

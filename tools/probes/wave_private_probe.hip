@@ -1,4 +1,4 @@
-// wave_private_probe.hip -- feasibility probe for DESIGN.md §10 item 0 (NOT part of the product; numerics unchecked).
+// wave_private_probe.hip -- feasibility probe for docs/KERNEL_NOTES.md §10 item 0 (NOT part of the product; numerics unchecked).
 //
 // Question: how fast does the MFMA / LDS / HBM skeleton of the actor fwd+bwd pass run when every wave owns a 16-row tile end
 // to end (no workgroup barrier in the tile loop), compared with the 2 x 2 wave split of k_mlp (1.87 ms at config 3, matrix
