@@ -284,7 +284,14 @@ def message_latencies(w, dev, pg, N, peer_too=True):
         if peer_too:
             try:
                 peer = D.PeerAllReduce(n, pg)
+                # one exchange first, waited for, with a short wall-time bound: a mailbox mapping that does not reach its peer shows up here as
+                # an error after 5 s (the step kernel gives up, check() raises) instead of 120 timed launches giving up one after the other
+                peer.timeout_s = min(peer.timeout_s, 5.0)
+                peer.step(buf, npar, opt(), N.stream_ptr())
+                torch.cuda.synchronize()
+                peer.check()
                 lat["peer_exchange_plus_step"][key] = timed(lambda: peer.step(buf, npar, opt(), N.stream_ptr()))
+                peer.check()
                 peer.close()
             except Exception as ex:  # noqa: BLE001 -- e.g. a node without peer access: reported, not fatal
                 lat["peer_exchange_plus_step"][key] = repr(ex)[:200]

@@ -15,7 +15,7 @@ from multiprocessing import Pipe, Process, shared_memory
 
 import numpy as np
 
-from .vector import environment
+from .vector import EnvWorkerDied, environment, recv_from_worker, send_to_worker  # noqa: F401
 
 
 def _worker(conn, factory_args, lo, hi, names, shapes, index_offset=0):
@@ -80,15 +80,16 @@ class ShmVectorEnv:
             parent, child = Pipe()
             p = Process(target=_worker, args=(child, factory_args, lo, hi, names, self.shapes, index_offset), daemon=True)
             p.start()
+            child.close()  # see vector.recv_from_worker: a dead worker must surface as an error, not as a hang
             self.conns.append(parent); self.procs.append(p)
 
     def info(self):
         return {"obs_size": self.Do, "action_size": self.K, "n_agents": self.A, "state_size": self.Ds}
 
     def _all(self, task):
-        for c in self.conns:
-            c.send(task)
-        return [c.recv() for c in self.conns]
+        for w, (c, p) in enumerate(zip(self.conns, self.procs)):
+            send_to_worker(c, p, task, f"shared-memory env worker {w}")
+        return [recv_from_worker(c, p, f"shared-memory env worker {w}") for w, (c, p) in enumerate(zip(self.conns, self.procs))]
 
     def collect_episode(self, act_fn, recurrent_state=None):
         """One episode per env.  act_fn(obs[n,A,Do], avail[n,A,K], alive_idx) -> (actions[n,A], logp[n,A]).
@@ -131,7 +132,7 @@ class ShmVectorEnv:
     def close(self):
         try:
             self._all("close")
-        except (BrokenPipeError, OSError, EOFError):
+        except (BrokenPipeError, OSError, EOFError, EnvWorkerDied):
             pass
         for p in self.procs:
             p.join(timeout=5)

@@ -56,6 +56,34 @@ def env_worker(conn, factory_args):
             break
 
 
+class EnvWorkerDied(RuntimeError):
+    """An env worker process ended while the driver was waiting for its answer."""
+
+
+def recv_from_worker(conn, proc, what="env worker"):
+    """conn.recv() that notices a dead worker.  The reference blocks in a bare recv() (cleanmarl/mappo_multienvs.py:318, 396) and, because the
+    parent keeps its copy of the child's pipe end, never even gets an EOFError: an env that crashes (an assertion inside a SMAC map, an OOM
+    kill) hangs the run for ever.  Here the parent closes the child's end after the fork (a dead worker then raises EOFError on the
+    parent's end) and polls in one-second slices, checking that the process is still alive."""
+    while True:
+        try:
+            if conn.poll(1.0):
+                return conn.recv()
+        except (EOFError, ConnectionResetError, BrokenPipeError, OSError) as ex:
+            raise EnvWorkerDied(f"{what} (pid {proc.pid}) closed its pipe: exit code {proc.exitcode}") from ex
+        if not proc.is_alive():
+            if conn.poll(0):  # its last message may still be in the pipe
+                continue
+            raise EnvWorkerDied(f"{what} (pid {proc.pid}) died with exit code {proc.exitcode} while the driver waited for its answer")
+
+
+def send_to_worker(conn, proc, msg, what="env worker"):
+    try:
+        conn.send(msg)
+    except (BrokenPipeError, ConnectionResetError, OSError) as ex:
+        raise EnvWorkerDied(f"{what} (pid {proc.pid}) is gone (exit code {proc.exitcode}): cannot send {msg[0] if isinstance(msg, tuple) else msg!r}") from ex
+
+
 class PipeVectorEnv:
     """B daemon processes, one env each.  index_offset: global index of env 0 (the first env of this rank's shard when the
     batch is env-sharded over ranks), so that index-keyed envs differ between ranks."""
@@ -67,22 +95,29 @@ class PipeVectorEnv:
             parent, child = Pipe()
             p = Process(target=env_worker, args=(child, dict(factory_args, index=index_offset + i)), daemon=True)
             p.start()
+            child.close()  # the parent's copy of the child's end: with it open a dead worker never produces an EOFError here
             self.conns.append(parent)
             self.procs.append(p)
 
+    def _recv(self, i):
+        return recv_from_worker(self.conns[i], self.procs[i], f"env worker {i}")
+
+    def _send(self, i, msg):
+        send_to_worker(self.conns[i], self.procs[i], msg, f"env worker {i}")
+
     def info(self):
-        self.conns[0].send(("get_env_info", None))
-        return self.conns[0].recv()
+        self._send(0, ("get_env_info", None))
+        return self._recv(0)
 
     def reset_all(self, seeds=None):
-        for i, c in enumerate(self.conns):
-            c.send(("reset", None if seeds is None else seeds[i]))
-        return [c.recv() for c in self.conns]
+        for i in range(self.n):
+            self._send(i, ("reset", None if seeds is None else seeds[i]))
+        return [self._recv(i) for i in range(self.n)]
 
     def step(self, env_ids, actions):
         for i, a in zip(env_ids, actions):
-            self.conns[i].send(("step", a))
-        return [self.conns[i].recv() for i in env_ids]
+            self._send(i, ("step", a))
+        return [self._recv(i) for i in env_ids]
 
     def close(self):
         for c in self.conns:

@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -175,3 +176,33 @@ def test_lds_hazard_linter_flags_a_copy_before_the_wait(tmp_path):
         f.write_text(text)
         probs, nk, nhand = lint.lint_file(str(f))
         assert nk == 1 and nhand == 1 and len(probs) == want, (text, probs)
+
+
+@pytest.mark.parametrize("kind", ["pipe", "shm"])
+def test_a_dead_env_worker_is_an_error_not_a_hang(kind):
+    """The reference waits in a bare recv() (cleanmarl/mappo_multienvs.py:318, 396) and keeps the child's pipe end open in the parent: an
+    env process that dies leaves the run hanging for ever.  Both vector envs of the build notice it (the parent closes the child's end
+    after the fork and polls with a liveness check) and raise EnvWorkerDied."""
+    import os
+    import signal
+    from cleanmarl_amd.env.shm_vector import ShmVectorEnv
+    from cleanmarl_amd.env.vector import EnvWorkerDied, PipeVectorEnv
+    fac = dict(env_type="synthetic_cpu", env_name="x", env_family="mpe", agent_ids=True, kwargs={}, seed=3, synthetic=dict(agents=2, steps=5, ragged=False))
+    if kind == "pipe":
+        v = PipeVectorEnv(3, fac)
+        v.reset_all()
+        os.kill(v.procs[1].pid, signal.SIGKILL)
+        v.procs[1].join(timeout=5)
+        with pytest.raises(EnvWorkerDied, match="env worker 1"):
+            v.reset_all()
+    else:
+        v = ShmVectorEnv(4, fac, n_workers=2)
+        v._all("reset")
+        os.kill(v.procs[0].pid, signal.SIGKILL)
+        v.procs[0].join(timeout=5)
+        with pytest.raises(EnvWorkerDied, match="worker 0"):
+            v._all("reset")
+    try:
+        v.close()
+    except Exception:  # noqa: BLE001 -- closing a half-dead pool must not raise anything new; a worker that is gone is gone
+        pass
