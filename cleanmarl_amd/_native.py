@@ -28,7 +28,7 @@ class OptStep(C.Structure):
     """cm_opt_step_t of include/cleanmarl_hip.h: one optimiser step, fused behind a training pass by the *_train_step entry points."""
     _fields_ = [("params", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("out_norm", _p), ("scratch", _p),
                 ("lr", _d), ("beta1", _d), ("beta2", _d), ("eps", _d), ("weight_decay", _d), ("max_norm", _d), ("grad_scale", _d),
-                ("step", C.c_int32), ("opt_kind", C.c_int32)]
+                ("step", C.c_int32), ("opt_kind", C.c_int32), ("stats_out", _p)]
 
 
 _po = C.POINTER(OptStep)

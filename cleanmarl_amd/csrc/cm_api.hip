@@ -13,7 +13,7 @@ void cm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cm_last_error(void) { return g_err; }
-extern "C" int cm_version(void) { return 100; }
+extern "C" int cm_version(void) { return 101; }  // 101: cm_opt_step_t::stats_out, cm_optimizer_step_peer(timeout_s, status), cm_clock_probe
 
 // ---- schedule / arithmetic options (include/cleanmarl_hip.h: cm_set_option).  The library never reads the process environment:
 // a caller that wants to force a schedule says so through this entry point (cleanmarl_amd/_native.py maps its CM_* test hooks onto it).

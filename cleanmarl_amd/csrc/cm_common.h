@@ -31,6 +31,10 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
                           const unsigned long long* peer_tags = nullptr, unsigned peer_seq = 0, double peer_timeout_s = 0.0,
                           unsigned* peer_status = nullptr);
 
+// launches whose optimiser step is the stand-alone cm_grad_norm_clip_adam (layered schedules): cm_opt_step_t::stats_out is served by a copy
+inline void cm_copy_stats_out(const cm_opt_step_t* o, const float* grad_and_stats, int64_t n_params, hipStream_t s) {
+    if (o && o->stats_out) (void)hipMemcpyAsync(o->stats_out, grad_and_stats + n_params, CM_NUM_STATS * sizeof(float), hipMemcpyDeviceToDevice, s);
+}
 unsigned cm_next_step_tag();  // tags of the step's hand-off words: unique per launch within the process, never 0 (cm_optim.hip)
 int cm_opt_check(const char* who, int64_t n_params, const cm_opt_step_t* o);
 

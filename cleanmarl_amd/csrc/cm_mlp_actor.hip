@@ -23,6 +23,7 @@ extern "C" size_t cm_ppo_actor_workspace_bytes(int E, int A, int T, int din, int
 // the stand-alone optimiser step behind a schedule that cannot carry it in its reduction launch (layered shapes)
 static int step_after(int rc, float* grad_and_stats, int64_t P, const cm_opt_step_t* o, cm_stream_t stream) {
     if (rc || !o) return rc;
+    cm_copy_stats_out(o, grad_and_stats, P, (hipStream_t)stream);
     return cm_grad_norm_clip_adam(o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq, P, o->step, o->lr, o->beta1, o->beta2, o->eps,
                                   o->weight_decay, o->opt_kind, o->max_norm, o->grad_scale, o->out_norm, stream);
 }

@@ -25,6 +25,7 @@ static int critic_pass(const float* x, int64_t x_ld, const float* ret, const int
     if (wide) {
         const int rc = wide_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd");
         if (rc || !opt) return rc;
+        cm_copy_stats_out(opt, grad_and_stats, cm_mlp_param_count(din, hidden, n_hidden_layers, 1), (hipStream_t)stream);
         return cm_grad_norm_clip_adam(opt->params, grad_and_stats, opt->exp_avg, opt->exp_avg_sq, cm_mlp_param_count(din, hidden, n_hidden_layers, 1),
                                       opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->opt_kind, opt->max_norm,
                                       opt->grad_scale, opt->out_norm, stream);

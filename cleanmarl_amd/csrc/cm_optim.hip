@@ -217,6 +217,7 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
         // beyond the scratch's sumsq slots (or no scratch): plain reduction + the stand-alone step
         hipLaunchKernelGGL(k_reduce_cols, dim3(grid), dim3(STEP_COLS * STEP_GROUPS), 0, s, part1, np1, PS1, part2, np2, PS2, isplit, (int)ntot, grad_and_stats);
         CM_CHECK_LAUNCH(who);
+        cm_copy_stats_out(o, grad_and_stats, n_params, s);
         return cm_grad_norm_clip_adam(o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq, n_params, o->step, o->lr, o->beta1, o->beta2, o->eps,
                                       o->weight_decay, o->opt_kind, o->max_norm, o->grad_scale, o->out_norm, (cm_stream_t)s);
     }

@@ -37,6 +37,7 @@ struct StepArgs {
     float* g; float* params; float* m; float* v;
     float lr, bc1, beta1, beta2, eps, wd, grad_scale, bc2_sqrt; int kind;
     float* out_norm; unsigned long long* nword; unsigned long long* slots; unsigned tag;
+    float* stats_out;   // optional second destination of the CM_NUM_STATS statistic sums (cm_opt_step_t::stats_out)
     const unsigned long long* peer_tags; unsigned peer_seq;
     unsigned long long peer_timeout;  // wall-clock bound of the wait for the peers' tags, in s_memrealtime ticks (100 MHz)
     unsigned* peer_status;            // optional host-visible word: set to peer_seq by a launch whose wait ran out (the step is then SKIPPED)
@@ -101,7 +102,7 @@ inline void step_args_fill(StepArgs& a, const float* part1, int np1, int PS1, co
     a.g = grad_and_stats; a.params = o->params; a.m = o->exp_avg; a.v = o->exp_avg_sq;
     a.lr = (float)o->lr; a.bc1 = (float)bc1; a.beta1 = (float)o->beta1; a.beta2 = (float)o->beta2; a.eps = (float)o->eps;
     a.wd = (float)o->weight_decay; a.grad_scale = (float)o->grad_scale; a.bc2_sqrt = (float)sqrt(bc2); a.kind = o->opt_kind;
-    a.out_norm = o->out_norm; a.nword = (unsigned long long*)o->scratch; a.slots = a.nword + 8;
+    a.out_norm = o->out_norm; a.nword = (unsigned long long*)o->scratch; a.slots = a.nword + 8; a.stats_out = o->stats_out;
     a.tag = cm_next_step_tag();
 }
 // LD: how the partial rows are read -- 0 plain loads (rows written by an earlier launch), 1 system-scope loads (peer mailbox slots),
@@ -204,6 +205,7 @@ __device__ __forceinline__ void step_fold_slab(const StepArgs& a, int bid, int n
         }
     } else if (i < a.ntot) {
         a.g[i] = t;       // statistics: un-normalised sums
+        if (a.stats_out) a.stats_out[i - a.n] = t;
     }
     ss = cm_wave_sum(ss);
     if (c == 0) __hip_atomic_store(a.slots + bid, step_word(a.tag, ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

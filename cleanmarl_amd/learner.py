@@ -160,12 +160,14 @@ class _Adam:
         # ticket + per-workgroup sums of squares of the fused step launch (cm_opt_step_t.scratch): zeroed once, left zeroed by the kernels
         self.scratch = torch.zeros(N.load().cm_opt_step_scratch_bytes(), dtype=torch.uint8, device=device)
 
-    def next_step(self, params, out_norm, max_norm, grad_scale=1.0):
-        """cm_opt_step_t of the NEXT optimiser step on `params` (advances the step counter)."""
+    def next_step(self, params, out_norm, max_norm, grad_scale=1.0, stats_out=None):
+        """cm_opt_step_t of the NEXT optimiser step on `params` (advances the step counter).  stats_out: [8] device view that also receives
+        the statistic sums (a row of the caller's record buffer: no copy launch afterwards)."""
         self.step += 1
         return N.OptStep(params=params.data_ptr(), exp_avg=self.m.data_ptr(), exp_avg_sq=self.v.data_ptr(), out_norm=out_norm.data_ptr(),
                          scratch=self.scratch.data_ptr(), lr=self.lr, beta1=0.9, beta2=self.beta2, eps=1e-8, weight_decay=self.wd,
-                         max_norm=float(max_norm), grad_scale=float(grad_scale), step=self.step, opt_kind=self.kind)
+                         max_norm=float(max_norm), grad_scale=float(grad_scale), step=self.step, opt_kind=self.kind,
+                         stats_out=0 if stats_out is None else stats_out.data_ptr())
 
 
 class LazyRecords:
@@ -362,8 +364,9 @@ class PPOLearner:
             N.check(lib.cm_normalize(N.ptr(b.ret), N.ptr(b.ep_len), E, A, T, N.ptr(self.moments), 0.0, 0, s), "cm_normalize")
 
     # ------------------------------------------------------------------ a8 - a12
-    def _adam(self, params, g, opt, which, s, grad_scale=1.0, out_norm=None):
-        """out_norm: 1-element device view that receives the pre-clip gradient norm (default: self.norms[which])."""
+    def _adam(self, params, g, opt, which, s, grad_scale=1.0, out_norm=None, stats_out=None):
+        """out_norm: 1-element device view that receives the pre-clip gradient norm (default: self.norms[which]).  stats_out: see
+        _Adam.next_step (the stand-alone two-launch step does not write it: its callers copy the statistics themselves)."""
         hp = self.hp
         if not self.fused_step:  # the stand-alone two-launch step (A/B runs, tests of the fused launch against it)
             opt.step += 1
@@ -372,7 +375,7 @@ class PPOLearner:
                                                     grad_scale, N.ptr(self.norms[which:] if out_norm is None else out_norm), s),
                     "cm_grad_norm_clip_adam")
             return
-        o = opt.next_step(params, self.norms[which:] if out_norm is None else out_norm, hp.clip_gradients, grad_scale)
+        o = opt.next_step(params, self.norms[which:] if out_norm is None else out_norm, hp.clip_gradients, grad_scale, stats_out)
         N.check(self.lib.cm_optimizer_step(N.ptr(g), params.numel(), o, s), "cm_optimizer_step")
 
     def _timed(self, kind, fn, *a):
@@ -415,7 +418,7 @@ class PPOLearner:
                 self._critic_joined.add(key)    # (kernel trace of the 512-env share: 25 us instead of 11 before the first actor pass)
                 st.wait_event(self._critic_done)
 
-    def critic_pass(self, b, s, g=None, step=None):
+    def critic_pass(self, b, s, g=None, step=None, stats=None):
         """g: [Pc + 8] gradient + statistics buffer to fill (default self.g_critic).  step: 1-element device view for the pre-clip norm --
         the critic's optimiser step then rides on the pass's reduction launch (cm_critic_train_step_ld; one process only: no all-reduce
         can come between the two)."""
@@ -427,7 +430,7 @@ class PPOLearner:
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
         if step is not None:
-            o = self.opt_c.next_step(self.critic, step, self.hp.clip_gradients)
+            o = self.opt_c.next_step(self.critic, step, self.hp.clip_gradients, stats_out=stats)
             N.check(self.lib.cm_critic_train_step_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len),
                                                      b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
                                                      N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), o, s),
@@ -438,7 +441,7 @@ class PPOLearner:
                                            N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), s),
                 "cm_critic_fwd_bwd")
 
-    def actor_pass(self, b, s, g=None, step=None):
+    def actor_pass(self, b, s, g=None, step=None, stats=None):
         """g: [Pa + 8] gradient + statistics buffer to fill (default self.g_actor).  step: see critic_pass."""
         if self._empty_shard(b):
             (self.g_actor if g is None else g).zero_()
@@ -446,7 +449,7 @@ class PPOLearner:
         self._ensure_ws(b)
         a = self.actor_spec
         if step is not None:
-            o = self.opt_a.next_step(self.actor, step, self.hp.clip_gradients)
+            o = self.opt_a.next_step(self.actor, step, self.hp.clip_gradients, stats_out=stats)
             N.check(self.lib.cm_ppo_actor_train_step_ld(N.ptr(b.obs), b.obs_ld, N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv),
                                                         N.ptr(b.ep_len), b.E, b.A, b.T, a.din, a.hidden, a.n_layers, a.dout,
                                                         self.hp.ppo_clip, self.hp.entropy_coef,
@@ -532,6 +535,9 @@ class PPOLearner:
         self.critic_span = None
 
         ride = self.fused_step and not self._coll  # the optimiser step rides on the pass's reduction launch
+        # statistics of an epoch: written into `rec` by the step launch itself (stats_out) -- except by the stand-alone A/B step and by
+        # the passes of a rank without environments (no launch at all: their zero buffers are copied like before)
+        copy_stats = (not self.fused_step) or b.E == 0
 
         def actor_step(ep, wa):
             g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
@@ -540,11 +546,11 @@ class PPOLearner:
                     kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
                 return
             if self.peer_a is not None:
-                self.peer_a.step(g_actor, Pa, self.opt_a.next_step(self.actor, rec[ep, 2 * N.NUM_STATS:], hp.clip_gradients), s)
+                self.peer_a.step(g_actor, Pa, self.opt_a.next_step(self.actor, rec[ep, 2 * N.NUM_STATS:], hp.clip_gradients, stats_out=rec[ep, :N.NUM_STATS]), s)
             else:
                 if wa is not None:
                     wa.wait()
-                self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:])
+                self._adam(self.actor, g_actor, self.opt_a, 0, s, out_norm=rec[ep, 2 * N.NUM_STATS:], stats_out=rec[ep, :N.NUM_STATS])
             if keep_grads:
                 kept_a.append((g_actor[:Pa].clone(), self.actor.clone()))
 
@@ -555,11 +561,12 @@ class PPOLearner:
                     kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
                 return
             if self.peer_c is not None:
-                self.peer_c.step(g_critic, Pc, self.opt_c.next_step(self.critic, rec[ep, 2 * N.NUM_STATS + 1:], hp.clip_gradients), sc)
+                self.peer_c.step(g_critic, Pc, self.opt_c.next_step(self.critic, rec[ep, 2 * N.NUM_STATS + 1:], hp.clip_gradients,
+                                                                     stats_out=rec[ep, N.NUM_STATS:2 * N.NUM_STATS]), sc)
             else:
                 if wc is not None:
                     wc.wait()
-                self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:])
+                self._adam(self.critic, g_critic, self.opt_c, 1, sc, out_norm=rec[ep, 2 * N.NUM_STATS + 1:], stats_out=rec[ep, N.NUM_STATS:2 * N.NUM_STATS])
             if keep_grads:
                 kept_c.append((g_critic[:Pc].clone(), self.critic.clone()))
 
@@ -568,11 +575,12 @@ class PPOLearner:
             pending = None  # the critic's optimiser step of the previous epoch, due before the next critic pass
             for ep in range(nE0):
                 g = self.gbuf_rows[ep]
-                self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS], rec[ep, 2 * N.NUM_STATS:] if ride else None)
+                self._timed("actor", self.actor_pass, b, s, g[:Pa + N.NUM_STATS], rec[ep, 2 * N.NUM_STATS:] if ride else None, rec[ep, :N.NUM_STATS])
                 wa = dist.allreduce_sum_async(g[:Pa + N.NUM_STATS], self.pg) if (self._coll and self.peer_a is None) else None
                 if pending is not None:
                     critic_step(*pending, s)
-                self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:], rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
+                self._timed("critic", self.critic_pass, b, s, g[Pa + N.NUM_STATS:], rec[ep, 2 * N.NUM_STATS + 1:] if ride else None,
+                            rec[ep, N.NUM_STATS:2 * N.NUM_STATS])
                 wc = dist.allreduce_sum_async(g[Pa + N.NUM_STATS:], self.pg_c) if (self._coll and self.peer_c is None) else None
                 actor_step(ep, wa)
                 if self._coll:
@@ -581,8 +589,9 @@ class PPOLearner:
                     critic_step(ep, None, s)
             if pending is not None:
                 critic_step(*pending, s)
-            rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
-            rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+            if copy_stats:  # (the fused step launches wrote every epoch's statistics into `rec` themselves: cm_opt_step_t::stats_out)
+                rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]
+                rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
             host, ev, attach = _to_host_async(self._ring, rec)  # no host wait here: see LazyRecords
         else:
             if self._critic_stream is None:
@@ -591,7 +600,7 @@ class PPOLearner:
 
             def actor_epoch(ep):
                 g_actor = self.gbuf_rows[ep][:Pa + N.NUM_STATS]
-                self._timed("actor", self.actor_pass, b, s, g_actor, rec[ep, 2 * N.NUM_STATS:] if ride else None)
+                self._timed("actor", self.actor_pass, b, s, g_actor, rec[ep, 2 * N.NUM_STATS:] if ride else None, rec[ep, :N.NUM_STATS])
                 actor_step(ep, dist.allreduce_sum_async(g_actor, self.pg) if (self._coll and self.peer_a is None) else None)
 
             def critic_epoch(ep):
@@ -601,10 +610,12 @@ class PPOLearner:
                         self._c0 = torch.cuda.Event(enable_timing=True)
                         self._c0.record()
                     g_critic = self.gbuf_rows[ep][Pa + N.NUM_STATS:]
-                    self._timed("critic", self.critic_pass, b, sc, g_critic, rec[ep, 2 * N.NUM_STATS + 1:] if ride else None)
+                    self._timed("critic", self.critic_pass, b, sc, g_critic, rec[ep, 2 * N.NUM_STATS + 1:] if ride else None,
+                                rec[ep, N.NUM_STATS:2 * N.NUM_STATS])
                     critic_step(ep, dist.allreduce_sum_async(g_critic, self.pg_c) if (self._coll and self.peer_c is None) else None, sc)
                     if ep == nE0 - 1:
-                        rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
+                        if copy_stats:
+                            rec[:, N.NUM_STATS:2 * N.NUM_STATS] = self.gbuf_rows[:nE0, Pa + N.NUM_STATS + Pc:]
                         if timed:
                             c1 = torch.cuda.Event(enable_timing=True)
                             c1.record()
@@ -627,7 +638,8 @@ class PPOLearner:
                     critic_epoch(ep)
             side.wait_stream(main)  # the statistics need both halves; they leave on the critic stream, `main` never waits for them
             with torch.cuda.stream(side):
-                rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]  # on the side stream too: nothing trails the actor's last step on `main`
+                if copy_stats:
+                    rec[:, :N.NUM_STATS] = self.gbuf_rows[:nE0, Pa:Pa + N.NUM_STATS]  # on the side stream too: nothing trails the actor's last step on `main`
                 host, ev, attach = _to_host_async(self._ring, rec)
                 self._critic_done = torch.cuda.Event()
                 self._critic_done.record(side)

@@ -54,7 +54,7 @@ enum {
 enum { CM_OPT_ADAM = 0, CM_OPT_ADAMW = 1, CM_OPT_SGD = 2, CM_OPT_RMSPROP = 3 };  /* RMSprop: beta2 := alpha (torch default 0.99) */
 
 const char* cm_last_error(void);
-int cm_version(void);
+int cm_version(void);  /* 101 since round 5 (cm_opt_step_t grew by stats_out; cm_optimizer_step_peer takes timeout_s / status; cm_clock_probe) */
 /* Schedule / arithmetic options.  The library picks schedules from the problem size (thresholds measured on MI355X);
  * a caller can force one -- for A/B measurements, tests, or a box where the thresholds sit elsewhere.  The library never reads the
  * process environment.  Options are process-wide, take effect at the next launch and may be changed at any time
@@ -217,6 +217,9 @@ typedef struct cm_opt_step {
     double lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale;
     int32_t step;       /* 1-based optimiser step (bias correction) */
     int32_t opt_kind;   /* CM_OPT_* */
+    float* stats_out;   /* optional [CM_NUM_STATS]: the un-normalised statistic sums (what follows the gradient in grad_and_stats) are ALSO
+                           written here by the step launch -- e.g. one row of a per-epoch record buffer, so that no copy launch has to collect
+                           them afterwards (mappo_multienvs.py:597-612's logged scalars); NULL: not written */
 } cm_opt_step_t;
 size_t cm_opt_step_scratch_bytes(void);
 int cm_optimizer_step(float* grad_and_stats, int64_t n_params, const cm_opt_step_t* opt, cm_stream_t stream);

@@ -90,7 +90,7 @@ def test_ctypes_recipe_reproduces_the_reference(golden_dir, name):
 class OptStep(C.Structure):  # cm_opt_step_t exactly as INTEGRATION.md section 6c declares it
     _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("out_norm", C.c_void_p), ("scratch", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
-                ("max_norm", C.c_double), ("grad_scale", C.c_double), ("step", C.c_int32), ("opt_kind", C.c_int32)]
+                ("max_norm", C.c_double), ("grad_scale", C.c_double), ("step", C.c_int32), ("opt_kind", C.c_int32), ("stats_out", C.c_void_p)]
 
 
 @pytest.mark.parametrize("name", ["mappo_dense", "mappo_ragged_norm"])
@@ -139,18 +139,21 @@ def test_ctypes_train_step_recipe_reproduces_the_reference(golden_dir, name):
                      dtype=torch.uint8, device="cuda")
     m_a, v_a, m_c, v_c = (torch.zeros(n, device="cuda") for n in (Pa, Pa, Pc, Pc))
     norms = torch.zeros(2, device="cuda")
+    rec = torch.zeros(int(hp["epochs"]), 8, device="cuda")  # cm_opt_step_t::stats_out (ABI 101): the actor's statistic sums of every epoch
+    assert lib.cm_version() >= 101
     scr_a, scr_c = (torch.zeros(lib.cm_opt_step_scratch_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2))
     try:
         for epoch in range(int(hp["epochs"])):
             oa = OptStep(actor_flat.data_ptr(), m_a.data_ptr(), v_a.data_ptr(), norms.data_ptr(), scr_a.data_ptr(), hp["learning_rate_actor"], 0.9,
-                         0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0)
+                         0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0, rec[epoch].data_ptr())
             oc = OptStep(critic_flat.data_ptr(), m_c.data_ptr(), v_c.data_ptr(), norms[1:].data_ptr(), scr_c.data_ptr(), hp["learning_rate_critic"],
-                         0.9, 0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0)
+                         0.9, 0.999, 1e-8, 0.0, hp["clip_gradients"], 1.0, epoch + 1, 0, None)
             chk(lib.cm_ppo_actor_train_step_ld(P(obs), C.c_int64(Do), P(avail), P(action), P(logp), P(adv), P(ep_len), E, A, T, Do, Ha, La, K,
                                                d(hp["ppo_clip"]), d(hp["entropy_coef"]), P(ga), P(ws), C.c_size_t(ws.numel()), C.byref(oa), S()))
             chk(lib.cm_critic_train_step_ld(P(state), C.c_int64(Ds), P(ret), P(ep_len), E, A, T, 0, Ds, Hc, Lc, P(gc), P(ws),
                                             C.c_size_t(ws.numel()), C.byref(oc), S()))
             st = ga[Pa:].cpu(); N = st[5]
+            assert torch.equal(rec[epoch].cpu(), st)  # the same sums, also where the caller asked for them
             assert _err(float((-st[0] - hp["entropy_coef"] * st[1]) / N), z["actor_losses"][epoch]) <= TOL
             assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
             assert _err(float(norms[0]), z["actor_gradients"][epoch]) <= TOL and _err(float(norms[1]), z["critic_gradients"][epoch]) <= TOL
