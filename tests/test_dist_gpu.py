@@ -350,10 +350,12 @@ def _coma_worker(rank, world, port, gold, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_reproduce_the_single_process_coma_reference(golden_dir, tmp_path):
-    """COMA: per-time-step advantage moments and the return normalisation need cross-rank sums; two env shards must land on
-    the unmodified single-process coma_multienvs.py result (tests/golden/coma_tdlambda.npz: ragged, normalisations on, clip)."""
-    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+@pytest.mark.parametrize("world", [2, 8])
+def test_env_shards_reproduce_the_single_process_coma_reference(golden_dir, tmp_path, world):
+    """COMA: per-time-step advantage moments and the return normalisation need cross-rank sums; the env shards must land on
+    the unmodified single-process coma_multienvs.py result (tests/golden/coma_tdlambda.npz: ragged, normalisations on, clip).
+    world 8: the golden holds 6 envs, so two ranks own none (COMALearner._empty_shard: zero buffers, every collective and step)."""
+    port, out = _free_port(), str(tmp_path / "rank")
     gold = os.path.join(golden_dir, "coma_tdlambda.npz")
     mp.spawn(_coma_worker, args=(world, port, gold, out), nprocs=world, join=True)
     z = np.load(gold)
@@ -365,7 +367,8 @@ def test_two_ranks_reproduce_the_single_process_coma_reference(golden_dir, tmp_p
         assert _err(g["rec"]["actor_gnorm"], float(z["actor_gradients"])) <= TOL
         assert _err(g["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(g["actor"].numpy(), z["actor_after"][0]) <= TOL
         assert _err(g["target"].numpy(), z["target_after"]) <= 1e-6
-    assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
+    for r in range(1, world):
+        assert torch.equal(got[0]["actor"], got[r]["actor"]) and torch.equal(got[0]["critic"], got[r]["critic"])
 
 
 def _gru_worker(rank, world, port, gold, algo, out):
@@ -396,11 +399,13 @@ def _gru_worker(rank, world, port, gold, algo, out):
     torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("name,algo", [("mappo_lstm_ragged", "mappo"), ("ippo_lstm_ragged", "ippo")])
-def test_two_ranks_reproduce_the_single_process_gru_reference(golden_dir, tmp_path, name, algo):
+def test_env_shards_reproduce_the_single_process_gru_reference(golden_dir, tmp_path, name, algo, world):
     """GRU / TBPTT: one all-reduce per chunk (actor) + one per epoch (critic); the env shards must land on the post-update
-    parameters of the unmodified single-process *_lstm_multienvs.py after all epochs x chunks optimiser steps."""
-    world, port, out = 2, _free_port(), str(tmp_path / "rank")
+    parameters of the unmodified single-process *_lstm_multienvs.py after all epochs x chunks optimiser steps.  world 8: the goldens
+    hold 6 / 5 envs -- two / three ranks own none and still enter every chunk's all-reduce and step (GRUPPOLearner: _empty_shard)."""
+    port, out = _free_port(), str(tmp_path / "rank")
     gold = os.path.join(golden_dir, name + ".npz")
     mp.spawn(_gru_worker, args=(world, port, gold, algo, out), nprocs=world, join=True)
     z = np.load(gold)
@@ -412,7 +417,8 @@ def test_two_ranks_reproduce_the_single_process_gru_reference(golden_dir, tmp_pa
             assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
         assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL
         assert _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
-    assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
+    for r in range(1, world):
+        assert torch.equal(got[0]["actor"], got[r]["actor"]) and torch.equal(got[0]["critic"], got[r]["critic"])
 
 
 def test_bench_contract_single_gpu():
