@@ -33,3 +33,20 @@ def _library_options_back_to_defaults():
             N._lib.cm_set_option(key.encode(), default.encode())
         N._applied.clear()
         N._env_seen.clear()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Observed maxima of the parity metrics (tests/parity.py) of this session -> gpurun_out/parity_observed.txt (or $CM_PARITY_REPORT):
+    the evidence that the bars of the GPU tests are bars the kernels pass with room, and by how much."""
+    try:
+        import parity
+    except Exception:
+        return
+    if not parity.OBSERVED:
+        return
+    path = os.environ.get("CM_PARITY_REPORT") or os.path.join(ROOT, "gpurun_out", "parity_observed.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        parity.report(path)
+    except OSError:
+        pass

@@ -6,14 +6,11 @@ import numpy as np
 import pytest
 import torch
 
+from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
+from parity import err as _err
+
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
-
-def _err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
 def _learner(batch, ap, cp, hp, dev, reward=None, target=None, pad=False):
@@ -50,12 +47,12 @@ def test_coma_update_matches_reference_golden(golden_dir, name):
     assert _err(rec["critic_loss"], float(z["cr_loss"])) <= TOL
     assert _err(rec["actor_loss"], float(z["ac_loss"])) <= TOL
     assert _err(rec["entropy"], float(z["entropies"])) <= TOL
-    assert _err(rec["critic_gnorm"], float(z["critic_gradients"])) <= TOL
-    assert _err(rec["actor_gnorm"], float(z["actor_gradients"])) <= TOL
-    assert _err(rec["critic_grads"].cpu().numpy(), z["critic_grads"][0]) <= TOL
-    assert _err(rec["actor_grads"].cpu().numpy(), z["actor_grads"][0]) <= TOL
-    assert _err(L.critic.cpu().numpy(), z["critic_after"][0]) <= TOL
-    assert _err(L.actor.cpu().numpy(), z["actor_after"][0]) <= TOL
+    assert grad_err(rec["critic_gnorm"], float(z["critic_gradients"])) <= GRAD_TOL
+    assert grad_err(rec["actor_gnorm"], float(z["actor_gradients"])) <= GRAD_TOL
+    check_grads(rec["critic_grads"], z["critic_grads"][0], "coma golden critic grad")
+    check_grads(rec["actor_grads"], z["actor_grads"][0], "coma golden actor grad")
+    check_step(L.critic, z["critic_after"][0], golden_before(z, "critic", 0), "coma golden critic step")
+    check_step(L.actor, z["actor_after"][0], golden_before(z, "actor", 0), "coma golden actor step")
     assert _err(L.target.cpu().numpy(), z["target_after"]) <= 1e-6
 
 
@@ -103,6 +100,7 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
     ts = 0
     for it in range(2):
         rec = L.train_iteration(b, keep_grads=True)
+        cp0, ap0 = R.flat(cp).clone(), R.flat(ap).clone()
         ref = C.update(ap, cp, tp, batch, hp, oa, oc, ts)
         ts = ref["training_step"]
         assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ref["ret"].numpy()) <= TOL, it
@@ -110,10 +108,11 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
         assert _err(b.adv.permute(0, 2, 1).cpu().numpy() * m, ref["adv"].numpy() * m) <= TOL, it
         assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, it
         assert _err(rec["entropy"], ref["entropy"]) <= TOL, it
-        assert _err(rec["critic_gnorm"], ref["critic_gnorm"]) <= TOL and _err(rec["actor_gnorm"], ref["actor_gnorm"]) <= TOL, it
-        assert _err(rec["critic_grads"].cpu().numpy(), ref["critic_grads"].numpy()) <= TOL, it
-        assert _err(rec["actor_grads"].cpu().numpy(), ref["actor_grads"].numpy()) <= TOL, it
-        assert _err(L.critic.cpu().numpy(), R.flat(cp).numpy()) <= TOL and _err(L.actor.cpu().numpy(), R.flat(ap).numpy()) <= TOL, it
+        assert grad_err(rec["critic_gnorm"], ref["critic_gnorm"]) <= GRAD_TOL and grad_err(rec["actor_gnorm"], ref["actor_gnorm"]) <= GRAD_TOL, it
+        check_grads(rec["critic_grads"], ref["critic_grads"], "coma oracle critic grad")
+        check_grads(rec["actor_grads"], ref["actor_grads"], "coma oracle actor grad")
+        check_step(L.critic, R.flat(cp), cp0, "coma oracle critic step")
+        check_step(L.actor, R.flat(ap), ap0, "coma oracle actor step")
         assert _err(L.target.cpu().numpy(), R.flat(tp).numpy()) <= TOL, it
 
 
@@ -143,15 +142,17 @@ def test_coma_on_padded_rollout_buffers_matches_oracle_and_the_contiguous_run(E,
     oa, oc = R.AdamState(ap, 5e-4, "Adam"), R.AdamState(cp, 5e-4, "Adam")
     ts = 0
     for it in range(2):
+        cp0, ap0 = R.flat(cp).clone(), R.flat(ap).clone()
         ref = C.update(ap, cp, tp, batch, hp, oa, oc, ts)
         ts = ref["training_step"]
         for pad in (False, True):
             rec = runs[pad][0][it]
             assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, (pad, it)
-            assert _err(rec["critic_grads"].cpu().numpy(), ref["critic_grads"].numpy()) <= TOL, (pad, it)
-            assert _err(rec["actor_grads"].cpu().numpy(), ref["actor_grads"].numpy()) <= TOL, (pad, it)
-    for pad in (False, True):
-        assert _err(runs[pad][1].cpu().numpy(), R.flat(cp).numpy()) <= TOL and _err(runs[pad][2].cpu().numpy(), R.flat(ap).numpy()) <= TOL
+            check_grads(rec["critic_grads"], ref["critic_grads"], "coma padded critic grad")
+            check_grads(rec["actor_grads"], ref["actor_grads"], "coma padded actor grad")
+    for pad in (False, True):  # two iterations' accumulated error against the LAST step's displacement
+        check_step(runs[pad][1], R.flat(cp), cp0, "coma padded critic step")
+        check_step(runs[pad][2], R.flat(ap), ap0, "coma padded actor step")
         assert _err(runs[pad][3].cpu().numpy(), R.flat(tp).numpy()) <= TOL
     for x, y in zip(runs[False][1:], runs[True][1:]):
         assert _err(x.cpu().numpy(), y.cpu().numpy()) <= 2e-6

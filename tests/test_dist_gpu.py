@@ -12,8 +12,10 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, disp_err, golden_before, golden_init, grad_err  # noqa: F401
+from parity import err as _err
+
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
 
 def _free_port():
@@ -22,10 +24,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+def _check_final_params(got, z, last=True):
+    """got["actor"] / got["critic"] after the update against the golden's parameters after its last (or only) optimiser step, as the
+    displacement of that step (tests/parity.py)."""
+    for net in ("actor", "critic"):
+        k = len(z[net + "_after"]) - 1 if last else 0
+        check_step(got[net], z[net + "_after"][k], golden_before(z, net, k), "dist final " + net + " step")
 
 
 def _worker(rank, world, port, gold, algo, out):
@@ -83,12 +87,12 @@ def test_env_shards_reproduce_the_single_process_reference(golden_dir, tmp_path,
             assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
             assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
             assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
-            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
-            assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
-            assert _err(r["actor_grads"].numpy(), z["actor_grads"][e]) <= TOL
-            assert _err(r["critic_grads"].numpy(), z["critic_grads"][e]) <= TOL
-            assert _err(r["actor_after"].numpy(), z["actor_after"][e]) <= TOL
-            assert _err(r["critic_after"].numpy(), z["critic_after"][e]) <= TOL
+            assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL
+            assert grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
+            check_grads(r["actor_grads"], z["actor_grads"][e], "env shards actor grad")
+            check_grads(r["critic_grads"], z["critic_grads"][e], "env shards critic grad")
+            check_step(r["actor_after"], z["actor_after"][e], golden_before(z, "actor", e), "env shards actor step")
+            check_step(r["critic_after"], z["critic_after"][e], golden_before(z, "critic", e), "env shards critic step")
     assert sum(g["n"] for g in got) == z["b_obs"].shape[0] and (world <= z["b_obs"].shape[0] or any(g["n"] == 0 for g in got))
     # replicated parameters stay bit-identical across ranks (same reduced buffer, same Adam kernel) -- ranks without envs included
     for e in range(len(got[0]["recs"])):
@@ -158,7 +162,7 @@ def test_peer_allreduce_processes_share_one_gpu(golden_dir, tmp_path, name, algo
             assert r["seq"] == (2 * nE, 2 * nE)
             for e, rec in enumerate(r["recs"]):
                 assert _err(rec["actor_loss"], z["actor_losses"][e]) <= TOL and _err(rec["critic_loss"], z["critic_losses"][e]) <= TOL, sched
-                assert _err(rec["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(rec["critic_gnorm"], z["critic_gradients"][e]) <= TOL, sched
+                assert grad_err(rec["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL and grad_err(rec["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL, sched
                 assert _err(rec["entropy"], z["entropies_bonuses"][e]) <= TOL and _err(rec["kl"], z["kl_divergences"][e]) <= TOL, sched
     for sched in ("0", "1", "2"):
         for r in range(1, world):
@@ -363,9 +367,9 @@ def test_env_shards_reproduce_the_single_process_coma_reference(golden_dir, tmp_
     for g in got:
         assert _err(g["rec"]["critic_loss"], float(z["cr_loss"])) <= TOL and _err(g["rec"]["actor_loss"], float(z["ac_loss"])) <= TOL
         assert _err(g["rec"]["entropy"], float(z["entropies"])) <= TOL
-        assert _err(g["rec"]["critic_gnorm"], float(z["critic_gradients"])) <= TOL
-        assert _err(g["rec"]["actor_gnorm"], float(z["actor_gradients"])) <= TOL
-        assert _err(g["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(g["actor"].numpy(), z["actor_after"][0]) <= TOL
+        assert grad_err(g["rec"]["critic_gnorm"], float(z["critic_gradients"])) <= GRAD_TOL
+        assert grad_err(g["rec"]["actor_gnorm"], float(z["actor_gradients"])) <= GRAD_TOL
+        _check_final_params(g, z, last=False)
         assert _err(g["target"].numpy(), z["target_after"]) <= 1e-6
     for r in range(1, world):
         assert torch.equal(got[0]["actor"], got[r]["actor"]) and torch.equal(got[0]["critic"], got[r]["critic"])
@@ -414,9 +418,8 @@ def test_env_shards_reproduce_the_single_process_gru_reference(golden_dir, tmp_p
         for e, r in enumerate(g["recs"]):
             assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
             assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL and _err(r["kl"], z["kl_divergences"][e]) <= TOL
-            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
-        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL
-        assert _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+            assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL and grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
+        _check_final_params(g, z, last=True)
     for r in range(1, world):
         assert torch.equal(got[0]["actor"], got[r]["actor"]) and torch.equal(got[0]["critic"], got[r]["critic"])
 
@@ -520,10 +523,10 @@ def _check_overlap_ranks(gold, out, world):
     z = np.load(gold)
     got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
     for g in got:
-        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+        _check_final_params(g, z, last=True)
         for e, r in enumerate(g["recs"]):
             assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
-            assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+            assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL and grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
     assert torch.equal(got[0]["actor"], got[1]["actor"]) and torch.equal(got[0]["critic"], got[1]["critic"])
 
 
@@ -575,7 +578,7 @@ def test_rccl_carries_the_all_reduces_of_every_update_schedule(golden_dir, tmp_p
     z = np.load(gold)
     got = torch.load(f"{out}.0", weights_only=False)
     for sched, g in got.items():
-        assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL, sched
+        _check_final_params(g, z, last=True)
         for e, r in enumerate(g["recs"]):
             assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL, sched
     assert torch.equal(got["1"]["actor"], got["2"]["actor"]) and torch.equal(got["1"]["critic"], got["2"]["critic"])
@@ -644,12 +647,12 @@ def test_rccl_carries_the_all_reduces_of_the_gru_and_coma_learners(golden_dir, t
     g = got["gru"]
     for e, r in enumerate(g["recs"]):
         assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL and _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
-        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL and _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
-    assert _err(g["actor"].numpy(), z["actor_after"][-1]) <= TOL and _err(g["critic"].numpy(), z["critic_after"][-1]) <= TOL
+        assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL and grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
+    _check_final_params(g, z, last=True)
     z = np.load(gc)
     c = got["coma"]
     assert _err(c["rec"]["critic_loss"], float(z["cr_loss"])) <= TOL and _err(c["rec"]["actor_loss"], float(z["ac_loss"])) <= TOL
-    assert _err(c["critic"].numpy(), z["critic_after"][0]) <= TOL and _err(c["actor"].numpy(), z["actor_after"][0]) <= TOL
+    _check_final_params(c, z, last=False)
     assert _err(c["target"].numpy(), z["target_after"]) <= 1e-6
 
 

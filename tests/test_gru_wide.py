@@ -8,7 +8,9 @@ import numpy as np
 import pytest
 import torch
 
-from test_hip_parity import TOL, _err, _random_case
+from test_hip_parity import _check_gru_against_oracle, _random_case
+from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
+from parity import err as _err
 
 pytestmark = pytest.mark.gpu
 
@@ -43,14 +45,7 @@ def test_layered_gru_update_matches_oracle(algo, E, A, T, Do, Ds, K, H, tb, fuse
     recs = L.train_iteration(b, keep_grads=True)
     ret, adv, orecs = R.gru_update(ap, cp, batch, hp, algo)
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL and _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
-    for r, o in zip(recs, orecs):
-        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
-            assert _err(r[k], o[k]) <= TOL, k
-        assert len(r["actor_steps"]) == len(o["actor_steps"])
-        for (g, after), ost in zip(r["actor_steps"], o["actor_steps"]):
-            assert _err(g.cpu().numpy(), R.flat(ost["grads"]).numpy()) <= TOL
-            assert _err(after.cpu().numpy(), R.flat(ost["after"]).numpy()) <= TOL
-        assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
+    _check_gru_against_oracle(recs, orecs, ap, cp, "gru layered")
 
 
 @pytest.mark.parametrize("rows,Do,Hd,K", [(150, 115, 64, 17), (70, 35, 128, 5), (33, 70, 96, 6), (90, 35, 64, 36), (150, 35, 64, 5)])

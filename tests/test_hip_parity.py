@@ -6,18 +6,15 @@ import numpy as np
 import pytest
 import torch
 
+from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, disp_err, golden_before, golden_init, grad_err  # noqa: F401
+from parity import err as _err
+
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4  # BASELINE.json north_star: returns / advantages / losses within 1e-4 fp32
 
 MLP_CASES = [("mappo_dense", "mappo"), ("mappo_ragged_norm", "mappo"), ("mappo_deep", "mappo"), ("mappo_wide", "mappo"), ("mappo_rmsprop", "mappo"), ("ippo_sgd", "ippo"),
              ("ippo_dense", "ippo"), ("ippo_ragged_norm", "ippo")]
 
-
-def _err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
 
 
 def _learner_from_golden(path, algo):
@@ -40,28 +37,47 @@ def _learner_from_golden(path, algo):
     return L, b, z, batch
 
 
+def _check_update_against_golden(b, recs, z, label):
+    """Every quantity the reference logs or produces in an update against the golden of the unmodified reference (tests/parity.py: the
+    three bars).  Raises AssertionError on the first miss."""
+    if "b_reward_raw" in z.files:
+        assert _err(b.reward, z["b_reward"], "reward") <= TOL
+    ret = b.ret.permute(0, 2, 1).cpu().numpy()
+    adv = b.adv.permute(0, 2, 1).cpu().numpy()
+    assert _err(ret, z["return_lambda"], "returns") <= TOL
+    assert _err(adv, z["advantages"], "advantages") <= TOL
+    for e, r in enumerate(recs):
+        assert _err(r["actor_loss"], z["actor_losses"][e], "losses") <= TOL
+        assert _err(r["critic_loss"], z["critic_losses"][e], "losses") <= TOL
+        assert _err(r["entropy"], z["entropies_bonuses"][e], "statistics") <= TOL
+        assert _err(r["kl"], z["kl_divergences"][e], "statistics") <= TOL
+        assert _err(r["clipfrac"], z["clipped_ratios"][e], "statistics") <= TOL
+        assert grad_err(r["actor_gnorm"], z["actor_gradients"][e], "gnorm") <= GRAD_TOL
+        assert grad_err(r["critic_gnorm"], z["critic_gradients"][e], "gnorm") <= GRAD_TOL
+        check_grads(r["actor_grads"], z["actor_grads"][e], label + " actor grad")
+        check_grads(r["critic_grads"], z["critic_grads"][e], label + " critic grad")
+        check_step(r["actor_after"], z["actor_after"][e], golden_before(z, "actor", e), label + " actor step")
+        check_step(r["critic_after"], z["critic_after"][e], golden_before(z, "critic", e), label + " critic step")
+
+
 @pytest.mark.parametrize("name,algo", MLP_CASES)
 def test_update_matches_reference_golden(golden_dir, name, algo):
     L, b, z, batch = _learner_from_golden(os.path.join(golden_dir, name + ".npz"), algo)
     recs = L.train_iteration(b, keep_grads=True)
-    if "b_reward_raw" in z.files:
-        assert _err(b.reward.cpu().numpy(), z["b_reward"]) <= TOL
-    ret = b.ret.permute(0, 2, 1).cpu().numpy()
-    adv = b.adv.permute(0, 2, 1).cpu().numpy()
-    assert _err(ret, z["return_lambda"]) <= TOL
-    assert _err(adv, z["advantages"]) <= TOL
-    for e, r in enumerate(recs):
-        assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL
-        assert _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
-        assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
-        assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
-        assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
-        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
-        assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
-        assert _err(r["actor_grads"].cpu().numpy(), z["actor_grads"][e]) <= TOL
-        assert _err(r["critic_grads"].cpu().numpy(), z["critic_grads"][e]) <= TOL
-        assert _err(r["actor_after"].cpu().numpy(), z["actor_after"][e]) <= TOL
-        assert _err(r["critic_after"].cpu().numpy(), z["critic_after"][e]) <= TOL
+    _check_update_against_golden(b, recs, z, "mlp golden")
+
+
+@pytest.mark.parametrize("what,factor", [("learning_rate_actor", 1.05), ("learning_rate_critic", 0.95), ("ppo_clip", 0.5), ("td_lambda", 0.99)])
+def test_a_wrong_learner_fails_the_golden_comparison(golden_dir, what, factor):
+    """The bars can fail: a learner whose optimiser step is 5 % too long (or short), whose clip range is halved or whose lambda is off by
+    1 % does NOT pass the comparison that test_update_matches_reference_golden applies (under the old absolute 1e-4 on the parameters a
+    12 %-wrong Adam step passed: max|after - before| is 8e-4 in this golden)."""
+    L, b, z, batch = _learner_from_golden(os.path.join(golden_dir, "mappo_dense.npz"), "mappo")
+    setattr(L.hp, what, getattr(L.hp, what) * factor)
+    L.opt_a.lr, L.opt_c.lr = L.hp.learning_rate_actor, L.hp.learning_rate_critic
+    recs = L.train_iteration(b, keep_grads=True)
+    with pytest.raises(AssertionError):
+        _check_update_against_golden(b, recs, z, "deliberately wrong")
 
 
 def _random_case(seed, E, A, T, Do, Ds, K, ragged=True, avail_p=0.7):
@@ -204,14 +220,29 @@ def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
     recs = Lr.train_iteration(b, keep_grads=True)
     ret, adv, orecs = R.mlp_update(ap, cp, batch, hp, algo)
     errs = {"ret": _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()), "adv": _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy())}
+    before = {"actor": R.flat(ap), "critic": R.flat(cp)}
+    scale = tol / TOL  # callers with a looser tier (bf16) loosen every bar by the same factor
+    bars = {}
     for r, o in zip(recs, orecs):
-        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
-            errs[k] = max(errs.get(k, 0.0), _err(r[k], o[k]))
-        for k in ("actor_grads", "critic_grads", "actor_after", "critic_after"):
-            errs[k] = max(errs.get(k, 0.0), _err(r[k].cpu().numpy(), R.flat(o[k]).numpy()))
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
+            errs[k] = max(errs.get(k, 0.0), _err(r[k], o[k], "seeded " + k))
+        for k in ("actor_gnorm", "critic_gnorm"):
+            errs[k] = max(errs.get(k, 0.0), grad_err(r[k], o[k], "seeded gnorm"))
+            bars[k] = GRAD_TOL * scale
+        for net in ("actor", "critic"):
+            k = net + "_grads"
+            errs[k] = max(errs.get(k, 0.0), grad_err(r[k], R.flat(o[k]), "seeded " + k))
+            bars[k] = GRAD_TOL * scale
+            k = net + "_after"
+            errs[k] = max(errs.get(k, 0.0), disp_err(r[k], R.flat(o[k]), before[net], "seeded " + k))
+            bars[k] = DISP_TOL * scale
+            before[net] = R.flat(o[k])
     for k, v in errs.items():
-        assert v <= tol, (k, v)
+        assert v <= bars.get(k, tol), (k, v)
     return errs
+
+
+BF16X3_GRAD, BF16X3_STEP = 1e-3, 1e-1
 
 
 def test_bf16x3_opt_in_keeps_the_parity_bar():
@@ -224,7 +255,7 @@ def test_bf16x3_opt_in_keeps_the_parity_bar():
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_hip_parity as t; "
             "from cleanmarl_amd import _native as N; "
-            "e = t._seeded_case('mappo', 48, 8, 64, 56, 384, 5, 64, 1, True); e['mode'] = N.load().cm_mfma_mode(); print('ERRS ' + json.dumps(e))"
+            "e = t._seeded_case('mappo', 48, 8, 64, 56, 384, 5, 64, 1, True, tol=1e9); e['mode'] = N.load().cm_mfma_mode(); print('ERRS ' + json.dumps(e))"
             % (here, os.path.dirname(here)))
     out = {}
     for mode in ("bf16x3", ""):
@@ -233,7 +264,15 @@ def test_bf16x3_opt_in_keeps_the_parity_bar():
         assert p.returncode == 0, p.stderr[-2000:]
         out[mode] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("ERRS ")][0][5:])
     assert out["bf16x3"]["mode"] == 1 and out[""]["mode"] == 0
-    assert max(v for k, v in out["bf16x3"].items() if k != "mode") <= TOL
+    # the compensated mode's tier: returns / advantages / losses / statistics inside north_star's 1e-4; gradients within 1e-3 of the
+    # largest gradient entry; an optimiser step within 10 % of the largest displacement (Adam's g / sqrt(v) amplifies the relative error
+    # of near-zero gradient entries; the exact-fp32 default sits at 1e-4 / 1e-3, tests/parity.py)
+    for k, v in out[""].items():  # the exact-fp32 default on the same case: the three bars of tests/parity.py
+        if k != "mode":
+            assert v <= (GRAD_TOL if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith("_after") else TOL), (k, v)
+    for k, v in out["bf16x3"].items():
+        if k != "mode":
+            assert v <= (BF16X3_GRAD if "grad" in k or "gnorm" in k else BF16X3_STEP if k.endswith("_after") else TOL), (k, v)
     assert out["bf16x3"]["actor_grads"] != out[""]["actor_grads"]
     print("max errors vs oracle  fp32:", {k: f"{v:.1e}" for k, v in out[""].items() if k != "mode"})
     print("max errors vs oracle bf16x3:", {k: f"{v:.1e}" for k, v in out["bf16x3"].items() if k != "mode"})
@@ -262,8 +301,8 @@ def test_bf16_single_pass_has_its_own_parity_tier():
         assert e[k] <= 2e-2, (k, e[k])
     for k in ("actor_gnorm", "critic_gnorm", "actor_grads", "critic_grads"):
         assert e[k] <= 5e-2, (k, e[k])
-    for k in ("actor_after", "critic_after"):
-        assert e[k] <= 1e-2, (k, e[k])
+    for k in ("actor_after", "critic_after"):  # relative to the step's largest displacement (tests/parity.py)
+        assert e[k] <= 1.0, (k, e[k])
     assert e["actor_grads"] > 1e-6  # it really took the single-pass kernels
 
 
@@ -685,15 +724,34 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
         assert _err(r["entropy"], z["entropies_bonuses"][e]) <= TOL
         assert _err(r["kl"], z["kl_divergences"][e]) <= TOL
         assert _err(r["clipfrac"], z["clipped_ratios"][e]) <= TOL
-        assert _err(r["actor_gnorm"], z["actor_gradients"][e]) <= TOL
-        assert _err(r["critic_gnorm"], z["critic_gradients"][e]) <= TOL
+        assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL
+        assert grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
         for g, after in r["actor_steps"]:
-            assert _err(g.cpu().numpy(), z["actor_grads"][k]) <= TOL, f"actor grad step {k}"
-            assert _err(after.cpu().numpy(), z["actor_after"][k]) <= TOL, f"actor params step {k}"
+            check_grads(g, z["actor_grads"][k], "gru golden actor grad")
+            check_step(after, z["actor_after"][k], golden_before(z, "actor", k), "gru golden actor step")
             k += 1
-        assert _err(r["critic_grads"].cpu().numpy(), z["critic_grads"][e]) <= TOL
-        assert _err(r["critic_after"].cpu().numpy(), z["critic_after"][e]) <= TOL
+        check_grads(r["critic_grads"], z["critic_grads"][e], "gru golden critic grad")
+        check_step(r["critic_after"], z["critic_after"][e], golden_before(z, "critic", e), "gru golden critic step")
     assert k == len(z["actor_grads"])
+
+
+def _check_gru_against_oracle(recs, orecs, ap, cp, label):
+    """Per-epoch scalars, per-chunk actor gradients / steps and the critic's steps of a GRU update against oracle.restatement.gru_update
+    (ap / cp: the parameters both started from)."""
+    from oracle import restatement as R
+    a0, c0 = R.flat(ap), R.flat(cp)
+    for r, o in zip(recs, orecs):
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
+            assert _err(r[k], o[k], label + " " + k) <= TOL, k
+        for k in ("actor_gnorm", "critic_gnorm"):
+            assert grad_err(r[k], o[k], label + " gnorm") <= GRAD_TOL, k
+        assert len(r["actor_steps"]) == len(o["actor_steps"])
+        for (g, after), ost in zip(r["actor_steps"], o["actor_steps"]):
+            check_grads(g, R.flat(ost["grads"]), label + " actor grad")
+            check_step(after, R.flat(ost["after"]), a0, label + " actor step")
+            a0 = R.flat(ost["after"])
+        check_step(r["critic_after"], R.flat(o["critic_after"]), c0, label + " critic step")
+        c0 = R.flat(o["critic_after"])
 
 
 @pytest.mark.parametrize("tile", ["auto", "32", "64"])
@@ -723,14 +781,7 @@ def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile,
     recs = L.train_iteration(b, keep_grads=True)
     ret, adv, orecs = R.gru_update(ap, cp, batch, hp, algo)
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL and _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
-    for r, o in zip(recs, orecs):
-        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac", "actor_gnorm", "critic_gnorm"):
-            assert _err(r[k], o[k]) <= TOL, k
-        assert len(r["actor_steps"]) == len(o["actor_steps"])
-        for (g, after), ost in zip(r["actor_steps"], o["actor_steps"]):
-            assert _err(g.cpu().numpy(), R.flat(ost["grads"]).numpy()) <= TOL
-            assert _err(after.cpu().numpy(), R.flat(ost["after"]).numpy()) <= TOL
-        assert _err(r["critic_after"].cpu().numpy(), R.flat(o["critic_after"]).numpy()) <= TOL
+    _check_gru_against_oracle(recs, orecs, ap, cp, "gru seeded")
 
 
 @pytest.mark.parametrize("E,A,T,Do,K,H,t0,t1", [(40, 5, 23, 35, 5, 64, 0, 10), (40, 5, 23, 35, 5, 64, 20, 23), (11, 4, 13, 37, 17, 64, 5, 10),
@@ -873,10 +924,49 @@ def test_full_size_env_sharding_additivity():
     scal, ag, cg = R.mlp_epoch(ap, cp, batch, sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu(), hp, "mappo")
     n = float(first[Pa + 5])
     assert n == float(mask.sum())
-    assert _err((first[:Pa] / n).cpu().numpy(), R.flat(ag).numpy()) <= TOL
-    assert _err((first[Pa + 8:Pa + 8 + Pc] / n).cpu().numpy(), R.flat(cg).numpy()) <= TOL
+    check_grads(first[:Pa] / n, R.flat(ag), "full-size shard actor grad")
+    check_grads(first[Pa + 8:Pa + 8 + Pc] / n, R.flat(cg), "full-size shard critic grad")
     assert abs(float((-first[Pa + 0] - hp["entropy_coef"] * first[Pa + 1]) / n) - scal["actor_loss"]) <= TOL * (1 + abs(scal["actor_loss"]))
     assert abs(float(first[Pa + 8 + Pc + 4] / n) - scal["critic_loss"]) <= TOL * (1 + abs(scal["critic_loss"]))
+
+
+def test_full_size_three_epochs_against_the_oracle():
+    """BASELINE configs[2] at FULL size (4096 envs x 8 agents x 128 steps, ragged episodes), the whole iteration -- value pass, scan,
+    THREE epochs with their optimiser steps -- against oracle.restatement.mlp_update on the host cores (a batched torch-CPU restatement:
+    about a minute on the GPU box): returns / advantages / per-epoch losses and statistics at 1e-4, every epoch's gradients relative to
+    their largest entry, every optimiser step as a displacement (tests/parity.py).  The other full-size tests pin ONE epoch's sums
+    through shard additivity; this one compares what three epochs leave behind."""
+    from oracle import restatement as R
+    L, b = _full_size_setup()
+    split = lambda flat, spec: [q.reshape(sh).clone() for q, sh in zip(torch.split(flat.cpu(), [int(np.prod(sh)) for sh in spec.shapes()]), spec.shapes())]
+    ap, cp = split(L.actor, L.actor_spec), split(L.critic_params(), L.critic_spec)
+    a0, c0 = R.flat(ap).clone(), R.flat(cp).clone()
+    recs = L.train_iteration(b, keep_grads=True)
+    torch.cuda.synchronize()
+    T = b.T
+    mask = torch.arange(T)[None, :] < b.ep_len.cpu()[:, None]
+    batch = dict(obs=b.obs.permute(0, 2, 1, 3).cpu(), actions=b.action.permute(0, 2, 1).long().cpu(), log_probs=b.logp.permute(0, 2, 1).cpu(),
+                 reward=b.reward.cpu(), states=b.state.cpu(), avail=b.avail.permute(0, 2, 1, 3).bool().cpu(), mask=mask)
+    hp = dict(gamma=L.hp.gamma, td_lambda=L.hp.td_lambda, epochs=L.hp.epochs, ppo_clip=L.hp.ppo_clip, entropy_coef=L.hp.entropy_coef,
+              clip_gradients=L.hp.clip_gradients, optimizer=L.hp.optimizer, learning_rate_actor=L.hp.learning_rate_actor,
+              learning_rate_critic=L.hp.learning_rate_critic, normalize_reward=False, normalize_advantage=False, normalize_return=False)
+    assert hp["epochs"] == 3
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    ret, adv, orecs = R.mlp_update(ap, cp, batch, hp, "mappo")
+    m3 = mask[:, :, None].numpy()
+    assert _err(b.ret.permute(0, 2, 1).cpu().numpy() * m3, ret.numpy() * m3, "full-size returns") <= TOL
+    assert _err(b.adv.permute(0, 2, 1).cpu().numpy() * m3, adv.numpy() * m3, "full-size advantages") <= TOL
+    assert len(recs) == 3
+    for e, (r, o) in enumerate(zip(recs, orecs)):
+        for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
+            assert _err(r[k], o[k], "full-size " + k) <= TOL, (e, k)
+        for k in ("actor_gnorm", "critic_gnorm"):
+            assert grad_err(r[k], o[k], "full-size gnorm") <= GRAD_TOL, (e, k)
+        check_grads(r["actor_grads"], R.flat(o["actor_grads"]), "full-size 3-epoch actor grad")
+        check_grads(r["critic_grads"], R.flat(o["critic_grads"]), "full-size 3-epoch critic grad")
+        check_step(r["actor_after"], R.flat(o["actor_after"]), a0, "full-size 3-epoch actor step")
+        check_step(r["critic_after"], R.flat(o["critic_after"]), c0, "full-size 3-epoch critic step")
+        a0, c0 = R.flat(o["actor_after"]), R.flat(o["critic_after"])
 
 
 def test_full_size_scan_linearity_and_padding_invariance():
@@ -994,8 +1084,8 @@ def test_full_size_other_configs_shard_additivity_and_oracle_shard(name):
     scal, ag, cg = R.mlp_epoch(ap, cp, batch, sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu(), hp, algo)
     n = float(first[Pa + 5])
     assert n == float(mask.sum())
-    assert _err((first[:Pa] / n).cpu().numpy(), R.flat(ag).numpy()) <= TOL
-    assert _err((first[Pa + 8:Pa + 8 + Pc] / n).cpu().numpy(), R.flat(cg).numpy()) <= TOL
+    check_grads(first[:Pa] / n, R.flat(ag), "full-size shard actor grad")
+    check_grads(first[Pa + 8:Pa + 8 + Pc] / n, R.flat(cg), "full-size shard critic grad")
     assert abs(float((-first[Pa + 0] - hp["entropy_coef"] * first[Pa + 1]) / n) - scal["actor_loss"]) <= TOL * (1 + abs(scal["actor_loss"]))
     assert abs(float(first[Pa + 8 + Pc + 4] / n) - scal["critic_loss"]) <= TOL * (1 + abs(scal["critic_loss"]))
 
@@ -1285,8 +1375,10 @@ def test_hand_ordered_and_compiler_scheduled_product_forms_agree_bit_for_bit(alg
         assert torch.equal(out["hand"][1][e]["actor_grads"], out["loop"][1][e]["actor_grads"])
     ret, adv, orec = R.mlp_update(ap, cp, batch, hpd, algo)
     assert _err(out["hand"][0].permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL
+    a0 = R.flat(ap)
     for e in range(2):
-        assert _err(out["hand"][1][e]["actor_after"].cpu().numpy(), R.flat(orec[e]["actor_after"]).numpy()) <= TOL
+        check_step(out["hand"][1][e]["actor_after"], R.flat(orec[e]["actor_after"]), a0, "hand forms actor step")
+        a0 = R.flat(orec[e]["actor_after"])
 
 
 def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeypatch):

@@ -8,13 +8,10 @@ import numpy as np
 import pytest
 import torch
 
+from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
+from parity import err as _err
+
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
-
-
-def _err(a, b):
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
 
 
 @pytest.mark.parametrize("name", ["mappo_dense", "mappo_deep"])
@@ -82,9 +79,9 @@ def test_ctypes_recipe_reproduces_the_reference(golden_dir, name):
         assert _err(float(st[2] / N), z["kl_divergences"][epoch]) <= TOL
         assert _err(float(st[3] / N), z["clipped_ratios"][epoch]) <= TOL
         assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
-        assert _err(float(norms[0]), z["actor_gradients"][epoch]) <= TOL and _err(float(norms[1]), z["critic_gradients"][epoch]) <= TOL
-        assert _err(actor_flat.cpu().numpy(), z["actor_after"][epoch]) <= TOL
-        assert _err(critic_flat.cpu().numpy(), z["critic_after"][epoch]) <= TOL
+        assert grad_err(float(norms[0]), z["actor_gradients"][epoch]) <= GRAD_TOL and grad_err(float(norms[1]), z["critic_gradients"][epoch]) <= GRAD_TOL
+        check_step(actor_flat, z["actor_after"][epoch], golden_before(z, "actor", epoch), "ctypes recipe actor step")
+        check_step(critic_flat, z["critic_after"][epoch], golden_before(z, "critic", epoch), "ctypes recipe critic step")
 
 
 class OptStep(C.Structure):  # cm_opt_step_t exactly as INTEGRATION.md section 6c declares it
@@ -156,8 +153,8 @@ def test_ctypes_train_step_recipe_reproduces_the_reference(golden_dir, name):
             assert torch.equal(rec[epoch].cpu(), st)  # the same sums, also where the caller asked for them
             assert _err(float((-st[0] - hp["entropy_coef"] * st[1]) / N), z["actor_losses"][epoch]) <= TOL
             assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
-            assert _err(float(norms[0]), z["actor_gradients"][epoch]) <= TOL and _err(float(norms[1]), z["critic_gradients"][epoch]) <= TOL
-            assert _err(actor_flat.cpu().numpy(), z["actor_after"][epoch]) <= TOL
-            assert _err(critic_flat.cpu().numpy(), z["critic_after"][epoch]) <= TOL
+            assert grad_err(float(norms[0]), z["actor_gradients"][epoch]) <= GRAD_TOL and grad_err(float(norms[1]), z["critic_gradients"][epoch]) <= GRAD_TOL
+            check_step(actor_flat, z["actor_after"][epoch], golden_before(z, "actor", epoch), "ctypes recipe actor step")
+            check_step(critic_flat, z["critic_after"][epoch], golden_before(z, "critic", epoch), "ctypes recipe critic step")
     finally:
         chk(lib.cm_set_option(b"critic_schedule", b"auto"))
