@@ -41,6 +41,7 @@ SIGNATURES = {
     "cm_set_option": (_i, [C.c_char_p, C.c_char_p]),
     "cm_get_option": (C.c_char_p, [C.c_char_p]),
     "cm_mlp_forward_ld": (_i, [_p, _l, _l, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "cm_mlp_forward_solo_ld": (_i, [_p, _l, _l, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "cm_w0_image_bytes": (_sz, [_i, _i]),
     "cm_policy_act_episode_ld": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p, _sz, _p]),
     "cm_ppo_actor_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),

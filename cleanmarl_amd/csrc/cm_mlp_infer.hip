@@ -8,7 +8,8 @@ extern unsigned long long* g_prof;
 #endif
 
 static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
-                          const float* params, const uint8_t* avail, float* y, cm_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0) {
+                          const float* params, const uint8_t* avail, float* y, cm_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0,
+                          bool solo = false) {
     if (int rc = check_shapes("cm_mlp_forward", din, hidden, n_hidden_layers, dout)) return rc;
     CM_REQUIRE(x_ld >= din, "cm_mlp_forward: leading dimension %lld < din %d", (long long)x_ld, din);
     if (rows <= 0) return 0;
@@ -17,7 +18,10 @@ static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, i
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
     prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);  // no workspace: W0 chunks on 4-byte loads where unaligned
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
-    set_tile_split(a, grid_for(rows), 0, true);  // forward kernels run two workgroups per CU as well: same two-group finish (cm_mlp_kernel.h)
+    // forward kernels run two workgroups per CU as well (same two-group finish, cm_mlp_kernel.h): the unequal split pays for a launch that
+    // has the GPU to itself and costs 15 - 25 % beside another stream's kernels -- only the caller knows which (cm_mlp_forward_solo_ld:
+    // the learner's value pass, ordered behind the critic stream); the generic entry points split by size like every other launch
+    set_tile_split(a, grid_for(rows), 0, solo);
     launch_infer<M_FWD>(a, grid_for(rows), lds_bytes, (hipStream_t)stream);
     CM_CHECK_LAUNCH("cm_mlp_forward");
     return 0;
@@ -45,6 +49,14 @@ extern "C" int cm_mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int
     a.x = x; a.x_stride = x_ld; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
     return wide_forward(a, ws, ws_bytes, (hipStream_t)stream, "cm_mlp_forward_ws");
+}
+/* cm_mlp_forward_ld for a launch the caller has ordered behind everything else on the device (the value pass of
+ * cleanmarl/mappo_multienvs.py:492-504 at the head of the update, after the join with the critic stream): same results, the full grid may
+ * take the unequal static tile split (set_tile_split) whatever its row count. */
+extern "C" int cm_mlp_forward_solo_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                                      const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    if (wide_shape(hidden, n_hidden_layers, dout)) return cm_mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, ws, ws_bytes, stream);
+    return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream, ws, ws_bytes, true);
 }
 extern "C" int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                                  const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {

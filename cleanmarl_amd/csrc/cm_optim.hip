@@ -52,7 +52,20 @@ __global__ __launch_bounds__(STEP_COLS * STEP_WAVES) void k_reduce_step(const St
             }
         }
         peer_lost = __syncthreads_or(lost ? 1 : 0) != 0;
-        if (peer_lost && threadIdx.x == 0 && a.peer_status)
+        // ONE verdict per launch, workgroup 0's: it travels in the N word that every other workgroup waits for anyway.  A
+        // workgroup whose OWN wait ran out while workgroup 0's did not (the last tag arrived between the two deadlines) must not skip its
+        // slab while the others update theirs: it waits for that word first -- a valid N means workgroup 0 saw every tag, so the slots are
+        // published and this workgroup folds them after all; a NaN N means the whole launch skips.  Only workgroup 0 raises the status word.
+        if (peer_lost && blockIdx.x != 0) {
+            float N0 = 0.f;
+            if (threadIdx.x == 0) N0 = step_wait(a.nword, a.tag);
+            sh[0][0] = N0;  // (sh is rewritten by the fold below, behind the barrier that follows)
+            __syncthreads();
+            N0 = sh[0][0];
+            __syncthreads();
+            peer_lost = !(N0 == N0);
+        }
+        if (peer_lost && blockIdx.x == 0 && threadIdx.x == 0 && a.peer_status)
             __hip_atomic_store(a.peer_status, a.peer_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // acquire at system scope, pairing with the pusher's release store of the tag (cm_peer.hip): the slot loads below are relaxed
         // system-scope loads and must not be satisfied from anything older than the tag that certified them.  One fence per
@@ -155,9 +168,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_grad_norm_small(const float* __
 __global__ __launch_bounds__(UPD_THREADS) void k_clip_adam_update(
     float* __restrict__ params, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
     float lr, float beta1, float beta2, float eps, float weight_decay, int opt_kind, float max_norm,
-    float grad_scale, float bc1, float bc2_sqrt, const float* __restrict__ norm_in, int skip_on_nan_norm) {
-    // the peer step (cm_peer.hip) marks a step whose wait for the peers ran out with a NaN norm: nothing may be applied then
-    if (skip_on_nan_norm && !(norm_in[0] == norm_in[0])) return;
+    float grad_scale, float bc1, float bc2_sqrt, const float* __restrict__ norm_in, const unsigned long long* __restrict__ skipword, unsigned tag) {
+    // the peer step (cm_peer.hip) whose wait for the peers ran out: workgroup 0 of the fold launch in front of this one left {tag, 1} in the
+    // scratch's skip word -- nothing may be applied then.  A dedicated word, not "the norm is NaN" (ADVICE r5): a norm that is NaN for real
+    // (Inf / NaN gradients, every tag arrived) is NOT a skipped step -- it is applied and poisons the parameters loudly, as on the RCCL path
+    if (skipword) { const unsigned long long w = skipword[0]; if ((unsigned)(w >> 32) == tag && (unsigned)w != 0u) return; }
     const float N = g[n + CM_STAT_COUNT];
     const float scale = (N > 0.0f) ? grad_scale / N : 0.0f;
     float coef = 1.0f;
@@ -231,7 +246,7 @@ int cm_launch_reduce_step(const float* part1, int np1, int PS1, const float* par
         else hipLaunchKernelGGL(k_reduce_step<false>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         const int ugrid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(ugrid), dim3(UPD_THREADS), 0, s, o->params, grad_and_stats, o->exp_avg, o->exp_avg_sq,
-                           (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm, peer_tags ? 1 : 0);
+                           (int)n_params, a.lr, a.beta1, a.beta2, a.eps, a.wd, a.kind, (float)o->max_norm, a.grad_scale, a.bc1, a.bc2_sqrt, o->out_norm, peer_tags ? a.nword + 1 : nullptr, a.tag);
     } else {
         if (peer_tags) hipLaunchKernelGGL((k_reduce_step<true, true>), dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
         else hipLaunchKernelGGL(k_reduce_step<true>, dim3(grid), dim3(STEP_COLS * STEP_WAVES), 0, s, a);
@@ -259,7 +274,7 @@ extern "C" int cm_grad_norm_clip_adam(float* params, float* grad_and_stats, floa
         const int grid = (int)((n_params + UPD_THREADS * UPD_PT - 1) / (UPD_THREADS * UPD_PT));
         hipLaunchKernelGGL(k_clip_adam_update, dim3(grid), dim3(UPD_THREADS), 0, (hipStream_t)stream, params, grad_and_stats,
                            exp_avg, exp_avg_sq, (int)n_params, (float)lr, (float)beta1, (float)beta2, (float)eps,
-                           (float)weight_decay, opt_kind, (float)max_norm, (float)grad_scale, (float)bc1, (float)sqrt(bc2), out_norm, 0);
+                           (float)weight_decay, opt_kind, (float)max_norm, (float)grad_scale, (float)bc1, (float)sqrt(bc2), out_norm, nullptr, 0u);
     }
     else
         hipLaunchKernelGGL(k_grad_norm_clip_adam, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grad_and_stats,

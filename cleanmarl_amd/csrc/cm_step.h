@@ -150,7 +150,11 @@ __device__ __forceinline__ void step_norm(const StepArgs& a, int nb, bool skip) 
     float tot = 0.f;
     for (int j = c; j < nb; j += STEP_COLS) tot += step_wait(a.slots + j, a.tag);
     tot = cm_wave_sum(tot);
-    if (c == 0) a.out_norm[0] = skip ? __builtin_nanf("") : sqrtf(tot);  // the logged norm of a skipped step is NaN (the status word is the error channel)
+    if (c == 0) {
+        a.out_norm[0] = skip ? __builtin_nanf("") : sqrtf(tot);  // the logged norm of a skipped step is NaN (the status word is the error channel)
+        // the launch's verdict for the clipping update that follows it (k_clip_adam_update): {tag, 1} = skipped, {tag, 0} = apply
+        __hip_atomic_store(a.nword + 1, ((unsigned long long)a.tag << 32) | (skip ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // collect: workgroup 0 finishes the norm right behind its slab (one slab per workgroup); false: the caller does it after its last slab

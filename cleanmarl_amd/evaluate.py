@@ -139,9 +139,12 @@ class HostEvaluator:
 
     Host cost: a rank keeps one in-process env per episode slot it owns (the reference reuses ONE eval env sequentially,
     cleanmarl/mappo_multienvs.py:614-650).  The envs are created on first use, and ``--eval_live_envs=N`` (N > 0) bounds how many are alive
-    at once: the slots are then played in waves of N and a wave's envs are closed before the next wave is built -- N = 1 is the reference's
-    sequential evaluation for heavy envs (smaclite).  The action keys do not depend on the wave size (row = global slot x agent), so every
-    setting plays the same episodes on the counter-keyed envs."""
+    at once: the slots are then played in waves of N.  Heavy envs whose episodes are NOT keyed by (index, episode) counters (smaclite,
+    pettingzoo) are POOLED: at most N envs are ever built, wave position i of every wave and every round reuses pool env i and only
+    resets it -- N = 1 is exactly the reference's sequential evaluation on one env whose RNG advances (no construction per episode, no
+    re-seeding per round).  The counter-keyed CPU twins of the synthetic envs ARE their index (an episode is a function of
+    (seed, index, episode)): they are cheap to build, so a wave's envs are closed before the next wave is built.  The action keys do not
+    depend on the wave size (row = global slot x agent), so every setting plays the same episodes on the counter-keyed envs."""
 
     def __init__(self, make_env, first_env, host_actor, args, n_agents, recurrent, device, batch_size, rank=0, world=1, pg=None):
         """make_env(index) -> CommonInterface env; first_env: the script's eval_env (index eval_base), reused as episode slot 0."""
@@ -154,10 +157,17 @@ class HostEvaluator:
         self.make_env, self.first_env = make_env, first_env
         self.max_live = max(0, int(getattr(args, "eval_live_envs", 0) or 0))
         self.envs = {}  # slot -> env, created on first use (_env)
+        self.pool = {}  # wave position -> env of the pooled (not counter-keyed) envs when --eval_live_envs bounds them; position 0 = first_env
+        self.pooled = self.max_live > 0 and not hasattr(first_env, "episode")
         self.smaclite = args.env_type == "smaclite"
         self.record, self.actions = False, None  # tests: the actions of the last round, [wave * t][slot of the wave][agent]
 
-    def _env(self, j):
+    def _env(self, j, pos=0):
+        """The env that plays slot j; pos = its position in the wave (pooled envs are owned by the position, not by the slot)."""
+        if self.pooled:
+            if pos not in self.pool:
+                self.pool[pos] = self.first_env if pos == 0 else self.make_env(self.base + pos)
+            return self.pool[pos]
         if j not in self.envs:
             self.envs[j] = self.first_env if j == 0 else self.make_env(self.base + j)
         return self.envs[j]
@@ -170,13 +180,17 @@ class HostEvaluator:
 
     def close(self):
         self._release(list(self.envs))
+        for pos, e in list(self.pool.items()):
+            if pos != 0:  # position 0 is the caller's eval_env
+                e.close()
+        self.pool.clear()
 
     def _play(self, slots, round_index, greedy, eps, seed):
         """One wave: the episodes of `slots` (contiguous) side by side.  The act call always carries ALL of the wave's slots (finished
         episodes ride along with their last observation, their actions are dropped): row (base + j) * A + a of step t is keyed the same
         whatever the other episodes do, however the slots are dealt over ranks and waves -- exactly like the device evaluator's rollout."""
         A = self.A
-        envs = {j: self._env(j) for j in slots}
+        envs = {j: self._env(j, i) for i, j in enumerate(slots)}
         for j in slots:
             if hasattr(envs[j], "episode"):  # the counter-keyed CPU twins: round n IS episode n of env base + j (resume-safe)
                 envs[j].episode = int(round_index) - 1
@@ -216,8 +230,8 @@ class HostEvaluator:
             wave = slots[w0:w0 + step]
             rw, lw, ww = self._play(wave, round_index, greedy, eps, seed)
             r += rw; l += lw; won += ww
-            if self.max_live > 0 and len(slots) > self.max_live:
-                self._release(wave)  # the next wave's envs take their place
+            if self.max_live > 0 and len(slots) > self.max_live and not self.pooled:
+                self._release(wave)  # the next wave's envs take their place (pooled envs stay: they are reset, not rebuilt)
         if self.world > 1:  # every rank played its block: gather (slot order, as if one process had played them all)
             loc = torch.full((3, self.per), float("nan"), dtype=torch.float64, device=self.device)
             if slots:

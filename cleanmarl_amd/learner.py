@@ -352,8 +352,9 @@ class PPOLearner:
         self._ensure_ws(b)
         self.wait_critic()  # the critic epochs of the previous update ran on their own stream (under this batch's rollout)
         x_ld = b.state_ld if self.algo == "mappo" else b.obs_ld
-        N.check(lib.cm_mlp_forward_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
-                                      N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_ld")
+        # "solo": this launch is ordered behind the critic stream (wait_critic above) and in front of the update -- it has the GPU to itself
+        N.check(lib.cm_mlp_forward_solo_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
+                                           N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_solo_ld")
         N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
                                       hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
         if hp.normalize_advantage:

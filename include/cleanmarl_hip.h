@@ -371,6 +371,12 @@ int cm_mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int h
  * image with an aligned leading dimension there (the training passes keep theirs in their workspace).  NULL / too small: W0 chunks
  * stay on 4-byte loads -- slower, same results. */
 size_t cm_w0_image_bytes(int din, int hidden);
+/* cm_mlp_forward_ld for a launch the CALLER has ordered behind everything else on the device -- the value pass V(s_t) of
+ * cleanmarl/mappo_multienvs.py:492-504 at the head of an update, after the join with the critic's stream.  Same arguments, same results;
+ * the hint lets a full persistent grid take the unequal static tile split whatever its row count (beside another stream's kernels that
+ * split costs 15 - 25 %, which is why the generic entry point only splits launches of >= 2^21 rows). */
+int cm_mlp_forward_solo_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
+                           const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream);
 int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint8_t* avail, int64_t n_seq, int T, int din, int hidden,
                              int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
                              int32_t* action, float* logp, void* ws, size_t ws_bytes, cm_stream_t stream);

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
+from parity import DISP_TOL, GRAD_TOL, TOL, StepChecker, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
 from parity import err as _err
 
 pytestmark = pytest.mark.gpu
@@ -49,10 +49,11 @@ def test_coma_update_matches_reference_golden(golden_dir, name):
     assert _err(rec["entropy"], float(z["entropies"])) <= TOL
     assert grad_err(rec["critic_gnorm"], float(z["critic_gradients"])) <= GRAD_TOL
     assert grad_err(rec["actor_gnorm"], float(z["actor_gradients"])) <= GRAD_TOL
-    check_grads(rec["critic_grads"], z["critic_grads"][0], "coma golden critic grad")
-    check_grads(rec["actor_grads"], z["actor_grads"][0], "coma golden actor grad")
-    check_step(L.critic, z["critic_after"][0], golden_before(z, "critic", 0), "coma golden critic step")
-    check_step(L.actor, z["actor_after"][0], golden_before(z, "actor", 0), "coma golden actor step")
+    kind = str(z["hp_optimizer"])
+    StepChecker(golden_init(z, "critic"), kind, float(z["hp_learning_rate_critic"]), "coma golden critic").step(
+        rec["critic_grads"], L.critic, z["critic_grads"][0], z["critic_after"][0])
+    StepChecker(golden_init(z, "actor"), kind, float(z["hp_learning_rate_actor"]), "coma golden actor").step(
+        rec["actor_grads"], L.actor, z["actor_grads"][0], z["actor_after"][0])
     assert _err(L.target.cpu().numpy(), z["target_after"]) <= 1e-6
 
 
@@ -98,9 +99,9 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
     L, b = _learner(batch, ap, cp, hp, dev, target=tp)
     oa, oc = R.AdamState(ap, 5e-4, "Adam"), R.AdamState(cp, 5e-4, "Adam")
     ts = 0
+    chk_c, chk_a = StepChecker(R.flat(cp), "Adam", 5e-4, "coma oracle critic"), StepChecker(R.flat(ap), "Adam", 5e-4, "coma oracle actor")
     for it in range(2):
         rec = L.train_iteration(b, keep_grads=True)
-        cp0, ap0 = R.flat(cp).clone(), R.flat(ap).clone()
         ref = C.update(ap, cp, tp, batch, hp, oa, oc, ts)
         ts = ref["training_step"]
         assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ref["ret"].numpy()) <= TOL, it
@@ -109,10 +110,8 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
         assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, it
         assert _err(rec["entropy"], ref["entropy"]) <= TOL, it
         assert grad_err(rec["critic_gnorm"], ref["critic_gnorm"]) <= GRAD_TOL and grad_err(rec["actor_gnorm"], ref["actor_gnorm"]) <= GRAD_TOL, it
-        check_grads(rec["critic_grads"], ref["critic_grads"], "coma oracle critic grad")
-        check_grads(rec["actor_grads"], ref["actor_grads"], "coma oracle actor grad")
-        check_step(L.critic, R.flat(cp), cp0, "coma oracle critic step")
-        check_step(L.actor, R.flat(ap), ap0, "coma oracle actor step")
+        chk_c.step(rec["critic_grads"], L.critic, ref["critic_grads"], R.flat(cp))
+        chk_a.step(rec["actor_grads"], L.actor, ref["actor_grads"], R.flat(ap))
         assert _err(L.target.cpu().numpy(), R.flat(tp).numpy()) <= TOL, it
 
 
@@ -150,9 +149,9 @@ def test_coma_on_padded_rollout_buffers_matches_oracle_and_the_contiguous_run(E,
             assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, (pad, it)
             check_grads(rec["critic_grads"], ref["critic_grads"], "coma padded critic grad")
             check_grads(rec["actor_grads"], ref["actor_grads"], "coma padded actor grad")
-    for pad in (False, True):  # two iterations' accumulated error against the LAST step's displacement
-        check_step(runs[pad][1], R.flat(cp), cp0, "coma padded critic step")
-        check_step(runs[pad][2], R.flat(ap), ap0, "coma padded actor step")
+    for pad in (False, True):  # two iterations' accumulated error against the LAST step's displacement, well-conditioned entries
+        check_step(runs[pad][1], R.flat(cp), cp0, "coma padded critic step", ref_grad=ref["critic_grads"])
+        check_step(runs[pad][2], R.flat(ap), ap0, "coma padded actor step", ref_grad=ref["actor_grads"])
         assert _err(runs[pad][3].cpu().numpy(), R.flat(tp).numpy()) <= TOL
     for x, y in zip(runs[False][1:], runs[True][1:]):
         assert _err(x.cpu().numpy(), y.cpu().numpy()) <= 2e-6

@@ -204,3 +204,48 @@ def test_host_evaluator_waves_bound_the_live_envs_and_play_the_same_episodes():
     he.run(0)
     assert live_max[0] <= 2 and len(made) == 6 and len(closed) == 6  # slots 1..6 built and closed again; slot 0 is the caller's env
     he.close()
+
+
+class _StatefulEnv:
+    """A heavy-env stand-in WITHOUT counter-keyed episodes (no `episode` attribute): its RNG advances from episode to episode, like the
+    reference's single eval env (cleanmarl/mappo_multienvs.py:614-650)."""
+
+    def __init__(self, index, log):
+        self.rng, self.t, self.log, self.index = np.random.default_rng(index), 0, log, index
+        log.append(("make", index))
+
+    def reset(self, seed=None):
+        self.t, self.h = 0, int(self.rng.integers(3, 7))
+        self.log.append(("reset", self.index))
+        return np.zeros((3, 4), np.float32), {}
+
+    def get_avail_actions(self):
+        return np.ones((3, 5), np.int64)
+
+    def step(self, actions):
+        self.t += 1
+        return np.zeros((3, 4), np.float32), float(self.rng.random()), False, self.t >= self.h, {}
+
+    def close(self):
+        self.log.append(("close", self.index))
+
+
+def test_host_evaluator_pools_heavy_envs_across_waves_and_rounds():
+    """--eval_live_envs=N with envs that are not counter-keyed: at most N envs are EVER built (wave position i reuses pool env i, reset per
+    episode), nothing is rebuilt between waves or rounds, and the envs' RNG streams advance across rounds -- with N = 1 that is the
+    reference's sequential evaluation on one env (the per-wave close / rebuild paid env construction per episode per round and
+    restarted every slot from the same freshly seeded state)."""
+    from cleanmarl_amd.evaluate import HostEvaluator, eval_base
+    for live, n_ep in ((1, 4), (2, 5)):
+        args = parse_args("mappo_multienvs", ["--env_type=synthetic_cpu", "--batch_size=8", f"--num_eval_ep={n_ep}", "--seed=5", f"--eval_live_envs={live}"])
+        log = []
+        first = _StatefulEnv(eval_base(8), log)
+        he = HostEvaluator(lambda index: _StatefulEnv(index, log), first, _FakeActor(), args, 3, False, torch.device("cpu"), 8)
+        r0 = he.run(0)
+        r1 = he.run(1)
+        made = [i for k, i in log if k == "make"]
+        assert len(made) == live and not [1 for k, _ in log if k == "close"]  # the caller's env + (live - 1) pool envs, nothing closed or rebuilt
+        assert sum(1 for k, _ in log if k == "reset") == 2 * n_ep  # one reset per episode
+        assert r0.ep_rewards != r1.ep_rewards  # the RNG streams advanced: round 1 is not a replay of round 0
+        he.close()
+        assert sorted(i for k, i in log if k == "close") == sorted(made[1:])  # the pool is closed once, the caller's env is left alone

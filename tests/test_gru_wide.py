@@ -43,9 +43,10 @@ def test_layered_gru_update_matches_oracle(algo, E, A, T, Do, Ds, K, H, tb, fuse
     L = GRUPPOLearner(algo, aspec, cspec, A, HParams(**hp), dev, actor_params=[p.clone() for p in ap], critic_params=[p.clone() for p in cp])
     L.fused_step = fused_step
     recs = L.train_iteration(b, keep_grads=True)
+    a0, c0 = R.flat(ap).clone(), R.flat(cp).clone()  # (gru_update steps the lists in place)
     ret, adv, orecs = R.gru_update(ap, cp, batch, hp, algo)
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL and _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
-    _check_gru_against_oracle(recs, orecs, ap, cp, "gru layered")
+    _check_gru_against_oracle(recs, orecs, a0, c0, hp, "gru layered")
 
 
 @pytest.mark.parametrize("rows,Do,Hd,K", [(150, 115, 64, 17), (70, 35, 128, 5), (33, 70, 96, 6), (90, 35, 64, 36), (150, 35, 64, 5)])

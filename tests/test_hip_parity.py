@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, disp_err, golden_before, golden_init, grad_err  # noqa: F401
+from parity import DISP_TOL, GRAD_TOL, TOL, StepChecker, check_grads, check_step, disp_err, golden_before, golden_init, grad_err, twin_err  # noqa: F401
+from parity import OptimizerTwin
 from parity import err as _err
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +47,9 @@ def _check_update_against_golden(b, recs, z, label):
     adv = b.adv.permute(0, 2, 1).cpu().numpy()
     assert _err(ret, z["return_lambda"], "returns") <= TOL
     assert _err(adv, z["advantages"], "advantages") <= TOL
+    kind = str(z["hp_optimizer"])  # the REFERENCE run's optimiser and learning rates: what the HIP steps are held to
+    ca = StepChecker(golden_init(z, "actor"), kind, float(z["hp_learning_rate_actor"]), label + " actor")
+    cc = StepChecker(golden_init(z, "critic"), kind, float(z["hp_learning_rate_critic"]), label + " critic")
     for e, r in enumerate(recs):
         assert _err(r["actor_loss"], z["actor_losses"][e], "losses") <= TOL
         assert _err(r["critic_loss"], z["critic_losses"][e], "losses") <= TOL
@@ -54,10 +58,8 @@ def _check_update_against_golden(b, recs, z, label):
         assert _err(r["clipfrac"], z["clipped_ratios"][e], "statistics") <= TOL
         assert grad_err(r["actor_gnorm"], z["actor_gradients"][e], "gnorm") <= GRAD_TOL
         assert grad_err(r["critic_gnorm"], z["critic_gradients"][e], "gnorm") <= GRAD_TOL
-        check_grads(r["actor_grads"], z["actor_grads"][e], label + " actor grad")
-        check_grads(r["critic_grads"], z["critic_grads"][e], label + " critic grad")
-        check_step(r["actor_after"], z["actor_after"][e], golden_before(z, "actor", e), label + " actor step")
-        check_step(r["critic_after"], z["critic_after"][e], golden_before(z, "critic", e), label + " critic step")
+        ca.step(r["actor_grads"], r["actor_after"], z["actor_grads"][e], z["actor_after"][e])
+        cc.step(r["critic_grads"], r["critic_after"], z["critic_grads"][e], z["critic_after"][e])
 
 
 @pytest.mark.parametrize("name,algo", MLP_CASES)
@@ -67,10 +69,10 @@ def test_update_matches_reference_golden(golden_dir, name, algo):
     _check_update_against_golden(b, recs, z, "mlp golden")
 
 
-@pytest.mark.parametrize("what,factor", [("learning_rate_actor", 1.05), ("learning_rate_critic", 0.95), ("ppo_clip", 0.5), ("td_lambda", 0.99)])
+@pytest.mark.parametrize("what,factor", [("learning_rate_actor", 1.05), ("learning_rate_critic", 0.95), ("entropy_coef", 10.0), ("td_lambda", 0.99), ("gamma", 0.99)])
 def test_a_wrong_learner_fails_the_golden_comparison(golden_dir, what, factor):
-    """The bars can fail: a learner whose optimiser step is 5 % too long (or short), whose clip range is halved or whose lambda is off by
-    1 % does NOT pass the comparison that test_update_matches_reference_golden applies (under the old absolute 1e-4 on the parameters a
+    """The bars can fail: a learner whose optimiser step is 5 % too long (or short), whose entropy bonus is ten times too large or whose
+    lambda / gamma is off by 1 % does NOT pass the comparison that test_update_matches_reference_golden applies (under the old absolute 1e-4 on the parameters a
     12 %-wrong Adam step passed: max|after - before| is 8e-4 in this golden)."""
     L, b, z, batch = _learner_from_golden(os.path.join(golden_dir, "mappo_dense.npz"), "mappo")
     setattr(L.hp, what, getattr(L.hp, what) * factor)
@@ -218,11 +220,13 @@ def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
     Lr = PPOLearner(algo, aspec, cspec, A, HParams(**hp), dev, actor_params=[p.clone() for p in ap],
                     critic_params=[p.clone() for p in cp])
     recs = Lr.train_iteration(b, keep_grads=True)
+    before = {"actor": R.flat(ap).clone(), "critic": R.flat(cp).clone()}  # (mlp_update steps the lists in place)
     ret, adv, orecs = R.mlp_update(ap, cp, batch, hp, algo)
     errs = {"ret": _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()), "adv": _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy())}
-    before = {"actor": R.flat(ap), "critic": R.flat(cp)}
     scale = tol / TOL  # callers with a looser tier (bf16) loosen every bar by the same factor
     bars = {}
+    twins = {"actor": OptimizerTwin(before["actor"], hp["optimizer"], hp["learning_rate_actor"]),
+             "critic": OptimizerTwin(before["critic"], hp["optimizer"], hp["learning_rate_critic"])}
     for r, o in zip(recs, orecs):
         for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
             errs[k] = max(errs.get(k, 0.0), _err(r[k], o[k], "seeded " + k))
@@ -233,8 +237,11 @@ def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
             k = net + "_grads"
             errs[k] = max(errs.get(k, 0.0), grad_err(r[k], R.flat(o[k]), "seeded " + k))
             bars[k] = GRAD_TOL * scale
-            k = net + "_after"
-            errs[k] = max(errs.get(k, 0.0), disp_err(r[k], R.flat(o[k]), before[net], "seeded " + k))
+            k = net + "_twin"  # the HIP step against torch.optim's on the gradient it consumed: every entry, whatever the arithmetic of the passes
+            errs[k] = max(errs.get(k, 0.0), twin_err(twins[net], r[net + "_grads"], r[net + "_after"], "seeded " + k))
+            bars[k] = DISP_TOL
+            k = net + "_after"  # ... and against the oracle's parameters on the well-conditioned entries
+            errs[k] = max(errs.get(k, 0.0), disp_err(r[k], R.flat(o[k]), before[net], "seeded " + k, ref_grad=R.flat(o[net + "_grads"])))
             bars[k] = DISP_TOL * scale
             before[net] = R.flat(o[k])
     for k, v in errs.items():
@@ -269,10 +276,10 @@ def test_bf16x3_opt_in_keeps_the_parity_bar():
     # of near-zero gradient entries; the exact-fp32 default sits at 1e-4 / 1e-3, tests/parity.py)
     for k, v in out[""].items():  # the exact-fp32 default on the same case: the three bars of tests/parity.py
         if k != "mode":
-            assert v <= (GRAD_TOL if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith("_after") else TOL), (k, v)
+            assert v <= (GRAD_TOL if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith(("_after", "_twin")) else TOL), (k, v)
     for k, v in out["bf16x3"].items():
-        if k != "mode":
-            assert v <= (BF16X3_GRAD if "grad" in k or "gnorm" in k else BF16X3_STEP if k.endswith("_after") else TOL), (k, v)
+        if k != "mode":  # (the optimiser step itself is the same fp32 kernel in every mode: the twin bar does not loosen)
+            assert v <= (BF16X3_GRAD if "grad" in k or "gnorm" in k else BF16X3_STEP if k.endswith("_after") else DISP_TOL if k.endswith("_twin") else TOL), (k, v)
     assert out["bf16x3"]["actor_grads"] != out[""]["actor_grads"]
     print("max errors vs oracle  fp32:", {k: f"{v:.1e}" for k, v in out[""].items() if k != "mode"})
     print("max errors vs oracle bf16x3:", {k: f"{v:.1e}" for k, v in out["bf16x3"].items() if k != "mode"})
@@ -301,8 +308,10 @@ def test_bf16_single_pass_has_its_own_parity_tier():
         assert e[k] <= 2e-2, (k, e[k])
     for k in ("actor_gnorm", "critic_gnorm", "actor_grads", "critic_grads"):
         assert e[k] <= 5e-2, (k, e[k])
-    for k in ("actor_after", "critic_after"):  # relative to the step's largest displacement (tests/parity.py)
+    for k in ("actor_after", "critic_after"):  # relative to the step's largest displacement, well-conditioned entries (tests/parity.py)
         assert e[k] <= 1.0, (k, e[k])
+    for k in ("actor_twin", "critic_twin"):    # the optimiser step is the fp32 kernel of every mode
+        assert e[k] <= DISP_TOL, (k, e[k])
     assert e["actor_grads"] > 1e-6  # it really took the single-pass kernels
 
 
@@ -718,6 +727,9 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), z["return_lambda"]) <= TOL
     assert _err(b.adv.permute(0, 2, 1).cpu().numpy(), z["advantages"]) <= TOL
     k = 0
+    kind = str(z["hp_optimizer"])
+    ca = StepChecker(golden_init(z, "actor"), kind, float(z["hp_learning_rate_actor"]), "gru golden actor")
+    cc = StepChecker(golden_init(z, "critic"), kind, float(z["hp_learning_rate_critic"]), "gru golden critic")
     for e, r in enumerate(recs):
         assert _err(r["actor_loss"], z["actor_losses"][e]) <= TOL
         assert _err(r["critic_loss"], z["critic_losses"][e]) <= TOL
@@ -727,19 +739,18 @@ def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile,
         assert grad_err(r["actor_gnorm"], z["actor_gradients"][e]) <= GRAD_TOL
         assert grad_err(r["critic_gnorm"], z["critic_gradients"][e]) <= GRAD_TOL
         for g, after in r["actor_steps"]:
-            check_grads(g, z["actor_grads"][k], "gru golden actor grad")
-            check_step(after, z["actor_after"][k], golden_before(z, "actor", k), "gru golden actor step")
+            ca.step(g, after, z["actor_grads"][k], z["actor_after"][k])
             k += 1
-        check_grads(r["critic_grads"], z["critic_grads"][e], "gru golden critic grad")
-        check_step(r["critic_after"], z["critic_after"][e], golden_before(z, "critic", e), "gru golden critic step")
+        cc.step(r["critic_grads"], r["critic_after"], z["critic_grads"][e], z["critic_after"][e])
     assert k == len(z["actor_grads"])
 
 
-def _check_gru_against_oracle(recs, orecs, ap, cp, label):
+def _check_gru_against_oracle(recs, orecs, a0, c0, hp, label):
     """Per-epoch scalars, per-chunk actor gradients / steps and the critic's steps of a GRU update against oracle.restatement.gru_update
-    (ap / cp: the parameters both started from)."""
+    (a0 / c0: flat copies of the parameters both started from, taken BEFORE the oracle stepped its lists in place)."""
     from oracle import restatement as R
-    a0, c0 = R.flat(ap), R.flat(cp)
+    ca = StepChecker(a0, hp["optimizer"], hp["learning_rate_actor"], label + " actor")
+    cc = StepChecker(c0, hp["optimizer"], hp["learning_rate_critic"], label + " critic")
     for r, o in zip(recs, orecs):
         for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
             assert _err(r[k], o[k], label + " " + k) <= TOL, k
@@ -747,11 +758,8 @@ def _check_gru_against_oracle(recs, orecs, ap, cp, label):
             assert grad_err(r[k], o[k], label + " gnorm") <= GRAD_TOL, k
         assert len(r["actor_steps"]) == len(o["actor_steps"])
         for (g, after), ost in zip(r["actor_steps"], o["actor_steps"]):
-            check_grads(g, R.flat(ost["grads"]), label + " actor grad")
-            check_step(after, R.flat(ost["after"]), a0, label + " actor step")
-            a0 = R.flat(ost["after"])
-        check_step(r["critic_after"], R.flat(o["critic_after"]), c0, label + " critic step")
-        c0 = R.flat(o["critic_after"])
+            ca.step(g, after, R.flat(ost["grads"]), R.flat(ost["after"]))
+        cc.step(r["critic_grads"], r["critic_after"], R.flat(o["critic_grads"]), R.flat(o["critic_after"]))
 
 
 @pytest.mark.parametrize("tile", ["auto", "32", "64"])
@@ -779,9 +787,10 @@ def test_gru_update_matches_oracle_seeded(algo, E, A, T, Do, Ds, K, H, tb, tile,
                                           batch["avail"], batch["mask"], dev)
     L = GRUPPOLearner(algo, aspec, cspec, A, HParams(**hp), dev, actor_params=[p.clone() for p in ap], critic_params=[p.clone() for p in cp])
     recs = L.train_iteration(b, keep_grads=True)
+    a0, c0 = R.flat(ap).clone(), R.flat(cp).clone()
     ret, adv, orecs = R.gru_update(ap, cp, batch, hp, algo)
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL and _err(b.adv.permute(0, 2, 1).cpu().numpy(), adv.numpy()) <= TOL
-    _check_gru_against_oracle(recs, orecs, ap, cp, "gru seeded")
+    _check_gru_against_oracle(recs, orecs, a0, c0, hp, "gru seeded")
 
 
 @pytest.mark.parametrize("E,A,T,Do,K,H,t0,t1", [(40, 5, 23, 35, 5, 64, 0, 10), (40, 5, 23, 35, 5, 64, 20, 23), (11, 4, 13, 37, 17, 64, 5, 10),
@@ -957,16 +966,15 @@ def test_full_size_three_epochs_against_the_oracle():
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy() * m3, ret.numpy() * m3, "full-size returns") <= TOL
     assert _err(b.adv.permute(0, 2, 1).cpu().numpy() * m3, adv.numpy() * m3, "full-size advantages") <= TOL
     assert len(recs) == 3
+    ca = StepChecker(a0, hp["optimizer"], hp["learning_rate_actor"], "full-size 3-epoch actor")
+    cc = StepChecker(c0, hp["optimizer"], hp["learning_rate_critic"], "full-size 3-epoch critic")
     for e, (r, o) in enumerate(zip(recs, orecs)):
         for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
             assert _err(r[k], o[k], "full-size " + k) <= TOL, (e, k)
         for k in ("actor_gnorm", "critic_gnorm"):
             assert grad_err(r[k], o[k], "full-size gnorm") <= GRAD_TOL, (e, k)
-        check_grads(r["actor_grads"], R.flat(o["actor_grads"]), "full-size 3-epoch actor grad")
-        check_grads(r["critic_grads"], R.flat(o["critic_grads"]), "full-size 3-epoch critic grad")
-        check_step(r["actor_after"], R.flat(o["actor_after"]), a0, "full-size 3-epoch actor step")
-        check_step(r["critic_after"], R.flat(o["critic_after"]), c0, "full-size 3-epoch critic step")
-        a0, c0 = R.flat(o["actor_after"]), R.flat(o["critic_after"])
+        ca.step(r["actor_grads"], r["actor_after"], R.flat(o["actor_grads"]), R.flat(o["actor_after"]))
+        cc.step(r["critic_grads"], r["critic_after"], R.flat(o["critic_grads"]), R.flat(o["critic_after"]))
 
 
 def test_full_size_scan_linearity_and_padding_invariance():
@@ -1373,12 +1381,11 @@ def test_hand_ordered_and_compiler_scheduled_product_forms_agree_bit_for_bit(alg
     assert torch.equal(out["hand"][2], out["loop"][2]) and torch.equal(out["hand"][3], out["loop"][3])
     for e in range(2):
         assert torch.equal(out["hand"][1][e]["actor_grads"], out["loop"][1][e]["actor_grads"])
+    ca = StepChecker(R.flat(ap), "Adam", 8e-4, "hand forms actor")  # (before mlp_update steps the lists in place)
     ret, adv, orec = R.mlp_update(ap, cp, batch, hpd, algo)
     assert _err(out["hand"][0].permute(0, 2, 1).cpu().numpy(), ret.numpy()) <= TOL
-    a0 = R.flat(ap)
     for e in range(2):
-        check_step(out["hand"][1][e]["actor_after"], R.flat(orec[e]["actor_after"]), a0, "hand forms actor step")
-        a0 = R.flat(orec[e]["actor_after"])
+        ca.step(out["hand"][1][e]["actor_grads"], out["hand"][1][e]["actor_after"], R.flat(orec[e]["actor_grads"]), R.flat(orec[e]["actor_after"]))
 
 
 def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeypatch):

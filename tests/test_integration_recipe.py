@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import DISP_TOL, GRAD_TOL, TOL, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
+from parity import DISP_TOL, GRAD_TOL, TOL, StepChecker, check_grads, check_step, golden_before, golden_init, grad_err  # noqa: F401
 from parity import err as _err
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +63,8 @@ def test_ctypes_recipe_reproduces_the_reference(golden_dir, name):
     m_a, v_a, m_c, v_c = (torch.zeros(n, device="cuda") for n in (Pa, Pa, Pc, Pc))
     norms = torch.zeros(2, device="cuda")
     adamw = hp["optimizer"] == "AdamW"
+    chk_a = StepChecker(golden_init(z, "actor"), str(hp["optimizer"]), float(hp["learning_rate_actor"]), "ctypes recipe actor")
+    chk_c = StepChecker(golden_init(z, "critic"), str(hp["optimizer"]), float(hp["learning_rate_critic"]), "ctypes recipe critic")
     for epoch in range(int(hp["epochs"])):
         chk(lib.cm_ppo_actor_fwd_bwd(P(obs), P(avail), P(action), P(logp), P(adv), P(ep_len), E, A, T, Do, Ha, La, K, P(actor_flat),
                                      d(hp["ppo_clip"]), d(hp["entropy_coef"]), P(ga), P(ws), C.c_size_t(ws.numel()), S()))
@@ -80,8 +82,8 @@ def test_ctypes_recipe_reproduces_the_reference(golden_dir, name):
         assert _err(float(st[3] / N), z["clipped_ratios"][epoch]) <= TOL
         assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
         assert grad_err(float(norms[0]), z["actor_gradients"][epoch]) <= GRAD_TOL and grad_err(float(norms[1]), z["critic_gradients"][epoch]) <= GRAD_TOL
-        check_step(actor_flat, z["actor_after"][epoch], golden_before(z, "actor", epoch), "ctypes recipe actor step")
-        check_step(critic_flat, z["critic_after"][epoch], golden_before(z, "critic", epoch), "ctypes recipe critic step")
+        chk_a.step(ga[:Pa], actor_flat, z["actor_grads"][epoch], z["actor_after"][epoch])  # (the step leaves the gradient it consumed in the buffer)
+        chk_c.step(gc[:Pc], critic_flat, z["critic_grads"][epoch], z["critic_after"][epoch])
 
 
 class OptStep(C.Structure):  # cm_opt_step_t exactly as INTEGRATION.md section 6c declares it
@@ -139,6 +141,8 @@ def test_ctypes_train_step_recipe_reproduces_the_reference(golden_dir, name):
     rec = torch.zeros(int(hp["epochs"]), 8, device="cuda")  # cm_opt_step_t::stats_out (ABI 101): the actor's statistic sums of every epoch
     assert lib.cm_version() >= 101
     scr_a, scr_c = (torch.zeros(lib.cm_opt_step_scratch_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2))
+    chk_a = StepChecker(golden_init(z, "actor"), str(hp["optimizer"]), float(hp["learning_rate_actor"]), "ctypes recipe actor")
+    chk_c = StepChecker(golden_init(z, "critic"), str(hp["optimizer"]), float(hp["learning_rate_critic"]), "ctypes recipe critic")
     try:
         for epoch in range(int(hp["epochs"])):
             oa = OptStep(actor_flat.data_ptr(), m_a.data_ptr(), v_a.data_ptr(), norms.data_ptr(), scr_a.data_ptr(), hp["learning_rate_actor"], 0.9,
@@ -154,7 +158,7 @@ def test_ctypes_train_step_recipe_reproduces_the_reference(golden_dir, name):
             assert _err(float((-st[0] - hp["entropy_coef"] * st[1]) / N), z["actor_losses"][epoch]) <= TOL
             assert _err(float(gc[Pc + 4] / gc[Pc + 5]), z["critic_losses"][epoch]) <= TOL
             assert grad_err(float(norms[0]), z["actor_gradients"][epoch]) <= GRAD_TOL and grad_err(float(norms[1]), z["critic_gradients"][epoch]) <= GRAD_TOL
-            check_step(actor_flat, z["actor_after"][epoch], golden_before(z, "actor", epoch), "ctypes recipe actor step")
-            check_step(critic_flat, z["critic_after"][epoch], golden_before(z, "critic", epoch), "ctypes recipe critic step")
+            chk_a.step(ga[:Pa], actor_flat, z["actor_grads"][epoch], z["actor_after"][epoch])  # (the step leaves the gradient it consumed in the buffer)
+            chk_c.step(gc[:Pc], critic_flat, z["critic_grads"][epoch], z["critic_after"][epoch])
     finally:
         chk(lib.cm_set_option(b"critic_schedule", b"auto"))
