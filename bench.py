@@ -151,6 +151,44 @@ class Workload:
                     update=phases[2], update_actor_stream=actor_half, update_critic_stream=phases[3]),
                     actor_ms=mean(act_ms), critic_ms=mean(cri_ms))
 
+    def solo_actor_leg(self, launches=10, warm=3):
+        """The dominant kernel ALONE on the device: `launches` back-to-back cm_ppo_actor_fwd_bwd_ld calls (the pass + its fold launch; no
+        optimiser step, the parameters do not move) on a fresh batch with nothing else in flight, each bracketed by HIP events on the launch
+        stream.  The timed iterations run the critic's epochs beside the actor's (learner.overlap_critic: the faster schedule), so the
+        in-iteration duration of this kernel is a co-residency figure; the roofline of the kernel itself is quoted on this leg.
+        -> (mean ms, [ms per launch]) or None for workloads without an MLP actor pass."""
+        from cleanmarl_amd import _native as N
+        L = self.learner
+        if self.actor_kind != "mlp" or self.E == 0:
+            return None
+        b = self.roll.collect(L.actor, self.aspec)
+        L.compute_targets(b)
+        torch.cuda.synchronize()
+        s = N.stream_ptr()
+        for _ in range(warm):
+            L.actor_pass(b, s)
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(launches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); L.actor_pass(b, s); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(c) for a, c in ev]
+        # the critic's pass the same way (phase_roofline.critic_fwd_bwd: beside the actor's kernels it only fills their tails)
+        L.wait_critic()
+        for _ in range(warm):
+            L.critic_pass(b, s)
+        torch.cuda.synchronize()
+        evc = []
+        for _ in range(launches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); L.critic_pass(b, s); e1.record()
+            evc.append((e0, e1))
+        torch.cuda.synchronize()
+        self.solo_critic_ms = sum(a.elapsed_time(c) for a, c in evc) / len(evc)
+        return sum(ms) / len(ms), ms
+
     # ---- algorithmic work per launch (SURVEY.md §8(d); weights, MFMA-tile padding and recomputation are NOT counted)
     def work(self):
         E, A, T, K = self.E, self.A, self.T, self.roll.K
@@ -243,13 +281,19 @@ def _bound(work, ms):
     return dict(ms=ms, bound=b, tflops=tf, gbs=gb, frac=(tf / PEAK_F32_MFMA_TFLOPS if b == "mfma" else gb / PEAK_HBM_GBS))
 
 
-def summarize(w, r):
-    """Compact record of one timed workload (used for other_workloads / strong_scaling_shares)."""
+def summarize(w, r, solo=None):
+    """Compact record of one timed workload (used for other_workloads / strong_scaling_shares).  solo: Workload.solo_actor_leg()'s result --
+    roofline_frac is then the actor pass's own rate (alone on the device), `actor_fwd_bwd_ms` stays the in-iteration duration."""
     wk = w.work()
     units = w.world * w.E * w.A * w.T * r["steps"]
-    return dict(envs=w.E, ms_per_step=r["ms_per_step"], value=units / r["dt"], phase_ms=r["phase_ms"],
-                actor_fwd_bwd_ms=r["actor_ms"], critic_fwd_bwd_ms=r["critic_ms"],
-                roofline_frac=(_bound(wk["actor"], r["actor_ms"]) or {}).get("frac"))
+    kern_ms = solo[0] if solo else r["actor_ms"]
+    out = dict(envs=w.E, ms_per_step=r["ms_per_step"], value=units / r["dt"], phase_ms=r["phase_ms"],
+               actor_fwd_bwd_ms=r["actor_ms"], critic_fwd_bwd_ms=r["critic_ms"],
+               roofline_frac=(_bound(wk["actor"], kern_ms) or {}).get("frac"))
+    if solo:
+        out["actor_fwd_bwd_solo_ms"] = solo[0]
+        out["critic_fwd_bwd_solo_ms"] = getattr(w, "solo_critic_ms", None)
+    return out
 
 
 def message_latencies(w, dev, pg, N, peer_too=True):
@@ -324,6 +368,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / strong_scaling_shares / weak_scaling legs")
     ap.add_argument("--cpu-envs", type=int, default=256, help="envs in the bounded CPU-baseline sample")
+    ap.add_argument("--solo-launches", type=int, default=10,
+                    help="launches of the solo leg that times the dominant kernel alone after the timed region (N = 1; 0 = off)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,6 +425,15 @@ def main():
     clk = torch.zeros(512, 4, dtype=torch.int64, device=dev)
     N.check(N.load().cm_clock_probe(N.ptr(clk)), "cm_clock_probe")
     r = w.run(args.steps, args.warmup)
+    # the dominant kernel alone (N = 1, MLP actors): after the timed region, before the probe is read -- the clock / workgroup-span figures
+    # below then describe a solo launch as well.  --solo-launches 0 skips the leg (the roofline then falls back to the in-iteration events)
+    solo = None
+    if world == 1 and args.solo_launches > 0:
+        try:
+            solo = w.solo_actor_leg(args.solo_launches)
+        except Exception as ex:  # noqa: BLE001 -- never instead of the headline line
+            solo = None
+            print(f"[bench] solo leg failed: {ex!r}", file=sys.stderr)
     N.check(N.load().cm_clock_probe(None), "cm_clock_probe")
     clk_all = clk.cpu()
     clk = [int(v) for v in clk_all[0]]
@@ -389,7 +444,9 @@ def main():
     if rank == 0:
         units = total_envs * A * T * args.steps
         wk = w.work()
-        act = _bound(wk["actor"], r["actor_ms"]) or dict(tflops=0.0)
+        # the kernel's own duration: the solo leg when there is one, else the launches inside the timed iterations
+        kern_ms = solo[0] if solo else r["actor_ms"]
+        act = _bound(wk["actor"], kern_ms) or dict(tflops=0.0)
         achieved = act["tflops"]
         desc = w.desc if not args.envs else f"{w.desc} [envs overridden to {E_glob}]"
         out = {
@@ -408,11 +465,15 @@ def main():
             "roofline": {"kernel": "k_mlp<NCH,M_ACTOR> (cm_ppo_actor_fwd_bwd)" if w.actor_kind == "mlp" else
                          "k_gru_chunk_fwd + k_gru_chunk_bwd (all TBPTT chunks of one epoch)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "flop_per_launch": wk["actor"]["flop"]},
+                         "traffic": None, "flop_per_launch": wk["actor"]["flop"],
+                         "launch_ms": kern_ms, "in_iteration_launch_ms": r["actor_ms"],
+                         "source": (f"solo leg: {len(solo[1])} back-to-back launches of the pass alone on the device after the timed region, HIP events on the launch "
+                                    "stream (min %.4f max %.4f ms); inside the timed iterations the critic's epochs run beside it (in_iteration_launch_ms)"
+                                    % (min(solo[1]), max(solo[1]))) if solo else "HIP events around the launches inside the timed iterations"},
             # the other phases of the step against their own bounds (algorithmic work of SURVEY.md §8(d) / event time)
             "phase_roofline": {"rollout": _bound(wk["rollout"], r["phase_ms"]["rollout"]),
                                "value_pass_scan": _bound(wk["value_pass"], r["phase_ms"]["value_pass_scan"]),
-                               "critic_fwd_bwd": _bound(wk["critic"], r["critic_ms"]),
+                               "critic_fwd_bwd": _bound(wk["critic"], getattr(w, "solo_critic_ms", None) or r["critic_ms"]),
                                "whole_step": _bound(dict(flop=wk["rollout"]["flop"] + wk["value_pass"]["flop"] + hp.epochs * (wk["actor"]["flop"] + wk["critic"]["flop"]),
                                                          bytes=wk["rollout"]["bytes"] + wk["value_pass"]["bytes"] + hp.epochs * (wk["actor"]["bytes"] + wk["critic"]["bytes"])),
                                                     r["ms_per_step"])},
@@ -424,11 +485,11 @@ def main():
             # what the kernel ISSUES on the matrix pipe (tile padding included: Do -> 64-column chunks in dW0, K -> 16 head rows ...) beside the
             # algorithmic flop the fraction above is quoted on: issued / algorithmic is the padding, issued_frac the pipe's share of nominal peak
             per_row = N.load().cm_ppo_actor_issued_flop_per_row(w.aspec.din, w.aspec.hidden, w.aspec.n_layers, w.aspec.dout)
-            if per_row > 0 and r["actor_ms"] > 0:
+            if per_row > 0 and kern_ms > 0:
                 issued = per_row * wk["rows_a"]
                 out["roofline"]["issued_flop_per_launch"] = issued
                 out["roofline"]["issued_over_algorithmic"] = issued / wk["actor"]["flop"]
-                out["roofline"]["issued_frac"] = issued / (r["actor_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                out["roofline"]["issued_frac"] = issued / (kern_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
         if clk[3] > clk[2] and clk[0] > 0:
             # s_memtime ticks are shader cycles, s_memrealtime ticks the constant 100 MHz reference: the clock workgroup 0 of the LAST actor
             # pass of the timed region ran at, and the pass's rate against the fp32 MFMA peak AT THAT CLOCK (256 CUs x 256 flop per cycle) --
@@ -443,7 +504,7 @@ def main():
             st, en = (live[:, 2] - t0) / 1e5, (live[:, 3] - t0) / 1e5
             out["roofline"]["workgroup_span"] = {"workgroups": int(live.shape[0]), "last_entry_ms": float(st.max()), "first_exit_ms": float(en.min()),
                                                  "median_exit_ms": float(en.median()), "last_exit_ms": float(en.max()),
-                                                 "mean_busy_ms": float((en - st).mean()), "launch_ms_hip_events": r["actor_ms"]}
+                                                 "mean_busy_ms": float((en - st).mean()), "launch_ms_hip_events": kern_ms}
         if args.workload == "cfg3" and not args.envs and world == 1:
             pmc, why = load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
             if pmc is not None:
@@ -519,7 +580,7 @@ def main():
                     continue
                 ww = Workload(name, WORKLOADS[name][0], 0, dev)
                 rr = ww.run(20, 5)  # 20 steps: a 5-step leg charges the deferred critic epochs' tail (joined at the final sync) to too few steps
-                others[name] = dict(summarize(ww, rr), workload=ww.desc)
+                others[name] = dict(summarize(ww, rr, ww.solo_actor_leg(args.solo_launches) if args.solo_launches > 0 else None), workload=ww.desc)
                 full_ms[name] = rr["ms_per_step"]
                 ww.close()
             for name in ("cfg3", "cfg4"):  # the configs north_star shards over 8 GPUs

@@ -475,16 +475,19 @@ class PPOLearner:
         the optimiser-step launch and the streaming dW0 kernel could be placed beside the other stream's kernels (gpurun_out/r03ac, r03ad;
         schedule 0 / 1 / 2): config 3 at 2048 envs 4.72 / 4.74 / 4.80, 1024 envs 2.71 / 2.74 / 2.68, 768 envs 2.35 / 2.19 / 2.09, 384 envs
         - / 1.26 / 1.24, 256 envs - / 0.97 / 1.00, 128 envs - / 0.745 / 0.752; config 2 1.33 / 1.21 / 1.19 (512 envs: - / 0.885 / 0.870);
-        config 4 at 512 envs 6.22 / 6.26 / 5.93, 256 envs 3.26 / 3.29 / 3.07, 128 envs - / 1.79 / 1.60.  Default: 1 below 2^17 rows, 2 below
-        2^21 rows, 0 from there -- at full size schedule 2 gains 2.6 % (8.43 vs 8.66 ms) but the actor kernel,
-        the one the roofline is quoted on, would be timed with a second kernel beside it (1.85 -> 2.2 ms per launch).
+        config 4 at 512 envs 6.22 / 6.26 / 5.93, 256 envs 3.26 / 3.29 / 3.07, 128 envs - / 1.79 / 1.60.  Default: 1 below 2^17 rows, 2 from
+        there on.  At full size (>= 2^21 rows) schedule 2 is the faster one as well -- round 6, on the round-5 kernels: 7.905 vs 7.985 ms per
+        iteration at 4096 envs (profiles/r06_schedule_full_size_ab.txt; the critic's one-pass kernel needs a whole CU's registers, so beside the
+        actor's persistent workgroups it only fills the tails of the actor's launches: 1 %, not the 2.6 % of round 2's kernels) -- and ships;
+        rounds 2 - 5 kept schedule 0 there so that the actor kernel, the one the roofline is quoted on, was timed alone: bench.py now times that
+        kernel in a SOLO leg after the timed region (roofline.source) and reports the in-iteration duration beside it.
         CM_CRITIC_OVERLAP=0 / 1 / 2 forces a schedule."""
         import os
         v = os.environ.get("CM_CRITIC_OVERLAP")
         if v in ("0", "1", "2"):
             return int(v)
         rows = self._schedule_rows(b)
-        return 1 if rows < (1 << 17) else 2 if rows < (1 << 21) else 0
+        return 1 if rows < (1 << 17) else 2
 
     def _schedule_rows(self, b):
         """Row count the schedule is chosen from -- the SAME number on every rank: env shards may differ by one env (dist.shard), and

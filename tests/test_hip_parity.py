@@ -227,29 +227,30 @@ def _seeded_case(algo, E, A, T, Do, Ds, K, H, L, normalize, tol=TOL):
     bars = {}
     twins = {"actor": OptimizerTwin(before["actor"], hp["optimizer"], hp["learning_rate_actor"]),
              "critic": OptimizerTwin(before["critic"], hp["optimizer"], hp["learning_rate_critic"])}
-    for r, o in zip(recs, orecs):
+    for epoch, (r, o) in enumerate(zip(recs, orecs)):
         for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
             errs[k] = max(errs.get(k, 0.0), _err(r[k], o[k], "seeded " + k))
         for k in ("actor_gnorm", "critic_gnorm"):
             errs[k] = max(errs.get(k, 0.0), grad_err(r[k], o[k], "seeded gnorm"))
             bars[k] = GRAD_TOL * scale
         for net in ("actor", "critic"):
-            k = net + "_grads"
-            errs[k] = max(errs.get(k, 0.0), grad_err(r[k], R.flat(o[k]), "seeded " + k))
-            bars[k] = GRAD_TOL * scale
+            k = net + ("_grads" if epoch == 0 else "_grads_later")  # later epochs: gradients at parameters that drifted apart (StepChecker)
+            errs[k] = max(errs.get(k, 0.0), grad_err(r[net + "_grads"], R.flat(o[net + "_grads"]), "seeded " + k))
+            bars[k] = GRAD_TOL * scale * (1.0 if epoch == 0 else StepChecker.LATER_GRAD)
             k = net + "_twin"  # the HIP step against torch.optim's on the gradient it consumed: every entry, whatever the arithmetic of the passes
             errs[k] = max(errs.get(k, 0.0), twin_err(twins[net], r[net + "_grads"], r[net + "_after"], "seeded " + k))
             bars[k] = DISP_TOL
-            k = net + "_after"  # ... and against the oracle's parameters on the well-conditioned entries
-            errs[k] = max(errs.get(k, 0.0), disp_err(r[k], R.flat(o[k]), before[net], "seeded " + k, ref_grad=R.flat(o[net + "_grads"])))
-            bars[k] = DISP_TOL * scale
+            k = net + "_after"  # ... and against the oracle's parameters: the absolute end-to-end bound (tests/parity.py: why not the displacement)
+            errs[k] = max(errs.get(k, 0.0), _err(r[k], R.flat(o[k]), "seeded " + k))
+            bars[k] = tol
+            disp_err(r[k], R.flat(o[k]), before[net], "seeded " + k + " displacement (well-conditioned entries, recorded)", ref_grad=R.flat(o[net + "_grads"]))
             before[net] = R.flat(o[k])
     for k, v in errs.items():
         assert v <= bars.get(k, tol), (k, v)
     return errs
 
 
-BF16X3_GRAD, BF16X3_STEP = 1e-3, 1e-1
+BF16X3_GRAD = 1e-3
 
 
 def test_bf16x3_opt_in_keeps_the_parity_bar():
@@ -271,15 +272,14 @@ def test_bf16x3_opt_in_keeps_the_parity_bar():
         assert p.returncode == 0, p.stderr[-2000:]
         out[mode] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("ERRS ")][0][5:])
     assert out["bf16x3"]["mode"] == 1 and out[""]["mode"] == 0
-    # the compensated mode's tier: returns / advantages / losses / statistics inside north_star's 1e-4; gradients within 1e-3 of the
-    # largest gradient entry; an optimiser step within 10 % of the largest displacement (Adam's g / sqrt(v) amplifies the relative error
-    # of near-zero gradient entries; the exact-fp32 default sits at 1e-4 / 1e-3, tests/parity.py)
+    # the compensated mode's tier: returns / advantages / losses / statistics / post-step parameters inside north_star's 1e-4; gradients
+    # within 1e-3 of the largest gradient entry (the exact-fp32 default: 1e-4); the optimiser step itself at the twin's bar in every mode
     for k, v in out[""].items():  # the exact-fp32 default on the same case: the three bars of tests/parity.py
         if k != "mode":
-            assert v <= (GRAD_TOL if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith(("_after", "_twin")) else TOL), (k, v)
+            assert v <= (GRAD_TOL * (StepChecker.LATER_GRAD if k.endswith("_later") else 1.0) if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith("_twin") else TOL), (k, v)
     for k, v in out["bf16x3"].items():
         if k != "mode":  # (the optimiser step itself is the same fp32 kernel in every mode: the twin bar does not loosen)
-            assert v <= (BF16X3_GRAD if "grad" in k or "gnorm" in k else BF16X3_STEP if k.endswith("_after") else DISP_TOL if k.endswith("_twin") else TOL), (k, v)
+            assert v <= (BF16X3_GRAD if "grad" in k or "gnorm" in k else DISP_TOL if k.endswith("_twin") else TOL), (k, v)
     assert out["bf16x3"]["actor_grads"] != out[""]["actor_grads"]
     print("max errors vs oracle  fp32:", {k: f"{v:.1e}" for k, v in out[""].items() if k != "mode"})
     print("max errors vs oracle bf16x3:", {k: f"{v:.1e}" for k, v in out["bf16x3"].items() if k != "mode"})
@@ -306,10 +306,10 @@ def test_bf16_single_pass_has_its_own_parity_tier():
     assert e["ret"] <= TOL and e["adv"] <= TOL
     for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
         assert e[k] <= 2e-2, (k, e[k])
-    for k in ("actor_gnorm", "critic_gnorm", "actor_grads", "critic_grads"):
+    for k in ("actor_gnorm", "critic_gnorm", "actor_grads", "critic_grads", "actor_grads_later", "critic_grads_later"):
         assert e[k] <= 5e-2, (k, e[k])
-    for k in ("actor_after", "critic_after"):  # relative to the step's largest displacement, well-conditioned entries (tests/parity.py)
-        assert e[k] <= 1.0, (k, e[k])
+    for k in ("actor_after", "critic_after"):
+        assert e[k] <= 1e-2, (k, e[k])
     for k in ("actor_twin", "critic_twin"):    # the optimiser step is the fp32 kernel of every mode
         assert e[k] <= DISP_TOL, (k, e[k])
     assert e["actor_grads"] > 1e-6  # it really took the single-pass kernels
@@ -941,15 +941,17 @@ def test_full_size_env_sharding_additivity():
 
 def test_full_size_three_epochs_against_the_oracle():
     """BASELINE configs[2] at FULL size (4096 envs x 8 agents x 128 steps, ragged episodes), the whole iteration -- value pass, scan,
-    THREE epochs with their optimiser steps -- against oracle.restatement.mlp_update on the host cores (a batched torch-CPU restatement:
-    about a minute on the GPU box): returns / advantages / per-epoch losses and statistics at 1e-4, every epoch's gradients relative to
-    their largest entry, every optimiser step as a displacement (tests/parity.py).  The other full-size tests pin ONE epoch's sums
-    through shard additivity; this one compares what three epochs leave behind."""
+    THREE epochs with their optimiser steps -- against the oracle on the host cores (a batched torch-CPU restatement: about a minute on
+    the GPU box): returns / advantages at 1e-4; per epoch the losses / statistics at 1e-4, the gradients relative to their largest entry,
+    and every optimiser step against torch.optim on the gradient it consumed (tests/parity.py).  The oracle is TEACHER-FORCED: epoch e is
+    evaluated at the parameters the HIP path holds before epoch e -- at this size an Adam step moves the ill-conditioned entries (gradient
+    sums of 524 288 rows that cancel to 1e-7 of the largest entry) by a good part of lr either way, and an oracle stepped on its own drifts
+    away in exactly those entries (measured: second-epoch critic gradient 6e-4 apart).  The other full-size tests pin ONE epoch's sums
+    through shard additivity; this one covers what three epochs leave behind."""
     from oracle import restatement as R
     L, b = _full_size_setup()
-    split = lambda flat, spec: [q.reshape(sh).clone() for q, sh in zip(torch.split(flat.cpu(), [int(np.prod(sh)) for sh in spec.shapes()]), spec.shapes())]
+    split = lambda flat, spec: [q.reshape(sh).clone() for q, sh in zip(torch.split(flat.detach().cpu(), [int(np.prod(sh)) for sh in spec.shapes()]), spec.shapes())]
     ap, cp = split(L.actor, L.actor_spec), split(L.critic_params(), L.critic_spec)
-    a0, c0 = R.flat(ap).clone(), R.flat(cp).clone()
     recs = L.train_iteration(b, keep_grads=True)
     torch.cuda.synchronize()
     T = b.T
@@ -959,22 +961,24 @@ def test_full_size_three_epochs_against_the_oracle():
     hp = dict(gamma=L.hp.gamma, td_lambda=L.hp.td_lambda, epochs=L.hp.epochs, ppo_clip=L.hp.ppo_clip, entropy_coef=L.hp.entropy_coef,
               clip_gradients=L.hp.clip_gradients, optimizer=L.hp.optimizer, learning_rate_actor=L.hp.learning_rate_actor,
               learning_rate_critic=L.hp.learning_rate_critic, normalize_reward=False, normalize_advantage=False, normalize_return=False)
-    assert hp["epochs"] == 3
+    assert hp["epochs"] == 3 and len(recs) == 3
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
-    ret, adv, orecs = R.mlp_update(ap, cp, batch, hp, "mappo")
+    ret, adv = R.prepare_targets(batch, cp, hp, "mappo")
     m3 = mask[:, :, None].numpy()
     assert _err(b.ret.permute(0, 2, 1).cpu().numpy() * m3, ret.numpy() * m3, "full-size returns") <= TOL
     assert _err(b.adv.permute(0, 2, 1).cpu().numpy() * m3, adv.numpy() * m3, "full-size advantages") <= TOL
-    assert len(recs) == 3
-    ca = StepChecker(a0, hp["optimizer"], hp["learning_rate_actor"], "full-size 3-epoch actor")
-    cc = StepChecker(c0, hp["optimizer"], hp["learning_rate_critic"], "full-size 3-epoch critic")
-    for e, (r, o) in enumerate(zip(recs, orecs)):
+    twin_a = OptimizerTwin(R.flat(ap), hp["optimizer"], hp["learning_rate_actor"])
+    twin_c = OptimizerTwin(R.flat(cp), hp["optimizer"], hp["learning_rate_critic"])
+    for e, r in enumerate(recs):
+        scal, ag, cg = R.mlp_epoch(ap, cp, batch, ret, adv, hp, "mappo")  # the oracle at the HIP path's parameters before this epoch
         for k in ("actor_loss", "critic_loss", "entropy", "kl", "clipfrac"):
-            assert _err(r[k], o[k], "full-size " + k) <= TOL, (e, k)
-        for k in ("actor_gnorm", "critic_gnorm"):
-            assert grad_err(r[k], o[k], "full-size gnorm") <= GRAD_TOL, (e, k)
-        ca.step(r["actor_grads"], r["actor_after"], R.flat(o["actor_grads"]), R.flat(o["actor_after"]))
-        cc.step(r["critic_grads"], r["critic_after"], R.flat(o["critic_grads"]), R.flat(o["critic_after"]))
+            assert _err(r[k], scal[k], "full-size " + k) <= TOL, (e, k)
+        assert grad_err(r["actor_gnorm"], R.grad_norm(ag).item(), "full-size gnorm") <= GRAD_TOL and grad_err(r["critic_gnorm"], R.grad_norm(cg).item(), "full-size gnorm") <= GRAD_TOL, e
+        check_grads(r["actor_grads"], R.flat(ag), "full-size 3-epoch actor grad (teacher-forced)")
+        check_grads(r["critic_grads"], R.flat(cg), "full-size 3-epoch critic grad (teacher-forced)")
+        assert twin_err(twin_a, r["actor_grads"], r["actor_after"], "full-size actor step vs torch.optim on the same gradient") <= DISP_TOL, e
+        assert twin_err(twin_c, r["critic_grads"], r["critic_after"], "full-size critic step vs torch.optim on the same gradient") <= DISP_TOL, e
+        ap, cp = split(r["actor_after"], L.actor_spec), split(r["critic_after"], L.critic_spec)
 
 
 def test_full_size_scan_linearity_and_padding_invariance():

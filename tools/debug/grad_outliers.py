@@ -74,7 +74,47 @@ def gru_case(algo, E, A, T, Do, Ds, K, H, tb, tile):
             report(f"epoch {e} chunk {c} actor", aspec, g.cpu().numpy(), R.flat(ost["grads"]).numpy())
 
 
+def shard_case(name):
+    """tests/test_hip_parity.py::test_full_size_other_configs_shard_additivity_and_oracle_shard: one epoch's actor gradient of a 16-env shard
+    of config 4 against the fp32 oracle AND against the same oracle evaluated in fp64 -- who is off, the HIP pass or the fp32 CPU sums?"""
+    from cleanmarl_amd import _native as N
+    L, b, c = t._full_size_cfg(name)
+    algo = c["algo"]
+    L.compute_targets(b)
+    s = N.stream_ptr()
+    sb = b.shard(0, c["shard"])
+    L.actor_pass(sb, s); L.critic_pass(sb, s)
+    torch.cuda.synchronize()
+    first = L.gbuf.clone()
+    Pa = L.actor.numel()
+    T = b.T
+    mask = torch.arange(T)[None, :] < sb.ep_len.cpu()[:, None]
+    batch = dict(obs=sb.obs.permute(0, 2, 1, 3).cpu(), actions=sb.action.permute(0, 2, 1).long().cpu(), log_probs=sb.logp.permute(0, 2, 1).cpu(),
+                 reward=sb.reward.cpu(), states=sb.state.cpu(), avail=sb.avail.permute(0, 2, 1, 3).bool().cpu(), mask=mask)
+    hp = dict(gamma=0.99, td_lambda=0.95, epochs=1, ppo_clip=0.2, entropy_coef=0.001, clip_gradients=-1, optimizer="Adam",
+              learning_rate_actor=8e-4, learning_rate_critic=8e-4, normalize_reward=False, normalize_advantage=False, normalize_return=False)
+    split = lambda flat, spec: [q.reshape(sh) for q, sh in zip(torch.split(flat.cpu(), [int(np.prod(sh)) for sh in spec.shapes()]), spec.shapes())]
+    ap, cp = split(L.actor, L.actor_spec), split(L.critic_params(), L.critic_spec)
+    ret, adv = sb.ret.permute(0, 2, 1).cpu(), sb.adv.permute(0, 2, 1).cpu()
+    scal, ag, cg = R.mlp_epoch(ap, cp, batch, ret, adv, hp, algo)
+    dbl = lambda x: x.double() if x.is_floating_point() else x
+    scal64, ag64, cg64 = R.mlp_epoch([p.double() for p in ap], [p.double() for p in cp], {k: dbl(v) for k, v in batch.items()}, ret.double(), adv.double(), hp, algo)
+    n = float(first[Pa + 5])
+    hip = (first[:Pa] / n).cpu().numpy().astype(np.float64)
+    o32, o64 = R.flat(ag).numpy().astype(np.float64), R.flat(ag64).numpy()
+    mx = np.abs(o64).max()
+    print(f"SHARD {name}: rows {int(mask.sum()) * sb.A}  max|g| {mx:.3e}")
+    print(f"  HIP   vs fp64 oracle: {np.abs(hip - o64).max() / mx:.3e}")
+    print(f"  fp32 oracle vs fp64 : {np.abs(o32 - o64).max() / mx:.3e}")
+    print(f"  HIP   vs fp32 oracle: {np.abs(hip - o32).max() / mx:.3e}")
+    report("HIP vs fp64 oracle", L.actor_spec, hip, o64)
+    report("fp32 oracle vs fp64 oracle", L.actor_spec, o32, o64)
+
+
 if __name__ == "__main__":
-    gru_case("ippo", 11, 4, 13, 37, 50, 17, 64, 5, "auto")
-    gru_case("ippo", 11, 4, 13, 37, 50, 17, 64, 5, "32")
-    mlp_case("ippo", 12, 10, 40, 115, 243, 17, 64, 1)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "shard"):
+        shard_case("cfg4")
+    if which in ("all", "gru"):
+        gru_case("ippo", 11, 4, 13, 37, 50, 17, 64, 5, "auto")
+        gru_case("ippo", 11, 4, 13, 37, 50, 17, 64, 5, "32")
