@@ -1109,7 +1109,9 @@ extern "C" size_t cm_gru_workspace_bytes(int E, int A, int din, int hidden, int 
     if (gru_wide(din, hidden, n_actions)) return cm_gru_wide_ws_bytes((int64_t)R, chunk_len, din, hidden, n_actions, 1);
     // per (step, row): the larger of the two activation formats (v2: 7 slots, cm_gru_v2.h) + the first generation's dlogits
     // + the pipelined sweeps' hand-over areas: step flags of k_gru2_fwdx (four 8-byte words per 32-row tile), {dh_t, tag} words of k_gru2_bwd<true>
-    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8 + (size_t)chunk_len * R * HP * 8;
+    // + the W_ih accumulators of the split forward sweep (k_gru2_pre -> k_gru2_fwdx<.., PRE>: GI_UNIT floats per 32-row tile and step)
+    return ((size_t)chunk_len * R * (WS2 + WS_DL) + (size_t)MAX_GRID * gru_ps(din, hidden, n_actions)) * sizeof(float) + 8 + (size_t)MAX_GRID * 4 * 8 + (size_t)chunk_len * R * HP * 8
+           + 16 + (size_t)chunk_len * ((R + T32 - 1) / T32) * GI_UNIT * sizeof(float);
 }
 
 static int gru_device_cus() {
@@ -1180,7 +1182,9 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         // ... and, while the tiles leave a third of the CUs idle, the head on those CUs (k_gru2_fwdx: one head workgroup per two tiles)
         const int tile_opt = cm_option(CM_OPTION_GRU_TILE);
         const int nh = (int)((nt32 + 1) / 2);
-        const bool pipelined = tile_opt == 0 && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
+        // gru_tile = "nopre": the pipelined sweeps of round 5 (the chain computes fc1 and the W_ih products itself) for A/B runs
+        const bool pipelined = (tile_opt == 0 || tile_opt == 1) && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
+        const bool split_fwd = pipelined && tile_opt == 0;
         GruXArgs xa = {};
         xa.nt = (int)nt32; xa.nh = nh;
         {
@@ -1191,9 +1195,23 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #define CM_GRU2_FX(WV_, KP_) do { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
         hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
+        // the split forward sweep: the h-independent products of all (tile, step) units on every CU first, then the chain on W_hh h + gates
+#define CM_GRU2_FXP(WV_, KP_) do { \
+        const long units_ = nt32 * CL; const int cus2_ = 2 * gru_device_cus(); \
+        hipLaunchKernelGGL((k_gru2_pre<WV_>), dim3((unsigned)(units_ < cus2_ ? units_ : cus2_)), dim3(NTHREADS), 0, (hipStream_t)stream, a, xa); \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
+        hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_, true>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
         if (tile_opt == 32) {
             if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
             else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
+        } else if (split_fwd) {
+            xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
+            {   // behind the {dh_t, tag} words of the backward sweep, 16-byte aligned
+                uintptr_t gp = reinterpret_cast<uintptr_t>(xa.flags + (size_t)MAX_GRID * 4 + (size_t)CL * R * HP);
+                xa.gi = reinterpret_cast<float*>((gp + 15) & ~(uintptr_t)15);
+            }
+            if (KP == 16) { if (wv) CM_GRU2_FXP(true, 16); else CM_GRU2_FXP(false, 16); }
+            else          { if (wv) CM_GRU2_FXP(true, 32); else CM_GRU2_FXP(false, 32); }
         } else if (pipelined) {
             xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
             if (KP == 16) { if (wv) CM_GRU2_FX(true, 16); else CM_GRU2_FX(false, 16); }
@@ -1204,6 +1222,7 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         }
 #undef CM_GRU2_F8
 #undef CM_GRU2_FX
+#undef CM_GRU2_FXP
 #undef CM_GRU2_F
         // backward: likewise, five of the seven weight-gradient products of a step on the idle CUs (k_gru2_bwd<true> / gru2_grad_wg: as many
         // workgroups as CUs are left, at most one per tile; their partial rows follow those of the tiles)

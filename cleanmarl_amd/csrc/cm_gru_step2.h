@@ -50,6 +50,30 @@ __device__ __forceinline__ void g2_load_weights(G2W& w, const float* params, con
     w.bin = ok ? params[off.bih + 2 * H + c] : 0.0f;
     w.bhn = ok ? params[off.bhh + 2 * H + c] : 0.0f;
 }
+// The two halves of g2_load_weights for the split forward sweep (k_gru2_pre / k_gru2_fwdx<.., PRE>): the blocks that multiply the
+// observation and x1 (h-independent: fc1, W_ir, W_iz, W_in) and the blocks that multiply h_{t-1} (the recurrence: W_hr, W_hz, W_hn).
+// The biases keep g2_load_weights' association (b_ih + b_hh for r and z).
+template <bool WV>
+__device__ __forceinline__ void g2_load_weights_x(G2W& w, const float* params, const GruOff& off, int din, int H) {
+    const int wave = threadIdx.x >> 6, c0 = 16 * wave, c = c0 + (threadIdx.x & 15);
+    load_nt16_regs<false>(w.w1, params + off.W1, c0, H, din, din);
+    load_nt16_regs<WV>(w.xr, params + off.Wih, c0, H, H, H);
+    load_nt16_regs<WV>(w.xz, params + off.Wih + H * H, c0, H, H, H);
+    load_nt16_regs<WV>(w.xn, params + off.Wih + 2 * H * H, c0, H, H, H);
+    w.b1 = (c < H) ? params[off.b1 + c] : 0.0f;
+}
+template <bool WV>
+__device__ __forceinline__ void g2_load_weights_h(G2W& w, const float* params, const GruOff& off, int H) {
+    const int wave = threadIdx.x >> 6, c0 = 16 * wave, c = c0 + (threadIdx.x & 15);
+    load_nt16_regs<WV>(w.hr, params + off.Whh, c0, H, H, H);
+    load_nt16_regs<WV>(w.hz, params + off.Whh + H * H, c0, H, H, H);
+    load_nt16_regs<WV>(w.hn, params + off.Whh + 2 * H * H, c0, H, H, H);
+    const bool ok = c < H;
+    w.br = ok ? params[off.bih + c] + params[off.bhh + c] : 0.0f;
+    w.bz = ok ? params[off.bih + H + c] + params[off.bhh + H + c] : 0.0f;
+    w.bin = ok ? params[off.bih + 2 * H + c] : 0.0f;
+    w.bhn = ok ? params[off.bhh + 2 * H + c] : 0.0f;
+}
 // three products that share their A operand: acc_p[rb] += A[16 rb + ..][16 kb] * W_p^T, p = 0..2, rb = 0..1 (six independent chains).
 // The sweeps run ONE wave per SIMD, so the A-operand reads of k block j + 1 are issued (inline asm, cm_common.h) BEFORE the 24 MFMAs of
 // block j: left to the compiler they followed them, and every block started with an exposed LDS round trip (~100 of its 770 cycles).
@@ -138,3 +162,60 @@ __device__ __forceinline__ void gru2_step(const G2W& w, const float* X0, float* 
     lds_barrier();                                  // h' (and the saved tiles) complete
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The step SPLIT at its dependence on h (round 6; cleanmarl/mappo_lstm_multienvs.py:170-176: x1 = relu(fc1(obs_t)) and gi = W_ih x1 + b_ih
+// do not depend on h_{t-1}, only gh = W_hh h_{t-1} does).  gru2_step runs fc1 + six 32 x 16 x 64 products = 6.7 k MFMA cycles per step on
+// the chain; four of those seven products are h-independent and the whole chunk's observations are known when the sweep starts.
+//   * gru2_pre_unit: x1 and the three W_ih products of ONE (tile, step) -- the first half of gru2_step, same MFMA sequences on the same
+//     operands, so the accumulators are the bits gru2_step would have held -- for a throughput launch over all (tile, step) units of the
+//     chunk on ALL compute units (k_gru2_pre).  The accumulators leave in lane order (one 16-byte store per lane and 16-row block: fully
+//     coalesced) and come back into the same lanes of the chain.
+//   * gru2_step_h: the rest of the step with those accumulators as inputs: three W_hh products + the gate math; ONE barrier per step
+//     (the caller's, at the top of its loop) instead of three, 3.07 k MFMA cycles instead of 6.9 k.
+// GI_UNIT floats per (tile, step): [wave 4][k = 2 gate + rb : 6][lane 64][4].
+constexpr int GI_UNIT = 4 * 6 * 64 * 4;
+__device__ __forceinline__ void gru2_pre_unit(const G2W& w, const float* X0, float* X1, float* gi_unit, int din) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int col = 16 * wave + n;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a1[2] = {zero, zero};
+    g2_prod1(a1, X0, w.w1, (din + 15) >> 4);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X1[(16 * rb + 4 * g + q) * LDT + col] = fmaxf(a1[rb][q] + w.b1, 0.0f);
+    lds_barrier();                                  // x1 complete
+    f32x4 xr[2] = {zero, zero}, xz[2] = {zero, zero}, xn[2] = {zero, zero};
+    g2_prod3(xr, xz, xn, X1, w.xr, w.xz, w.xn);
+    f32x4* out = reinterpret_cast<f32x4*>(gi_unit + (size_t)wave * (6 * 64 * 4)) + lane;
+    out[0] = xr[0]; out[64] = xr[1]; out[128] = xz[0]; out[192] = xz[1]; out[256] = xn[0]; out[320] = xn[1];
+}
+__device__ __forceinline__ void gru2_gi_load(f32x4 (&gi)[6], const float* gi_unit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4* in = reinterpret_cast<const f32x4*>(gi_unit + (size_t)wave * (6 * 64 * 4)) + lane;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gi[k] = in[64 * k];
+}
+// hp = h_{t-1} (complete: the caller's barrier), gi = this lane's W_ih accumulators of the step.  Writes hn = h' and, with SAVE, the tiles
+// the backward sweep needs; NO trailing barrier (the caller's next loop-top barrier completes them).
+template <bool SAVE>
+__device__ __forceinline__ void gru2_step_h(const G2W& w, const f32x4 (&gi)[6], const float* hp, float* hn,
+                                            float* SR, float* SZ, float* SN, float* SG, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int col = 16 * wave + n;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hr[2] = {zero, zero}, hz[2] = {zero, zero}, hnn[2] = {zero, zero};
+    g2_prod3(hr, hz, hnn, hp, w.hr, w.hz, w.hn);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = (16 * rb + 4 * g + q) * LDT + col;
+            const float r = sigmoidf_((gi[rb][q] + hr[rb][q]) + w.br);
+            const float z = sigmoidf_((gi[2 + rb][q] + hz[rb][q]) + w.bz);
+            const float ghn = hnn[rb][q] + w.bhn;
+            const float nn = tanhf_(gi[4 + rb][q] + w.bin + r * ghn);
+            hn[o] = (col < H) ? (1.0f - z) * nn + z * hp[o] : 0.0f;
+            if (SAVE) { SR[o] = r; SZ[o] = z; SN[o] = nn; SG[o] = ghn; }
+        }
+}

@@ -707,11 +707,13 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwd8(const GruArgs a) {
 // shares the device; a head workgroup gives up after a bounded number of polls and poisons its statistics with NaN.
 // Numerics: the arithmetic of k_gru2_fwd per item; the fc2 gradient / statistics are summed per head workgroup instead of per tile
 // (a different association of the same terms; everything else bit-identical).
-struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; unsigned long long* dhq; };  // dhq: [CL][R][64] {dh_t, tag} words (backward)
+struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; unsigned long long* dhq;  // dhq: [CL][R][64] {dh_t, tag} words (backward)
+                  float* gi; };  // [CL][nt][GI_UNIT] W_ih accumulators of k_gru2_pre (split forward sweep; NULL: the chain computes them itself)
 constexpr int GX_RED = 4 * 64 * 8 + 256;   // head workgroup's reduction scratch: half 1's fc2 accumulators (4 waves x 64 lanes x 8), b2 parts, statistics
 constexpr int g2fx_lds_floats(int KP) {
-    // chain workgroup: 9 tiles; head workgroup: per half HB + ls + ls2, shared wouts + b2 + red
-    return (9 * T32 * LDT > 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED) ? 9 * T32 * LDT : 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED;
+    // chain workgroup: 9 tiles (10 in the split form); head workgroup: per half HB + ls + ls2, shared wouts + b2 + red
+    // (split forward sweep: 10 tiles -- h_{t-1}, h_t and two sets of the four saved tiles)
+    return (10 * T32 * LDT > 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED) ? 10 * T32 * LDT : 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED;
 }
 inline size_t gru2_fwdx_lds_bytes(int KP) {
     const size_t b = (size_t)g2fx_lds_floats(KP) * sizeof(float);
@@ -974,7 +976,42 @@ __device__ __forceinline__ void gru2_head_wg(const GruArgs& a, const GruXArgs& x
     }
 }
 
-template <bool WV, int KP>
+// ---- the h-independent half of the forward sweep as a throughput launch over all (tile, step) units of the chunk (gru2_pre_unit,
+// cm_gru_step2.h): x1 = relu(fc1(obs_t)) goes to its workspace slot (what the chain's helper waves used to store), the three W_ih products
+// to x.gi.  Two workgroups per CU (17 KB of LDS, 64 weight registers): one's obs staging and stores under the other's products.
+template <bool WV>
+__global__ __launch_bounds__(NTHREADS, 2) void k_gru2_pre(const GruArgs a, const GruXArgs x) {
+    __shared__ __attribute__((aligned(16))) float X0[T32 * LDT];
+    __shared__ __attribute__((aligned(16))) float X1[T32 * LDT];
+    const GruOff off = gru_offsets(a.din, a.H, a.K);
+    const int tid = threadIdx.x, din = a.din, T = a.T, CL = a.t1 - a.t0;
+    const long R = (long)a.E * a.A;
+    const long units = (long)x.nt * CL;
+    G2W w;
+    g2_load_weights_x<WV>(w, a.params, off, din, a.H);
+    X32 xr;
+    long u = blockIdx.x;
+    if (u < units) x32_load(xr, a.obs + (long)(a.t0 + (int)(u / x.nt)) * din, (u % x.nt) * T32, R, (long)T * din, din);
+    for (; u < units; u += gridDim.x) {
+        const int s = (int)(u / x.nt);
+        const long row0 = (u % x.nt) * T32;
+        x32_store(X0, xr);  // (the previous unit's readers of X0 passed its "x1 complete" barrier; X1's pass the barrier below)
+        const long un = u + gridDim.x;
+        if (un < units) x32_load(xr, a.obs + (long)(a.t0 + (int)(un / x.nt)) * din, (un % x.nt) * T32, R, (long)T * din, din);
+        lds_barrier();
+        gru2_pre_unit(w, X0, X1, x.gi + (size_t)u * GI_UNIT, din);
+        float* wsS = a.ws_act + ((long)s * R + row0) * WS2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+            if (row0 + r < R) *reinterpret_cast<float4*>(wsS + (long)r * WS2 + c4) = *reinterpret_cast<const float4*>(X1 + r * LDT + c4);
+        }
+    }
+}
+
+// PRE: the split sweep -- fc1 and the W_ih products of every step come from k_gru2_pre (x.gi), the chain keeps W_hh h + gates: one barrier
+// per step, the saved tiles double-buffered so that the helper waves store step s - 1 while the recurrence writes step s.
+template <bool WV, int KP, bool PRE = false>
 __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXArgs x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CM_X_NOHEAD
@@ -982,6 +1019,84 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXAr
 #endif
     if ((int)blockIdx.x >= x.nt) { gru2_head_wg<KP>(a, x, smem); return; }
     const GruOff off = gru_offsets(a.din, a.H, a.K);
+    if constexpr (PRE) {
+        float* hp = smem; float* hn = smem + T32 * LDT;
+        float* S0 = smem + 2 * T32 * LDT;   // [2 sets][SR, SZ, SN, SG]
+        const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+        const int tid = threadIdx.x & (NTHREADS - 1), lane = tid & 63, wave = tid >> 6;
+        const int H = a.H, CL = a.t1 - a.t0;
+        const long R = (long)a.E * a.A;
+        const long row0 = (long)blockIdx.x * T32;
+        if (!helper) {
+            G2W w;
+            g2_load_weights_h<WV>(w, a.params, off, H);
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+            }
+            f32x4 gq[6];
+            gru2_gi_load(gq, x.gi + (size_t)blockIdx.x * GI_UNIT);
+            for (int s = 0; s <= CL; ++s) {
+                lds_barrier();  // hp = h_{t-1} complete (and the saved tiles of step s - 1)
+                if (s < CL) {
+                    f32x4 gc[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) gc[k] = gq[k];
+                    if (s + 1 < CL) gru2_gi_load(gq, x.gi + ((size_t)(s + 1) * x.nt + blockIdx.x) * GI_UNIT);  // a step ahead
+                    float* S = S0 + (s & 1) * 4 * T32 * LDT;
+                    gru2_step_h<true>(w, gc, hp, hn, S, S + T32 * LDT, S + 2 * T32 * LDT, S + 3 * T32 * LDT, H);
+                    float* tmp = hp; hp = hn; hn = tmp;
+                } else if (a.h_out) {
+                    for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                        const int r = i >> 6, c = i & 63;
+                        if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+                    }
+                }
+            }
+        } else {
+            unsigned long long* fl = x.flags + (size_t)blockIdx.x * 4 + wave;
+            for (int s = 0; s <= CL; ++s) {
+                const int sp = s - 1;
+                lds_barrier();
+                if (sp >= 0) {  // the tiles of step sp leave during step s; h' first (the head workgroups wait for it), then publish
+                    float* wsS = a.ws_act + ((long)sp * R + row0) * WS2;
+                    const float* S = S0 + (sp & 1) * 4 * T32 * LDT;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < R) {
+                            const float4 hv = *reinterpret_cast<const float4*>(hp + r * LDT + c4);
+                            float* wp = wsS + (long)r * WS2 + 5 * HP + c4;
+                            st_agent64(wp, hv.x, hv.y);
+                            st_agent64(wp + 2, hv.z, hv.w);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(fl, ((unsigned long long)x.tag << 32) | (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < R) {
+                            float* wp = wsS + (long)r * WS2 + c4;
+                            const int o = r * LDT + c4;
+                            *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(S + o);
+                            *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(S + T32 * LDT + o);
+                            *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(S + 2 * T32 * LDT + o);
+                            *reinterpret_cast<float4*>(wp + 4 * HP) = *reinterpret_cast<const float4*>(S + 3 * T32 * LDT + o);
+                        }
+                    }
+                }
+                if (s < CL) { float* tmp = hp; hp = hn; hn = tmp; }
+            }
+        }
+        if ((int)blockIdx.x >= x.nh) {
+            float* out = a.partial + (size_t)blockIdx.x * a.PS;
+            for (int i = threadIdx.x; i < a.K * H; i += NT8) out[off.W2 + i] = 0.0f;
+            if (threadIdx.x < a.K) out[off.b2 + threadIdx.x] = 0.0f;
+            if (threadIdx.x < CM_NUM_STATS) out[off.P + threadIdx.x] = 0.0f;
+        }
+        return;
+    }
     float* p = smem;
     float* X0 = p; p += T32 * LDT;    // obs tile of the step
     float* X1a = p; p += T32 * LDT;   // x1 = relu(fc1(obs)), even steps
