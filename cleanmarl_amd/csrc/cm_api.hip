@@ -21,7 +21,7 @@ namespace {
 struct OptDef { const char* key; const char* const* names; const int* values; int n; };
 const char* const kFormsN[] = {"auto", "hand", "loop"};          const int kFormsV[] = {0, 1, 2};
 const char* const kCriticN[] = {"auto", "fused", "split"};       const int kCriticV[] = {0, 1, 2};
-const char* const kGruN[] = {"auto", "64", "32", "8w", "nopre"}; const int kGruV[] = {0, 64, 32, 8, 1};
+const char* const kGruN[] = {"auto", "64", "32", "8w", "split"}; const int kGruV[] = {0, 64, 32, 8, 1};
 const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRollV[] = {0, 64, 16, 17, 65};
 const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};
 const char* const kWideN[] = {"auto", "fused", "layered", "fused_r3"}; const int kWideV[] = {0, 1, 2, 3};

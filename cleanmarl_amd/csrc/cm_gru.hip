@@ -1182,9 +1182,13 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         // ... and, while the tiles leave a third of the CUs idle, the head on those CUs (k_gru2_fwdx: one head workgroup per two tiles)
         const int tile_opt = cm_option(CM_OPTION_GRU_TILE);
         const int nh = (int)((nt32 + 1) / 2);
-        // gru_tile = "nopre": the pipelined sweeps of round 5 (the chain computes fc1 and the W_ih products itself) for A/B runs
+        // gru_tile = "split" (opt-in, round 6): the pipelined forward sweep split at its dependence on h -- fc1 and the W_ih products of the
+        // whole chunk as one throughput launch (k_gru2_pre), the chain on W_hh h + gates with one barrier per step.  Bit-identical, and
+        // SLOWER at config 5 (profiles/r06_gru_split_ab.txt: k_gru2_pre 23.6 us + chain launch 51 us against 66 us unsplit -- the chain's
+        // ten steps take 26 us instead of 45, but the launch ends with the head workgroups, 80 of them serving 160 tiles, and the
+        // throughput launch costs more than the chain saves): not the default
         const bool pipelined = (tile_opt == 0 || tile_opt == 1) && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
-        const bool split_fwd = pipelined && tile_opt == 0;
+        const bool split_fwd = pipelined && tile_opt == 1;
         GruXArgs xa = {};
         xa.nt = (int)nt32; xa.nh = nh;
         {

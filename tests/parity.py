@@ -35,6 +35,14 @@ TOL = 1e-4       # BASELINE.json north_star: returns / advantages / losses withi
 GRAD_TOL = 1e-4  # gradients, relative to max|reference gradient|
 DISP_TOL = 1e-3  # optimiser-step displacement, relative to max|reference displacement|
 COND = 1e-2      # end-to-end displacement is compared where |g_ref_i| >= COND * max|g_ref| (see above)
+# Full-size gradients (10^5 .. 10^6 rows per sum).  A hidden unit whose pre-activation lies within fp32 rounding of relu's kink for some row
+# is on or off depending on the summation order of the matmul that produced it; that one row's term then enters or leaves the gradient.
+# Expected count at config 3: 6.7e7 (row, unit) pairs of the critic x 4e-8 = 2 .. 3 per pass; one row's term is ~ 1e-4 of the largest entry
+# of the critic's mean gradient (MSE against returns of magnitude 10).  Measured (tools/debug/grad_outliers.py, profiles/r06_gputests.txt):
+# on a config-4 shard the fp32 CPU oracle is 1.7e-4 from its own fp64 evaluation where the HIP pass is 1.6e-7 from it; on another it is the
+# fp64 evaluation that stands 3.2e-4 apart from the two fp32 ones.  So at full size a gradient is held to the NEARER of the two evaluations of
+# the reference's expression (fp32 as the reference computes it, fp64 as its value) at KINK_GRAD_TOL = 2 x GRAD_TOL.
+KINK_GRAD_TOL = 2e-4
 
 OBSERVED = {}    # (metric, label) -> [max observed, number of comparisons]
 
@@ -179,6 +187,14 @@ def golden_before(z, net, step):
     return golden_init(z, net) if step == 0 else np.asarray(z[f"{net}_after"][step - 1], dtype=np.float64)
 
 
+def check_grads_kink(a, ref32, ref64, label=""):
+    """Full-size gradient against the nearer of the fp32 and the fp64 evaluation of the oracle (KINK_GRAD_TOL above); also records how far
+    the two evaluations are from each other."""
+    grad_err(ref32, ref64, label + ": the fp32 oracle's own distance from its fp64 evaluation")
+    e32, e64 = grad_err(a, ref32, label + " vs the fp32 oracle"), grad_err(a, ref64, label + " vs the oracle evaluated in fp64")
+    assert min(e32, e64) <= KINK_GRAD_TOL, (label, e32, e64)
+
+
 def check_grads(a, b, label="", tol=GRAD_TOL):
     v = grad_err(a, b, label)
     assert v <= tol, (label, v)
@@ -195,6 +211,7 @@ def check_step(after, ref_after, before, label="", tol=TOL, ref_grad=None):
 def report(path):
     lines = ["# observed maxima of the parity metrics (tests/parity.py): metric, label, max observed, comparisons, bar"]
     bars = {"err": TOL, "grad_err": GRAD_TOL, "disp_err": DISP_TOL, "twin_err": DISP_TOL, "conditioned_fraction": 1.0}
+    lines.append("# (grad_err rows labelled 'full-size ...': the assertion is min(vs fp32 oracle, vs fp64 evaluation) <= KINK_GRAD_TOL = 2e-4, see tests/parity.py)")
     lines.append("# (labels containing 'deliberately wrong' belong to the tests that check that a wrong learner FAILS; conditioned_fraction = largest")
     lines.append("#  fraction of entries excluded from an end-to-end displacement comparison as ill-conditioned, |g_ref| < COND max|g_ref|)")
     for (metric, label), (v, n) in sorted(OBSERVED.items()):
