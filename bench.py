@@ -161,9 +161,16 @@ class Workload:
         L = self.learner
         if self.actor_kind != "mlp" or self.E == 0:
             return None
-        b = self.roll.collect(L.actor, self.aspec)
-        L.compute_targets(b)
+        # the rollout and the value pass + scan alone as well (phase_roofline: inside the timed iterations the critic's last epoch is still
+        # running beside the next rollout, so their in-iteration event times are co-residency figures too)
         torch.cuda.synchronize()
+        ro, vp = [], []
+        for _ in range(3):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(); b = self.roll.collect(L.actor, self.aspec); e1.record(); L.compute_targets(b); e2.record()
+            torch.cuda.synchronize()
+            ro.append(e0.elapsed_time(e1)); vp.append(e1.elapsed_time(e2))
+        self.solo_rollout_ms, self.solo_value_pass_ms = min(ro), min(vp)
         s = N.stream_ptr()
         for _ in range(warm):
             L.actor_pass(b, s)
@@ -461,6 +468,10 @@ def main():
                        "allreduce": args.allreduce if world > 1 else "none (one rank: the optimiser step rides on the pass's reduction launch)"},
             "ppo_update_ms": r["phase_ms"]["update"], "ppo_update_ms_per_epoch": r["phase_ms"]["update"] / hp.epochs,
             "phase_ms": r["phase_ms"],
+            "phase_solo_ms": {"rollout": getattr(w, "solo_rollout_ms", None), "value_pass_scan": getattr(w, "solo_value_pass_ms", None),
+                              "actor_fwd_bwd": solo[0] if solo else None, "critic_fwd_bwd": getattr(w, "solo_critic_ms", None),
+                              "note": "each phase alone on the device (solo leg after the timed region); phase_ms / kernel_ms are event times inside the "
+                                      "timed iterations, where the critic's epochs run beside the actor's passes and the next rollout"},
             "kernel_ms": {"actor_fwd_bwd": r["actor_ms"], "critic_fwd_bwd": r["critic_ms"]},
             "roofline": {"kernel": "k_mlp<NCH,M_ACTOR> (cm_ppo_actor_fwd_bwd)" if w.actor_kind == "mlp" else
                          "k_gru_chunk_fwd + k_gru_chunk_bwd (all TBPTT chunks of one epoch)", "bound": "mfma", "achieved": achieved,
@@ -471,8 +482,8 @@ def main():
                                     "stream (min %.4f max %.4f ms); inside the timed iterations the critic's epochs run beside it (in_iteration_launch_ms)"
                                     % (min(solo[1]), max(solo[1]))) if solo else "HIP events around the launches inside the timed iterations"},
             # the other phases of the step against their own bounds (algorithmic work of SURVEY.md §8(d) / event time)
-            "phase_roofline": {"rollout": _bound(wk["rollout"], r["phase_ms"]["rollout"]),
-                               "value_pass_scan": _bound(wk["value_pass"], r["phase_ms"]["value_pass_scan"]),
+            "phase_roofline": {"rollout": _bound(wk["rollout"], getattr(w, "solo_rollout_ms", None) or r["phase_ms"]["rollout"]),
+                               "value_pass_scan": _bound(wk["value_pass"], getattr(w, "solo_value_pass_ms", None) or r["phase_ms"]["value_pass_scan"]),
                                "critic_fwd_bwd": _bound(wk["critic"], getattr(w, "solo_critic_ms", None) or r["critic_ms"]),
                                "whole_step": _bound(dict(flop=wk["rollout"]["flop"] + wk["value_pass"]["flop"] + hp.epochs * (wk["actor"]["flop"] + wk["critic"]["flop"]),
                                                          bytes=wk["rollout"]["bytes"] + wk["value_pass"]["bytes"] + hp.epochs * (wk["actor"]["bytes"] + wk["critic"]["bytes"])),

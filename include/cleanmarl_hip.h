@@ -60,7 +60,8 @@ int cm_version(void);  /* 101 since round 5 (cm_opt_step_t grew by stats_out; cm
  * process environment.  Options are process-wide, take effect at the next launch and may be changed at any time
  * (value "auto" / the first value listed is the default):
  *   "mlp_forms"        auto | hand | loop      hand-ordered vs compiler-scheduled LDS reads of the fused MLP product loops
- *   "critic_schedule"  auto | fused | split    one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule
+ *   "critic_schedule"  auto | fused | split | fused1   one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule;
+ *                                              fused1: the one-pass kernel with one row tile per iteration where "fused" takes two (two-chunk inputs)
  *   "gru_tile"         auto | 64 | 32 | 8w | split   auto: pipelined 32-row sweeps while tiles + helper workgroups fit the CUs (head / weight gradients
  *                                              on the idle CUs), eight-wave 32-row forward above, 64-row streaming sweeps from 512 64-row tiles;
  *                                              32: four-wave 32-row sweeps, 8w: eight-wave forward, 64: the 64-row sweeps at any batch size;
