@@ -20,7 +20,7 @@ extern "C" int cm_version(void) { return 101; }  // 101: cm_opt_step_t::stats_ou
 namespace {
 struct OptDef { const char* key; const char* const* names; const int* values; int n; };
 const char* const kFormsN[] = {"auto", "hand", "loop"};          const int kFormsV[] = {0, 1, 2};
-const char* const kCriticN[] = {"auto", "fused", "split", "fused1"}; const int kCriticV[] = {0, 1, 2, 3};
+const char* const kCriticN[] = {"auto", "fused", "split", "fused2"}; const int kCriticV[] = {0, 1, 2, 3};
 const char* const kGruN[] = {"auto", "64", "32", "8w", "split"}; const int kGruV[] = {0, 64, 32, 8, 1};
 const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRollV[] = {0, 64, 16, 17, 65};
 const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};

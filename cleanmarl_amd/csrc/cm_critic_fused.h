@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
     }
 }
 
-// ---- TWO row tiles per iteration (round 6; NC <= 2: 2 x (NC + 2) tiles of LDS = 139 KB at NC = 2 -- config 4's per-agent critic on 115-wide
+// ---- TWO row tiles per iteration (round 6, OPT-IN: critic_schedule = "fused2" -- measured 5 % slower than the kernel above at config 4; NC <= 2: 2 x (NC + 2) tiles of LDS = 139 KB at NC = 2 -- config 4's per-agent critic on 115-wide
 // observations).  The kernel above runs ONE wave per SIMD: nothing hides the latency of its five short phases (h0 -> LDS, hidden layer +
 // value, loss, dZ1 -> LDS, dW1 / dH0 + dZ0 -> LDS: 12 k of the ~22 k cycles of a two-chunk tile for 6 k cycles of MFMA issue) except more
 // independent work between the same barriers.  Two workgroups per CU do not fit the register file (300 registers: measured with spills,
@@ -764,10 +764,10 @@ inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t w
 #endif
     const int nc = (a.din + KC - 1) / KC;
     const long ntiles = (a.rows + TM - 1) / TM;
-    // two-chunk inputs with at least four tiles per CU: two row tiles per iteration (k_critic_fused2).  critic_schedule = "fused" takes it
-    // at any size (tests), "fused1" keeps the one-tile kernel (A/B runs)
-    const int sched_ = cm_option(CM_OPTION_CRITIC_SCHEDULE);
-    if (nc == 2 && sched_ != 3 && ntiles >= (sched_ == 1 ? 2L : 4L * 256)) {
+    // critic_schedule = "fused2" (opt-in, round 6): two row tiles per iteration for two-chunk inputs (k_critic_fused2).  Measured at config 4
+    // (5.2 M rows x 115 columns, profiles/r06_critic_two_tile_ab.txt): 3.08 ms against 2.93 ms for the one-tile kernel -- half the barriers per
+    // row, but 410 registers (values shuttled between the two register files, 86 spilled scalars) and sequential hand-issued pipelines: not the default
+    if (nc == 2 && cm_option(CM_OPTION_CRITIC_SCHEDULE) == 3 && ntiles >= 2) {
         const long npairs = (ntiles + 1) / 2;
         const int grid2 = (int)(npairs < 256 ? npairs : 256);
         const size_t lds2 = critic_fused2_lds_bytes(nc);

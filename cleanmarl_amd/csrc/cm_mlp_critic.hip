@@ -35,7 +35,7 @@ static int critic_pass(const float* x, int64_t x_ld, const float* ret, const int
     // of LDS), so a small batch neither amortises its per-workgroup prologue / partial-gradient row nor shares CUs with the rollout
     // it is overlapped with (learner.overlap_critic).  cm_set_option("critic_schedule", "fused" / "split") forces either schedule (A/B runs, tests).
     const int sched = cm_option(CM_OPTION_CRITIC_SCHEDULE);
-    const bool force_fused = sched == 1 || sched == 3, force_split = sched == 2;  // 3 = "fused1": the one-pass kernel with one row tile per iteration
+    const bool force_fused = sched == 1 || sched == 3, force_split = sched == 2;  // 3 = "fused2": the one-pass kernel with two row tiles per iteration where the shape allows (opt-in)
     if (critic_fused_shape(a) && !force_split && (force_fused || a.rows >= CM_FUSED_MIN_ROWS))
         return run_critic_fused(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd", opt);
     return run_train<M_CRITIC>(a, grad_and_stats, ws, ws_bytes, (hipStream_t)stream, "cm_critic_fwd_bwd", opt);

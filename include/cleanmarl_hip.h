@@ -60,8 +60,9 @@ int cm_version(void);  /* 101 since round 5 (cm_opt_step_t grew by stats_out; cm
  * process environment.  Options are process-wide, take effect at the next launch and may be changed at any time
  * (value "auto" / the first value listed is the default):
  *   "mlp_forms"        auto | hand | loop      hand-ordered vs compiler-scheduled LDS reads of the fused MLP product loops
- *   "critic_schedule"  auto | fused | split | fused1   one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule;
- *                                              fused1: the one-pass kernel with one row tile per iteration where "fused" takes two (two-chunk inputs)
+ *   "critic_schedule"  auto | fused | split | fused2   one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule;
+ *                                              fused2: the one-pass kernel with TWO row tiles per iteration for two-chunk inputs (opt-in: measured
+ *                                              5 % slower than "fused" at config 4; same sums up to the association of a workgroup's tiles)
  *   "gru_tile"         auto | 64 | 32 | 8w | split   auto: pipelined 32-row sweeps while tiles + helper workgroups fit the CUs (head / weight gradients
  *                                              on the idle CUs), eight-wave 32-row forward above, 64-row streaming sweeps from 512 64-row tiles;
  *                                              32: four-wave 32-row sweeps, 8w: eight-wave forward, 64: the 64-row sweeps at any batch size;

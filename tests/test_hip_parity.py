@@ -1437,7 +1437,7 @@ def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeyp
         ep_len = torch.from_numpy(rng.integers(1, T + 1, size=E).astype(np.int32)).to(dev)
         ws = torch.empty(lib.cm_critic_workspace_bytes(E, A, T, per_agent, din, H, 1), dtype=torch.uint8, device=dev)
         out = {}
-        for sched in ("fused", "split", "fused1"):  # fused: two row tiles per iteration for two-chunk inputs (k_critic_fused2), fused1: always one
+        for sched in ("fused", "split", "fused2"):  # fused2: two row tiles per iteration for two-chunk inputs (k_critic_fused2, opt-in)
             N.set_option("critic_schedule", sched)
             g = torch.full((spec.nparams + N.NUM_STATS,), float("nan"), device=dev)
             N.check(lib.cm_critic_fwd_bwd_ld(N.ptr(x), ld, N.ptr(ret), N.ptr(ep_len), E, A, T, per_agent, din, H, 1, N.ptr(p), N.ptr(g),
@@ -1447,15 +1447,15 @@ def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeyp
         assert np.isfinite(out["fused"]).all(), (case, din, H, A, T, E, per_agent)
         scale = 1.0 + np.abs(out["split"]).max()
         assert np.abs(out["fused"] - out["split"]).max() <= TOL * scale, (case, din, ld, H, A, T, E, per_agent)
-        assert np.abs(out["fused"] - out["fused1"]).max() <= 1e-5 * scale, (case, din, ld, H, A, T, E, per_agent)
+        assert np.abs(out["fused"] - out["fused2"]).max() <= 1e-5 * scale, (case, din, ld, H, A, T, E, per_agent)
         if nc != 2:
-            assert np.array_equal(out["fused"], out["fused1"])  # only two-chunk inputs have a two-tile form
+            assert np.array_equal(out["fused"], out["fused2"])  # only two-chunk inputs have a two-tile form
 
 
 @pytest.mark.parametrize("per_agent", [0, 1])
 @pytest.mark.parametrize("rows_e,T", [(2, 64), (3, 64), (5, 40), (33, 31), (1030, 64), (2049, 33)])
 def test_two_tile_critic_equals_the_one_tile_kernel(rows_e, T, per_agent):
-    """k_critic_fused2 (two row tiles per iteration, two-chunk inputs: config 4's per-agent critic on 115-wide observations) against
+    """k_critic_fused2 (critic_schedule = "fused2", opt-in: two row tiles per iteration, two-chunk inputs -- config 4's per-agent critic on 115-wide observations) against
     k_critic_fused on tile counts that are even, odd (the last pair's second tile lies past the end), partial, fewer and more than two per
     workgroup: the same sums up to the association of a workgroup's tiles (1e-5 of the buffer's scale), equal N, two launches bit-identical."""
     from cleanmarl_amd import _native as N
@@ -1475,7 +1475,7 @@ def test_two_tile_critic_equals_the_one_tile_kernel(rows_e, T, per_agent):
     ws = torch.empty(lib.cm_critic_workspace_bytes(E, A, T, per_agent, din, H, 1), dtype=torch.uint8, device=dev)
     out = {}
     try:
-        for sched in ("fused", "fused", "fused1"):
+        for sched in ("fused2", "fused2", "fused"):
             N.set_option("critic_schedule", sched)
             g = torch.full((spec.nparams + N.NUM_STATS,), float("nan"), device=dev)
             N.check(lib.cm_critic_fwd_bwd_ld(N.ptr(x), ld, N.ptr(ret), N.ptr(ep_len), E, A, T, per_agent, din, H, 1, N.ptr(p), N.ptr(g),
@@ -1484,7 +1484,7 @@ def test_two_tile_critic_equals_the_one_tile_kernel(rows_e, T, per_agent):
             out.setdefault(sched, []).append(g.cpu().numpy())
     finally:
         N.set_option("critic_schedule", "auto")
-    two, again, one = out["fused"][0], out["fused"][1], out["fused1"][0]
+    two, again, one = out["fused2"][0], out["fused2"][1], out["fused"][0]
     assert np.isfinite(two).all() and np.array_equal(two, again)
     P = spec.nparams
     assert two[P + N.STAT_COUNT] == one[P + N.STAT_COUNT] == float(ep_len.sum())
