@@ -21,7 +21,7 @@ namespace {
 struct OptDef { const char* key; const char* const* names; const int* values; int n; };
 const char* const kFormsN[] = {"auto", "hand", "loop"};          const int kFormsV[] = {0, 1, 2};
 const char* const kCriticN[] = {"auto", "fused", "split", "fused2"}; const int kCriticV[] = {0, 1, 2, 3};
-const char* const kGruN[] = {"auto", "64", "32", "8w", "split"}; const int kGruV[] = {0, 64, 32, 8, 1};
+const char* const kGruN[] = {"auto", "64", "32", "8w", "split", "nosplit"}; const int kGruV[] = {0, 64, 32, 8, 1, 2};
 const char* const kRollN[] = {"auto", "64", "16", "16s", "64s"}; const int kRollV[] = {0, 64, 16, 17, 65};
 const char* const kMfmaN[] = {"fp32", "bf16x3", "bf16"};         const int kMfmaV[] = {0, 1, 2};
 const char* const kWideN[] = {"auto", "fused", "layered", "fused_r3"}; const int kWideV[] = {0, 1, 2, 3};
@@ -29,7 +29,7 @@ const char* const kDw0N[] = {"auto", "8", "4"};                  const int kDw0V
 const char* const kGridN[] = {"auto", "512", "384", "256", "192", "128", "64"}; const int kGridV[] = {0, 512, 384, 256, 192, 128, 64};
 const char* const kSplitN[] = {"auto", "50", "52", "53", "54", "55", "56", "57", "58", "60"}; const int kSplitV[] = {0, 50, 52, 53, 54, 55, 56, 57, 58, 60};
 const OptDef kOpts[CM_OPTION_COUNT] = {
-    {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 4}, {"gru_tile", kGruN, kGruV, 5},
+    {"mlp_forms", kFormsN, kFormsV, 3}, {"critic_schedule", kCriticN, kCriticV, 4}, {"gru_tile", kGruN, kGruV, 6},
     {"rollout_tile", kRollN, kRollV, 5}, {"mfma", kMfmaN, kMfmaV, 3}, {"wide_schedule", kWideN, kWideV, 4},
     {"dw0_batch", kDw0N, kDw0V, 3}, {"dw0_grid", kGridN, kGridV, 7}, {"train_grid", kGridN, kGridV, 7},
     {"tile_split", kSplitN, kSplitV, 10}};

@@ -1187,8 +1187,9 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
         // SLOWER at config 5 (profiles/r06_gru_split_ab.txt: k_gru2_pre 23.6 us + chain launch 51 us against 66 us unsplit -- the chain's
         // ten steps take 26 us instead of 45, but the launch ends with the head workgroups, 80 of them serving 160 tiles, and the
         // throughput launch costs more than the chain saves): not the default
-        const bool pipelined = (tile_opt == 0 || tile_opt == 1) && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
-        const bool split_fwd = pipelined && tile_opt == 1;
+        // gru_tile = "nosplit": the unsplit pipelined sweeps of round 5 (A/B runs); auto: split inside the workgroup (k_gru2_fwdx<.., 2>)
+        const bool pipelined = (tile_opt == 0 || tile_opt == 1 || tile_opt == 2) && nt32 <= MAX_GRID && nt32 + nh <= gru_device_cus();
+        const bool split_fwd = pipelined && tile_opt == 1, split_in_wg = pipelined && tile_opt == 0;
         GruXArgs xa = {};
         xa.nt = (int)nt32; xa.nh = nh;
         {
@@ -1203,8 +1204,12 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #define CM_GRU2_FXP(WV_, KP_) do { \
         const long units_ = nt32 * CL; const int cus2_ = 2 * gru_device_cus(); \
         hipLaunchKernelGGL((k_gru2_pre<WV_>), dim3((unsigned)(units_ < cus2_ ? units_ : cus2_)), dim3(NTHREADS), 0, (hipStream_t)stream, a, xa); \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
-        hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_, true>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
+        hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_, 1>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
+        // the same split inside the workgroup (helper waves run the h-independent half a step ahead): no extra launch
+#define CM_GRU2_FXI(WV_, KP_) do { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru2_fwdx<WV_, KP_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx); \
+        hipLaunchKernelGGL((k_gru2_fwdx<WV_, KP_, 2>), dim3(grid32 + nh), dim3(NT8), lfx, (hipStream_t)stream, a, xa); } while (0)
         if (tile_opt == 32) {
             if (KP == 16) { if (wv) CM_GRU2_F(true, 16); else CM_GRU2_F(false, 16); }
             else          { if (wv) CM_GRU2_F(true, 32); else CM_GRU2_F(false, 32); }
@@ -1216,6 +1221,10 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
             }
             if (KP == 16) { if (wv) CM_GRU2_FXP(true, 16); else CM_GRU2_FXP(false, 16); }
             else          { if (wv) CM_GRU2_FXP(true, 32); else CM_GRU2_FXP(false, 32); }
+        } else if (split_in_wg) {
+            xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
+            if (KP == 16) { if (wv) CM_GRU2_FXI(true, 16); else CM_GRU2_FXI(false, 16); }
+            else          { if (wv) CM_GRU2_FXI(true, 32); else CM_GRU2_FXI(false, 32); }
         } else if (pipelined) {
             xa.tag = g_gru_tag.fetch_add(1, std::memory_order_relaxed);
             if (KP == 16) { if (wv) CM_GRU2_FX(true, 16); else CM_GRU2_FX(false, 16); }
@@ -1227,6 +1236,7 @@ static int gru_chunk_pass(const float* obs, const uint8_t* avail, const int32_t*
 #undef CM_GRU2_F8
 #undef CM_GRU2_FX
 #undef CM_GRU2_FXP
+#undef CM_GRU2_FXI
 #undef CM_GRU2_F
         // backward: likewise, five of the seven weight-gradient products of a step on the idle CUs (k_gru2_bwd<true> / gru2_grad_wg: as many
         // workgroups as CUs are left, at most one per tile; their partial rows follow those of the tiles)

@@ -712,8 +712,8 @@ struct GruXArgs { unsigned long long* flags; unsigned tag; int nt, nh; unsigned 
 constexpr int GX_RED = 4 * 64 * 8 + 256;   // head workgroup's reduction scratch: half 1's fc2 accumulators (4 waves x 64 lanes x 8), b2 parts, statistics
 constexpr int g2fx_lds_floats(int KP) {
     // chain workgroup: 9 tiles (10 in the split form); head workgroup: per half HB + ls + ls2, shared wouts + b2 + red
-    // (split forward sweep: 10 tiles -- h_{t-1}, h_t and two sets of the four saved tiles)
-    return (10 * T32 * LDT > 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED) ? 10 * T32 * LDT : 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED;
+    // (split forward sweep, in the workgroup: 8 tiles + 24 KB of W_ih accumulators; as a pre-pass launch: 10 tiles)
+    return (8 * T32 * LDT + GI_UNIT > 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED) ? 8 * T32 * LDT + GI_UNIT : 2 * (TM * LDT + 2 * TM * KP) + KP * WLD + KMAX + GX_RED;
 }
 inline size_t gru2_fwdx_lds_bytes(int KP) {
     const size_t b = (size_t)g2fx_lds_floats(KP) * sizeof(float);
@@ -1011,7 +1011,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_gru2_pre(const GruArgs a, const
 
 // PRE: the split sweep -- fc1 and the W_ih products of every step come from k_gru2_pre (x.gi), the chain keeps W_hh h + gates: one barrier
 // per step, the saved tiles double-buffered so that the helper waves store step s - 1 while the recurrence writes step s.
-template <bool WV, int KP, bool PRE = false>
+// PRE == 2 (round 6, the default): the same split INSIDE the workgroup -- waves 4-7, which only stored finished tiles so far, run the
+// h-independent half of step s + 1 (fc1, then the three W_ih products) while waves 0-3 run the h-dependent half of step s, handed over through
+// 24 KB of LDS in lane order.  Two barriers per step, arranged so that the two halves want different pipes at the same time:
+//     interval A:  recurrence: W_hh h_{t-1} (96 MFMAs)        | helpers: tiles of step s - 1 -> workspace, publish; fc1 of step s + 1 (24 MFMAs)
+//     interval B:  recurrence: gate math (VALU), h', tiles     | helpers: W_ih x1 of step s + 1 (96 MFMAs) -> LDS, x1 -> workspace, next obs tile
+// No extra launch, no extra workgroup role; the MFMA sequences and operands are those of gru2_step: bit-identical results.
+template <bool WV, int KP, int PRE = 0>
 __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXArgs x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef CM_X_NOHEAD
@@ -1019,7 +1025,169 @@ __global__ __launch_bounds__(NT8) void k_gru2_fwdx(const GruArgs a, const GruXAr
 #endif
     if ((int)blockIdx.x >= x.nt) { gru2_head_wg<KP>(a, x, smem); return; }
     const GruOff off = gru_offsets(a.din, a.H, a.K);
-    if constexpr (PRE) {
+    if constexpr (PRE == 2) {
+        float* hp = smem; float* hn = smem + T32 * LDT;
+        float* S = smem + 2 * T32 * LDT;    // SR, SZ, SN, SG
+        float* X0 = smem + 6 * T32 * LDT;   // obs tile of the step the helpers work on
+        float* X1 = smem + 7 * T32 * LDT;   // its x1
+        float* GI = smem + 8 * T32 * LDT;   // [4 waves][6][64 lanes][4]: the W_ih accumulators of the next step, lane order
+        const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+        const int tid = threadIdx.x & (NTHREADS - 1), lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+        const int H = a.H, din = a.din, T = a.T, CL = a.t1 - a.t0;
+        const long R = (long)a.E * a.A;
+        const long row0 = (long)blockIdx.x * T32;
+        f32x4* gil = reinterpret_cast<f32x4*>(GI + wave * (6 * 64 * 4)) + lane;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        PH_DECL
+        if (!helper) {
+            G2W w;
+            g2_load_weights_h<WV>(w, a.params, off, H);
+            for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                const int r = i >> 6, c = i & 63;
+                hp[r * LDT + c] = (row0 + r < R && c < H && a.h_in) ? a.h_in[(row0 + r) * H + c] : 0.0f;
+            }
+            lds_barrier(); lds_barrier();   // the helpers' prologue: x1 and the W_ih products of step 0
+            for (int s = 0; s <= CL; ++s) {
+                lds_barrier();              // top: h_{t-1}, the tiles of step s - 1 and GI(s) are complete
+                PH(0);
+                f32x4 hr[2] = {zero, zero}, hz[2] = {zero, zero}, hnn[2] = {zero, zero};
+                f32x4 gi[6];
+                if (s < CL) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) gi[k] = gil[64 * k];
+                    g2_prod3(hr, hz, hnn, hp, w.hr, w.hz, w.hn);
+                }
+                PH(1);
+                lds_barrier();              // mid: GI is read, the helpers are done with the tiles of step s - 1
+                PH(2);
+                if (s < CL) {
+                    const int col = 16 * wave + n;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int o = (16 * rb + 4 * g + q) * LDT + col;
+                            const float r = sigmoidf_((gi[rb][q] + hr[rb][q]) + w.br);
+                            const float z = sigmoidf_((gi[2 + rb][q] + hz[rb][q]) + w.bz);
+                            const float ghn = hnn[rb][q] + w.bhn;
+                            const float nn = tanhf_(gi[4 + rb][q] + w.bin + r * ghn);
+                            hn[o] = (col < H) ? (1.0f - z) * nn + z * hp[o] : 0.0f;
+                            S[o] = r; S[T32 * LDT + o] = z; S[2 * T32 * LDT + o] = nn; S[3 * T32 * LDT + o] = ghn;
+                        }
+                    float* tmp = hp; hp = hn; hn = tmp;
+                } else if (a.h_out) {
+                    for (int i = tid; i < T32 * HP; i += NTHREADS) {
+                        const int r = i >> 6, c = i & 63;
+                        if (row0 + r < R && c < H) a.h_out[(row0 + r) * H + c] = hp[r * LDT + c];
+                    }
+                }
+                PH(3);
+            }
+        } else {
+            // ---- helpers: the h-independent half, one step ahead; their own obs staging (x32_* of the recurrence waves, same row mapping)
+            float w1[16], wxr[16], wxz[16], wxn[16];
+            const int c0 = 16 * wave, col = c0 + n;
+            load_nt16_regs<false>(w1, a.params + off.W1, c0, H, din, din);
+            load_nt16_regs<WV>(wxr, a.params + off.Wih, c0, H, H, H);
+            load_nt16_regs<WV>(wxz, a.params + off.Wih + H * H, c0, H, H, H);
+            load_nt16_regs<WV>(wxn, a.params + off.Wih + 2 * H * H, c0, H, H, H);
+            const float b1 = (col < H) ? a.params[off.b1 + col] : 0.0f;
+            const int r0 = wave * 8;
+            auto obs_load = [&](X32& xx, int t) {
+                const float* p = a.obs + (long)t * din + (row0 + r0) * ((long)T * din) + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xx.v[i] = (row0 + r0 + i < R && lane < din) ? p[i * ((long)T * din)] : 0.0f;
+            };
+            auto obs_store = [&](const X32& xx) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) X0[(r0 + i) * LDT + lane] = xx.v[i];
+            };
+            auto half_a = [&]() {   // x1 = relu(fc1(obs)) of the step whose obs tile is in X0
+                f32x4 a1[2] = {zero, zero};
+                g2_prod1(a1, X0, w1, (din + 15) >> 4);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) X1[(16 * rb + 4 * g + q) * LDT + col] = fmaxf(a1[rb][q] + b1, 0.0f);
+            };
+            auto half_b = [&](int st) {   // the three W_ih products of step st -> GI (lane order); x1 -> its workspace slot
+                f32x4 xr[2] = {zero, zero}, xz[2] = {zero, zero}, xn[2] = {zero, zero};
+                g2_prod3(xr, xz, xn, X1, wxr, wxz, wxn);
+                gil[0] = xr[0]; gil[64] = xr[1]; gil[128] = xz[0]; gil[192] = xz[1]; gil[256] = xn[0]; gil[320] = xn[1];
+                float* wsS = a.ws_act + ((long)st * R + row0) * WS2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                    if (row0 + r < R) *reinterpret_cast<float4*>(wsS + (long)r * WS2 + c4) = *reinterpret_cast<const float4*>(X1 + r * LDT + c4);
+                }
+            };
+            unsigned long long* fl = x.flags + (size_t)blockIdx.x * 4 + wave;
+            X32 xo;
+            obs_load(xo, a.t0);
+            obs_store(xo);
+            if (CL > 1) obs_load(xo, a.t0 + 1);
+            lds_barrier();
+            half_a();
+            lds_barrier();
+            half_b(0);
+            if (CL > 1) obs_store(xo);
+            if (CL > 2) obs_load(xo, a.t0 + 2);
+            for (int s = 0; s <= CL; ++s) {
+                const int sp = s - 1;
+                lds_barrier();              // top
+                PH(8);
+                float* wsS = a.ws_act + ((long)(sp < 0 ? 0 : sp) * R + row0) * WS2;
+                if (sp >= 0) {              // h' of step sp leaves first (the head workgroups wait for it) ...
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < R) {
+                            const float4 hv = *reinterpret_cast<const float4*>(hp + r * LDT + c4);
+                            float* wp = wsS + (long)r * WS2 + 5 * HP + c4;
+                            st_agent64(wp, hv.x, hv.y);
+                            st_agent64(wp + 2, hv.z, hv.w);
+                        }
+                    }
+                }
+                if (s + 1 < CL) half_a();   // ... fc1 of step s + 1 runs under the stores' way to memory (its obs tile went to X0 in the previous interval B) ...
+                if (sp >= 0) {              // ... then the step is published, and the four saved tiles follow
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(fl, ((unsigned long long)x.tag << 32) | (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int idx = tid + NTHREADS * q, r = idx >> 4, c4 = (idx & 15) * 4;
+                        if (row0 + r < R) {
+                            float* wp = wsS + (long)r * WS2 + c4;
+                            const int o = r * LDT + c4;
+                            *reinterpret_cast<float4*>(wp + HP) = *reinterpret_cast<const float4*>(S + o);
+                            *reinterpret_cast<float4*>(wp + 2 * HP) = *reinterpret_cast<const float4*>(S + T32 * LDT + o);
+                            *reinterpret_cast<float4*>(wp + 3 * HP) = *reinterpret_cast<const float4*>(S + 2 * T32 * LDT + o);
+                            *reinterpret_cast<float4*>(wp + 4 * HP) = *reinterpret_cast<const float4*>(S + 3 * T32 * LDT + o);
+                        }
+                    }
+                }
+                PH(9);
+                lds_barrier();              // mid
+                PH(10);
+                if (s + 1 < CL) {
+                    half_b(s + 1);
+                    if (s + 2 < CL) obs_store(xo);
+                    if (s + 3 < CL) obs_load(xo, a.t0 + s + 3);
+                }
+                if (s < CL) { float* tmp = hp; hp = hn; hn = tmp; }
+                PH(11);
+            }
+        }
+        PH8_FLUSH();
+        if ((int)blockIdx.x >= x.nh) {
+            float* out = a.partial + (size_t)blockIdx.x * a.PS;
+            for (int i = threadIdx.x; i < a.K * H; i += NT8) out[off.W2 + i] = 0.0f;
+            if (threadIdx.x < a.K) out[off.b2 + threadIdx.x] = 0.0f;
+            if (threadIdx.x < CM_NUM_STATS) out[off.P + threadIdx.x] = 0.0f;
+        }
+        return;
+    }
+    if constexpr (PRE == 1) {
         float* hp = smem; float* hn = smem + T32 * LDT;
         float* S0 = smem + 2 * T32 * LDT;   // [2 sets][SR, SZ, SN, SG]
         const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;

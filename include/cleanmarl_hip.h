@@ -63,12 +63,12 @@ int cm_version(void);  /* 101 since round 5 (cm_opt_step_t grew by stats_out; cm
  *   "critic_schedule"  auto | fused | split | fused2   one-pass wide-input critic (csrc/cm_critic_fused.h) vs the two-kernel split schedule;
  *                                              fused2: the one-pass kernel with TWO row tiles per iteration for two-chunk inputs (opt-in: measured
  *                                              5 % slower than "fused" at config 4; same sums up to the association of a workgroup's tiles)
- *   "gru_tile"         auto | 64 | 32 | 8w | split   auto: pipelined 32-row sweeps while tiles + helper workgroups fit the CUs (head / weight gradients
+ *   "gru_tile"         auto | 64 | 32 | 8w | split | nosplit   auto: pipelined 32-row sweeps while tiles + helper workgroups fit the CUs (head / weight gradients
  *                                              on the idle CUs), eight-wave 32-row forward above, 64-row streaming sweeps from 512 64-row tiles;
  *                                              32: four-wave 32-row sweeps, 8w: eight-wave forward, 64: the 64-row sweeps at any batch size;
- *                                              split: the pipelined sweeps with the forward sweep split at its dependence on h (fc1 and the
- *                                              W_ih products of the whole chunk as one throughput launch, the chain keeps W_hh h + gates):
- *                                              bit-identical, measured slower at config 5, kept for A/B runs
+ *                                              the pipelined forward sweep is split at its dependence on h: helper waves run fc1 and the W_ih
+ *                                              products a step ahead of the recurrence waves; split: the same split as a throughput launch in
+ *                                              front of the chain (measured slower), nosplit: the unsplit sweep of round 5 -- all bit-identical
  *   "rollout_tile"     auto | 64 | 16 | 16s | 64s   tiling of the fused rollout (64 / 16: four-wave workgroups; 64s / 16s: four compute
  *                                              waves + a writer and a scorer wave, the defaults); the fused GRU rollout: 64 / 16 = its
  *                                              four-wave kernel, anything else = the six-wave one (bit-identical buffers)

@@ -697,11 +697,11 @@ def test_fused_gru_rollout_matches_per_step_kernels(E, A, T, H, tile, monkeypatc
 GRU_CASES = [("mappo_lstm_ragged", "mappo"), ("mappo_lstm_dense", "mappo"), ("ippo_lstm_ragged", "ippo")]
 
 
-@pytest.mark.parametrize("tile", ["auto", "split", "32", "64"])
+@pytest.mark.parametrize("tile", ["auto", "split", "nosplit", "32", "64"])
 @pytest.mark.parametrize("name,algo", GRU_CASES)
 def test_gru_tbptt_update_matches_reference_golden(golden_dir, name, algo, tile, monkeypatch):
-    # "auto" takes the pipelined 32-row sweeps at this batch size, "split" the same with the forward sweep split at its dependence on h
-    # (k_gru2_pre + k_gru2_fwdx<.., PRE>: opt-in); CM_GRU_TILE=32 the four-wave kernels; CM_GRU_TILE=64 forces the 64-row streaming kernels that large batches use: all three are pinned to the goldens
+    # "auto" takes the pipelined 32-row sweeps at this batch size with the forward sweep split at its dependence on h inside the workgroup,
+    # "split" the same split as a pre-pass launch (k_gru2_pre), "nosplit" the unsplit sweeps of round 5; CM_GRU_TILE=32 the four-wave kernels; CM_GRU_TILE=64 forces the 64-row streaming kernels that large batches use: all three are pinned to the goldens
     if tile != "auto":
         monkeypatch.setenv("CM_GRU_TILE", tile)
     else:
@@ -835,6 +835,7 @@ def test_gru_forward_sweeps_agree(E, A, T, Do, K, H, t0, t1):
         g8, h8 = run("8w")
         gx, hx = run("auto")
         gn, hn_ = run("split")
+        gu, hu = run("nosplit")
         again = [run("auto") for _ in range(5)]
     finally:
         N.set_option("gru_tile", "auto")
@@ -845,9 +846,11 @@ def test_gru_forward_sweeps_agree(E, A, T, Do, K, H, t0, t1):
     assert (gx - g4).abs().max().item() <= 1e-5 * (1.0 + scale)
     for g, h1 in again:
         assert torch.equal(g, gx) and torch.equal(h1, hx)
-    # the split forward sweep (gru_tile = "split": fc1 and the W_ih products of the chunk as one throughput launch, k_gru2_pre, the chain on
-    # W_hh h + gates) runs the MFMA sequences of the pipelined sweep on the same operands: the same bits everywhere
+    # the forward sweep split at its dependence on h -- inside the workgroup ("auto": helper waves run fc1 and the W_ih products a step ahead of
+    # the recurrence waves) or as a throughput launch in front of the chain ("split": k_gru2_pre) -- runs the MFMA sequences of the unsplit
+    # pipelined sweep ("nosplit") on the same operands: the same bits everywhere
     assert torch.equal(gn, gx) and torch.equal(hn_, hx)
+    assert torch.equal(gu, gx) and torch.equal(hu, hx)
 
 
 def test_gru_policy_act_matches_oracle():
