@@ -10,8 +10,10 @@
  *   - every function returns 0 on success, <0 on error; cm_last_error() gives a thread-local text.
  *   - the CALLER owns all memory: arguments are raw DEVICE pointers (e.g. torch tensor.data_ptr()),
  *     explicit dims, and the hipStream_t to launch on (torch.cuda.current_stream().cuda_stream).
- *   - no hidden allocation, no global mutable state, no implicit host sync: functions that need
- *     scratch take a caller-provided workspace sized by the matching *_workspace_bytes() query.
+ *   - no hidden allocation, no implicit host sync: functions that need scratch take a caller-provided workspace sized by
+ *     the matching *_workspace_bytes() query.  The only state the library keeps between calls are the process-wide options
+ *     of cm_set_option (atomic ints, documented below), the measurement hooks cm_clock_probe / cm_prof_set_buffer, and
+ *     nonces that tag hand-off words (no result depends on their value).
  *   - all device arithmetic is fp32; scalar hyper-parameters cross the ABI as double so that expressions the
  *     reference evaluates in Python float64 (e.g. 1 - td_lambda, 1 +- ppo_clip) are rounded to fp32 once.
  *     Device data layout (docs/KERNEL_NOTES.md §2), E envs, A agents, T steps:

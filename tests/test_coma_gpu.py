@@ -289,4 +289,4 @@ def test_factored_critic_equals_materialised_input(E, A, T, Do, Ds, K, H, L):
     assert np.abs(g_fac[:P].cpu().numpy() - gref).max() / scale <= TOL
     assert np.abs(g_lit[:P].cpu().numpy() - gref).max() / scale <= TOL
     assert _err(g_fac[P:].cpu().numpy(), g_lit[P:].cpu().numpy()) <= TOL
-    assert abs(float(g_fac[P + N.STAT_VLOSS]) - float(loss)) <= TOL * (1 + abs(float(loss)))
+    assert abs(float(g_fac[P + N.STAT_VLOSS]) - float(loss.detach())) <= TOL * (1 + abs(float(loss.detach())))
