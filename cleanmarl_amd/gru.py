@@ -90,6 +90,9 @@ class GRUPPOLearner(PPOLearner):
         # actor's epochs, i.e. under the next rollout (self.critic_schedule, measurements in __init__).  The serial chain of TBPTT chunk
         # kernels is never extended by them.  Issue order is identical on all ranks, so the collectives still pair up.
         ride = self.fused_step and not self._coll
+        # the fused step launch writes an epoch's / a chunk's statistic sums and norm straight into the record buffers (cm_opt_step_t::
+        # stats_out, out_norm): no copy launch per epoch; the stand-alone A/B step and a rank without environments copy as before
+        direct = self.fused_step and not empty
         main = torch.cuda.current_stream()
         kind, defer = self._parse_schedule(self.critic_schedule)
         if self._critic_stream is None:
@@ -107,13 +110,14 @@ class GRUPPOLearner(PPOLearner):
             with torch.cuda.stream(side):
                 sc = N.stream_ptr()
                 if ride:  # one process: the optimiser step rides on the pass's reduction launch
-                    self._timed("critic", self.critic_pass, b, sc, None, self.norms[1:])
+                    self._timed("critic", self.critic_pass, b, sc, None, rec_c[ep, N.NUM_STATS:], rec_c[ep, :N.NUM_STATS])
                 else:
                     self._timed("critic", self.critic_pass, b, sc)
                     self._allreduce(self.g_critic, self.pg_c)  # own communicator: never queues ahead of a chunk's message
-                    self._adam(self.critic, self.g_critic, self.opt_c, 1, sc)
-                rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
-                rec_c[ep, N.NUM_STATS] = self.norms[1]
+                    self._adam(self.critic, self.g_critic, self.opt_c, 1, sc, out_norm=rec_c[ep, N.NUM_STATS:],
+                               stats_out=rec_c[ep, :N.NUM_STATS] if direct else None)
+                if not direct:
+                    rec_c[ep, :N.NUM_STATS] = self.g_critic[Pc:]
                 if keep_grads:
                     kept_c.append((self.g_critic[:Pc].clone(), self.critic.clone()))
 
@@ -130,7 +134,8 @@ class GRUPPOLearner(PPOLearner):
                 h_out = self.h[ci & 1]
                 g = self.g_rows[ci]  # one [grads | stats] row per chunk: the statistics survive without per-chunk copies
                 if ride:
-                    o = self.opt_a.next_step(self.actor, rec_a[ep, ci, N.NUM_STATS:], hp.clip_gradients, 1.0 / (t1 - t0))
+                    o = self.opt_a.next_step(self.actor, rec_a[ep, ci, N.NUM_STATS:], hp.clip_gradients, 1.0 / (t1 - t0),
+                                             stats_out=rec_a[ep, ci, :N.NUM_STATS])
                     N.check(self.lib.cm_gru_actor_chunk_train_step(
                         N.ptr(b.obs), N.ptr(b.avail), N.ptr(b.action), N.ptr(b.logp), N.ptr(b.adv), N.ptr(b.ep_len),
                         b.E, b.A, T, t0, t1, a.din, a.hidden, a.dout, N.ptr(h_in), N.ptr(h_out),
@@ -147,11 +152,13 @@ class GRUPPOLearner(PPOLearner):
                         hp.ppo_clip, hp.entropy_coef, N.ptr(g), N.ptr(self.gru_ws), self.gru_ws.numel(), s),
                         "cm_gru_actor_chunk_fwd_bwd")
                     self._allreduce(g)
-                    self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:])
+                    self._adam(self.actor, g, self.opt_a, 0, s, grad_scale=1.0 / (t1 - t0), out_norm=rec_a[ep, ci, N.NUM_STATS:],
+                               stats_out=rec_a[ep, ci, :N.NUM_STATS] if direct else None)
                 if keep_grads:
                     steps.append((g[:Pa].clone(), self.actor.clone()))
                 h_in = h_out
-            rec_a[ep, :, :N.NUM_STATS] = self.g_rows[:len(chunks), Pa:]  # one strided copy per epoch
+            if not direct:
+                rec_a[ep, :, :N.NUM_STATS] = self.g_rows[:len(chunks), Pa:]  # one strided copy per epoch
             if self.events is not None:
                 ev1.record()
                 self.events.append(("actor", ev0, ev1))

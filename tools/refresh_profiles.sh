@@ -50,7 +50,8 @@ python $R/tools/cli_steady_state.py > $O/cli_steady_state.txt 2>&1
 # ---- kernel timelines of one steady-state iteration (two queues): config 3 at full size, its 512-env share, config 2
 for w in "cfg3" "cfg3 --envs 512" "cfg2"; do
   n=$(echo $w | tr -d ' -')
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$n -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  rm -rf /tmp/kt_$n
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$n -- python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extras --solo-launches 0 > /dev/null 2>&1
   python $R/tools/trace_timeline.py $(find /tmp/kt_$n -name "*kernel_trace.csv" | head -1) k_ro 3 > $O/timeline_$n.txt 2>&1
   # launches of an iteration that are not this library's kernels (torch copies / fills): counted per name
   python - $(find /tmp/kt_$n -name "*kernel_trace.csv" | head -1) > $O/foreign_launches_$n.txt <<'PYEOF'
@@ -60,7 +61,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
     if "at::native" in k or "rocclr" in k or "Fill" in k:
         n[k[:110]] += 1
-print("launches that are not libcleanmarl_hip kernels, whole run (13 iterations + set-up):")
+print("launches that are not libcleanmarl_hip kernels, whole run (1 set-up pass that allocates and fills the buffers + 13 iterations; a count that does not")
+print("grow with the iterations is set-up; __amd_rocclr_copyBuffer = the asynchronous copy of an update's record buffer to pinned host memory):")
 for k, v in n.most_common():
     print(f"  {v:5d}  {k}")
 PYEOF
