@@ -278,6 +278,33 @@ def load_pmc(path, workload="cfg3"):
     return pmc, None
 
 
+def load_issue_counters(path, kernel_pat):
+    """Instruction-issue counters of the dominant kernel (profiles/issue_counters.json, tools/gpu/r06_issue_pmc.sh: rocprofv3 --pmc passes),
+    accepted only for the sources of the library being timed.  On gfx950 fp32 MFMAs and VALU instructions do not co-execute (DESIGN.md
+    section 3, tools/probes/cosimd_overlap.hip), so a kernel's issue bound is MFMA cycles + VALU instruction cycles per SIMD; this turns the
+    counters into those shares of the launch.  -> dict or None."""
+    from cleanmarl_amd.build import source_hash
+    try:
+        rec = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    if rec.get("source_hash") != source_hash():
+        return None
+    k = next((v for n, v in rec.get("kernels", {}).items() if kernel_pat in n), None)
+    if not k or not k.get("GRBM_GUI_ACTIVE"):
+        return None
+    simd_cycles = 1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0          # 256 CUs x 4 SIMDs x the launch's cycles (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    valu = k["SQ_INSTS_VALU"] - k["SQ_INSTS_MFMA"]             # SQ_INSTS_VALU counts the MFMAs as well
+    return {"mfma_insts_per_launch": k["SQ_INSTS_MFMA"], "other_valu_insts_per_launch": valu,
+            "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+            "valu_issue_frac_at_4_cycles": 4.0 * valu / simd_cycles, "valu_issue_frac_at_7_cycles": 7.0 * valu / simd_cycles,
+            "valu_mfma_coexec_cycles": k.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+            "note": "shares of the launch's SIMD cycles: MFMA pipe busy, and the other VALU instructions at 4 cycles each (issue minimum of a 64-lane "
+                    "wave) / 7 cycles each (marginal cost measured behind an MFMA, profiles/r06_cosimd_overlap.txt); the two do not co-execute, so their "
+                    "sum is the part of the launch its instruction stream needs whatever the schedule",
+            "source": "profiles/r06_issue_counters.txt (rocprofv3 --pmc, tools/gpu/r06_issue_pmc.sh), stamped with the library's source hash"}
+
+
 def _bound(work, ms):
     """Achieved rates of one launch / phase against BOTH peaks; the bound is the one that takes longer at peak."""
     if ms <= 0:
@@ -524,6 +551,9 @@ def main():
                 out["roofline"]["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
             else:
                 out["roofline"]["traffic_refused"] = why  # traffic stays null: never a number measured on other kernels
+            issue = load_issue_counters(os.path.join(ROOT, "profiles", "issue_counters.json"), DOMINANT_KERNEL)
+            if issue is not None:
+                out["roofline"]["issue"] = issue
     w.close()
 
     weak_leg = None

@@ -350,3 +350,28 @@ def test_bench_refuses_a_pmc_record_taken_on_other_sources(tmp_path):
     # the committed record is either current or refused -- never silently used for other kernels
     rec, why = bench.load_pmc(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))
     assert (rec is None) != (why is None)
+
+
+def test_bench_refuses_issue_counters_taken_on_other_sources(tmp_path):
+    """roofline.issue (MFMA-busy and VALU-issue shares of the dominant kernel's launch) comes from a committed PMC record as well: same
+    stamp rule as roofline.traffic -- other sources, another kernel or an unreadable file give None, never numbers of another build."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from cleanmarl_amd.build import source_hash
+    name = "void (anonymous namespace)::k_mlp<1, 2, 1, 1, 2, false, true>((anonymous namespace)::MlpArgs)"
+    ctr = dict(SQ_INSTS_MFMA=50.0e6, SQ_INSTS_VALU=170.0e6, SQ_VALU_MFMA_BUSY_CYCLES=2.9e9, GRBM_GUI_ACTIVE=32.0e6, SQ_VALU_MFMA_COEXEC_CYCLES=0.0)
+    p = tmp_path / "issue.json"
+    p.write_text(json.dumps(dict(source_hash=source_hash(), workload="cfg3", kernels={name: ctr})))
+    rec = bench.load_issue_counters(str(p), bench.DOMINANT_KERNEL)
+    simd = 1024 * 32.0e6 / 8
+    assert rec["other_valu_insts_per_launch"] == 120.0e6 and abs(rec["mfma_busy_frac"] - 2.9e9 / simd) < 1e-12
+    assert abs(rec["valu_issue_frac_at_4_cycles"] - 4 * 120.0e6 / simd) < 1e-12 and rec["valu_mfma_coexec_cycles"] == 0.0
+    p.write_text(json.dumps(dict(source_hash="0123456789abcdef", workload="cfg3", kernels={name: ctr})))
+    assert bench.load_issue_counters(str(p), bench.DOMINANT_KERNEL) is None
+    p.write_text(json.dumps(dict(source_hash=source_hash(), workload="cfg3", kernels={"k_critic_fused<6>": ctr})))
+    assert bench.load_issue_counters(str(p), bench.DOMINANT_KERNEL) is None
+    p.write_text("{not json")
+    assert bench.load_issue_counters(str(p), bench.DOMINANT_KERNEL) is None
+    assert bench.load_issue_counters(str(tmp_path / "missing.json"), bench.DOMINANT_KERNEL) is None

@@ -13,6 +13,15 @@ for path in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recu
 names = ["SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_COEXEC_CYCLES",
          "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]
 print("per launch (mean over launches), raw counter values summed over the device; rocprofv3 --pmc, two passes")
+import json
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from cleanmarl_amd.build import source_hash
+rec = {"source_hash": source_hash(), "workload": "cfg3", "kernels": {}}
+for k in d:
+    if "at::native" in k or "rocclr" in k:
+        continue
+    rec["kernels"][k] = {n: sum(v) / len(v) for n, v in d[k].items()}
+json.dump(rec, open(os.path.join(os.path.dirname(root), "issue_counters.json"), "w"), indent=1)
 for k in sorted(d, key=lambda k: -sum(d[k].get("GRBM_GUI_ACTIVE", [0]))):
     if "at::native" in k or "rocclr" in k:
         continue
