@@ -171,6 +171,42 @@ template <int KIND, int NV> void run_shadow() {
     hipFree(out); hipFree(cyc);
 }
 
+// the same question for a bf16 MFMA (v_mfma_f32_32x32x16_bf16: 8 passes, 16 x the fp32 rate per pass): does the real matrix core run beside the VALU?
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int NV>
+__global__ void k_shadow_bf16(float* out, unsigned long long* cyc, int iters) {
+    f32x16 a32;
+    for (int g = 0; g < 16; ++g) a32[g] = 0.f;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(1.0f + 0.01f * j); b[j] = (__bf16)(0.5f + 0.01f * threadIdx.x); }
+    float x[16];
+    for (int j = 0; j < 16; ++j) x[j] = 1.0f + j + threadIdx.x * 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, a32, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j & 15]) : "v"(0.999f), "v"(0.001f));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = a32[0];
+    for (int j = 0; j < 16; ++j) r += x[j];
+    out[threadIdx.x] = r;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int NV> void run_shadow_bf16() {
+    float* out; unsigned long long* cyc; unsigned long long h;
+    hipMalloc(&out, 64 * 4); hipMalloc(&cyc, 8);
+    const int iters = 2000;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k_shadow_bf16<NV>), dim3(1), dim3(64), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    printf("one wave, 1 x v_mfma_f32_32x32x16_bf16 + %2d independent v_fma_f32 behind it: %.1f cycles per group\n", NV, (double)h / (iters * 8.0));
+    hipFree(out); hipFree(cyc);
+}
+
 // two waves of one SIMD again, the YOUNGER wave (B: VALU) at s_setprio 3: does priority let it into the MFMA wave's stream?
 template <int A>
 __global__ __launch_bounds__(512) void k_prio(float* out, unsigned long long* cyc, int ia, int ib) {
@@ -196,6 +232,7 @@ template <int A> void run_prio(const char* na, int ia, int ib) {
 int main() {
     run_shadow<32, 0>(); run_shadow<32, 4>(); run_shadow<32, 8>(); run_shadow<32, 12>(); run_shadow<32, 16>(); run_shadow<32, 24>();
     run_shadow<16, 0>(); run_shadow<16, 4>(); run_shadow<16, 8>(); run_shadow<16, 12>(); run_shadow<16, 16>();
+    run_shadow_bf16<0>(); run_shadow_bf16<4>(); run_shadow_bf16<8>(); run_shadow_bf16<16>();
     run_shadow_lds<0>(); run_shadow_lds<1>(); run_shadow_lds<2>(); run_shadow_lds<4>(); run_shadow_lds<8>();
     run_prio<M16>("M16", 400, 200); run_prio<M32>("M32", 400, 400);
     // iteration counts chosen so that A and B take about the same time alone (the informative case)
