@@ -42,6 +42,13 @@ constexpr int wgs_per_cu(int nch) { return nch <= CM_WG2_MAX_NCH ? 2 : 1; }
 #ifndef CM_TILE_SPLIT_DEFAULT
 #define CM_TILE_SPLIT_DEFAULT 56  // per cent of the tiles for the first half of a full grid (set_tile_split); 50 = equal
 #endif
+#ifndef CM_HEAD_FAST
+#define CM_HEAD_FAST 0  // 1 = the PPO head's exp / log / reciprocal as single hardware instructions (v_exp_f32, v_log_f32, v_rcp_f32: 1 ulp each) instead of libm's
+#endif
+#ifndef CM_HEAD_44
+#define CM_HEAD_44 1  // wave-private training heads (K <= 8) on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks per instruction: 8 head outputs cost 8, not 16,
+                      // columns of MFMA work); 0 = the 16x16x4 products of round 4, kept for A/B builds
+#endif
 #ifndef CM_HEAD_WP
 #define CM_HEAD_WP 1  // wave-private head backward (head_bwd_wave); 0 = the workgroup-wide products of rounds 1 - 3, kept for A/B builds
 #endif
@@ -124,6 +131,11 @@ __host__ __device__ inline Lds make_lds(int L, int dout, int nch) {
     s.total = p;
     return s;
 }
+
+// exp / log / reciprocal of the PPO head's per-row math (CM_HEAD_FAST)
+__device__ __forceinline__ float head_exp(float x) { return CM_HEAD_FAST ? __expf(x) : expf(x); }
+__device__ __forceinline__ float head_log(float x) { return CM_HEAD_FAST ? __logf(x) : logf(x); }
+__device__ __forceinline__ float head_rcp(float x) { return CM_HEAD_FAST ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
 
 // 4-lane (quad) butterflies on the VALU via DPP quad_perm -- no LDS round trip like ds_bpermute
 __device__ __forceinline__ float quad_xor1(float v) {
@@ -561,6 +573,112 @@ __device__ __forceinline__ void head_bwd_wave(f32x4 (&accWo)[NQ][4], const float
         }
 }
 
+// ---- K <= 8 training heads on v_mfma_f32_4x4x1_16b_f32 (CM_HEAD_44, round 6).  One instruction = 16 independent 4 x 4 outer products: lane 4 b + x supplies
+// A[b][i = x] and B[b][j = x], register i of lane 4 b + j receives D[b][i][j] (tools/probes/mfma4x4_layout.hip).  The same 32 MAC per cycle as the larger forms
+// (8.75 cycles per instruction from two accumulator chains on), but the padding of a K = 5 head is 8 columns instead of 16: the wave's three head
+// products take 32 + 32 + 4 K instructions x 8.75 cycles = 735 cycles at K = 5 where the 16x16x4 forms took 40 x 32 = 1280.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float row_ror8(float v) {  // lane l of a 16-lane row <- lane l ^ 8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+
+// The 4x4x1 products are short (4 MFMAs = 35 cycles per 16-byte operand pair), so their LDS reads are hand-issued (cm_common.h: fixed issue order, counted
+// waits) several steps ahead; the "memory" clobber keeps the compiler's own LDS stores (the dlogits the head math just wrote) on their side of the reads.
+template <int OFF> __device__ __forceinline__ f32x4 hd_lds128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF0, int OFF1> __device__ __forceinline__ f32x2 hd_lds32x2(unsigned addr) {  // offsets in 4-byte units
+    f32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1) : "memory");
+    return v;
+}
+
+// logits of the wave's 16 rows, 8 head outputs: block (rg, kh, og) = rows 4 rg .. 4 rg + 3 x outputs 4 og .. 4 og + 3 over the k half [32 kh, 32 kh + 32)
+// (lane = 16 rg + 8 kh + 4 og + x); the bias is the initial accumulator of the kh = 0 blocks, the two halves meet through one DPP row rotation, the kh = 0
+// lanes write lsw[row][k] (row stride 8).  Operand pairs in a ring of four, issued four steps ahead.
+template <bool BF = false>
+__device__ __forceinline__ void head_logits44(float* lsw /* ls + 16 * wave * 8 */, const float* HLw /* H_L + 16 * wave * LDT */, const float* wouts,
+                                              const float* bout) {
+    static_assert(HP == 64, "eight 16-byte steps per k half");
+    const int lane = threadIdx.x & 63, x = lane & 3, og = (lane >> 2) & 1, kh = (lane >> 3) & 1, rg = lane >> 4;
+    const float b0 = kh ? 0.0f : bout[4 * og + x];
+    const unsigned aa = cf_lds_addr(HLw + (4 * rg + x) * LDT + 32 * kh), ba = cf_lds_addr(wouts + (4 * og + x) * WLD + 32 * kh);
+    f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a[4], b[4];
+#define CM_LG_ISSUE(m) do { a[(m) & 3] = hd_lds128<16 * (m)>(aa); b[(m) & 3] = hd_lds128<16 * (m)>(ba); } while (0)
+#define CM_LG_STEP(m, N) do { cf_wait<N>(a[(m) & 3], b[(m) & 3]); \
+        acc0 = mfma4(dec<BF>(a[(m) & 3][0]), b[(m) & 3][0], acc0); acc1 = mfma4(dec<BF>(a[(m) & 3][1]), b[(m) & 3][1], acc1); \
+        acc0 = mfma4(dec<BF>(a[(m) & 3][2]), b[(m) & 3][2], acc0); acc1 = mfma4(dec<BF>(a[(m) & 3][3]), b[(m) & 3][3], acc1); } while (0)
+    CM_LG_ISSUE(0); CM_LG_ISSUE(1); CM_LG_ISSUE(2); CM_LG_ISSUE(3);
+    CM_LG_STEP(0, 6); CM_LG_ISSUE(4);
+    CM_LG_STEP(1, 6); CM_LG_ISSUE(5);
+    CM_LG_STEP(2, 6); CM_LG_ISSUE(6);
+    CM_LG_STEP(3, 6); CM_LG_ISSUE(7);
+    CM_LG_STEP(4, 6); CM_LG_STEP(5, 4); CM_LG_STEP(6, 2); CM_LG_STEP(7, 0);
+#undef CM_LG_ISSUE
+#undef CM_LG_STEP
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = acc0[i] + acc1[i];
+        v += row_ror8(v);
+        if (!kh) lsw[(4 * rg + i) * 8 + 4 * og + x] = v;
+    }
+}
+
+// head backward of the wave's 16 rows (see head_bwd_wave): dWout partial in accWo[m] -- block (rh, kg, cg) of lane 4 b + x, b = 8 rh + 4 kg + cg: register i =
+// dWout[4 kg + i][16 cg + 4 x + m] over the rows 8 rh .. 8 rh + 7 (the two row halves are separate partials, summed with the waves' at the end of the
+// launch); dZ_L -- block (rg, cg), b = 4 rg + cg: dz[m] register i = dZ_L[4 rg + i][16 cg + 4 x + m], written in place on 16-byte accesses.  All 8 head rows of
+// the weight image take part (rows >= dout are zero): no branch inside the hand-issued pipeline.  At most 14 reads in flight (lgkmcnt counts to 15).
+template <bool BF = false>
+__device__ __forceinline__ void head_bwd_wave44(f32x4 (&accWo)[4], const float* lsw, float* HLw, const float* wouts) {
+    const int lane = threadIdx.x & 63, x = lane & 3, b = lane >> 2, cg = b & 3, kg = (b >> 2) & 1, rh = b >> 3, rg = b >> 2;
+    const unsigned da = cf_lds_addr(lsw + 8 * rh * 8 + 4 * kg + x);          // dlogits[8 rh + s][4 kg + x]: + 32 s bytes
+    const unsigned ha = cf_lds_addr(HLw + 8 * rh * LDT + 16 * cg + 4 * x);   // H_L[8 rh + s][16 cg + 4 x ..]: + 4 LDT s bytes
+    const unsigned za = cf_lds_addr(lsw + (4 * rg + x) * 8);                 // dlogits[4 rg + x][0 .. 7]
+    const unsigned wa = cf_lds_addr(wouts + 16 * cg + 4 * x);                // Wout[k][16 cg + 4 x ..]: + 4 WLD k bytes
+    const unsigned pa = cf_lds_addr(HLw + 4 * rg * LDT + 16 * cg + 4 * x);   // H_L[4 rg + i][16 cg + 4 x ..]: + 4 LDT i bytes
+    f32x2 d2[4];
+    f32x4 hv[8], az[2], wv[8], hz[4];
+    d2[0] = hd_lds32x2<0, 8>(da); d2[1] = hd_lds32x2<16, 24>(da); d2[2] = hd_lds32x2<32, 40>(da); d2[3] = hd_lds32x2<48, 56>(da);
+#define CM_HB_H(s_) hv[s_] = hd_lds128<4 * LDT * (s_)>(ha)
+#define CM_HB_W(k_) wv[k_] = hd_lds128<4 * WLD * (k_)>(wa)
+#define CM_HB_DW(s_, N) do { cf_wait<N>(hv[s_]); const float av_ = d2[(s_) >> 1][(s_) & 1]; \
+        accWo[0] = mfma4(av_, dec<BF>(hv[s_][0]), accWo[0]); accWo[1] = mfma4(av_, dec<BF>(hv[s_][1]), accWo[1]); \
+        accWo[2] = mfma4(av_, dec<BF>(hv[s_][2]), accWo[2]); accWo[3] = mfma4(av_, dec<BF>(hv[s_][3]), accWo[3]); } while (0)
+    CM_HB_H(0); CM_HB_H(1); CM_HB_H(2); CM_HB_H(3); CM_HB_H(4); CM_HB_H(5); CM_HB_H(6); CM_HB_H(7);   // 12 in flight
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(d2[0]), "+v"(d2[1]), "+v"(d2[2]), "+v"(d2[3]));      // the four dlogits pairs
+    CM_HB_DW(0, 7); CM_HB_DW(1, 6); CM_HB_DW(2, 5); CM_HB_DW(3, 4);
+    az[0] = hd_lds128<0>(za); az[1] = hd_lds128<16>(za);
+    CM_HB_W(0); CM_HB_W(1); CM_HB_W(2); CM_HB_W(3); CM_HB_W(4);                                     // 4 + 7 in flight
+    CM_HB_DW(4, 10); CM_HB_DW(5, 9); CM_HB_DW(6, 8); CM_HB_DW(7, 7);
+    CM_HB_W(5); CM_HB_W(6); CM_HB_W(7);
+    hz[0] = hd_lds128<0>(pa); hz[1] = hd_lds128<4 * LDT>(pa); hz[2] = hd_lds128<8 * LDT>(pa); hz[3] = hd_lds128<12 * LDT>(pa);   // 14 in flight
+    f32x4 dz[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dz[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define CM_HB_DZ(k_, N) do { cf_wait<N>(az[(k_) >> 2], wv[k_]); const float av_ = az[(k_) >> 2][(k_) & 3]; \
+        dz[0] = mfma4(av_, wv[k_][0], dz[0]); dz[1] = mfma4(av_, wv[k_][1], dz[1]); \
+        dz[2] = mfma4(av_, wv[k_][2], dz[2]); dz[3] = mfma4(av_, wv[k_][3], dz[3]); } while (0)
+    CM_HB_DZ(0, 11); CM_HB_DZ(1, 10); CM_HB_DZ(2, 9); CM_HB_DZ(3, 8); CM_HB_DZ(4, 7); CM_HB_DZ(5, 6); CM_HB_DZ(6, 5); CM_HB_DZ(7, 4);
+    cf_wait<0>(hz[0], hz[1]); cf_wait<0>(hz[2], hz[3]);
+#undef CM_HB_H
+#undef CM_HB_W
+#undef CM_HB_DW
+#undef CM_HB_DZ
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 o;
+        o.x = enc<BF>((dec<BF>(hz[i][0]) > 0.0f) ? dz[0][i] : 0.0f);
+        o.y = enc<BF>((dec<BF>(hz[i][1]) > 0.0f) ? dz[1][i] : 0.0f);
+        o.z = enc<BF>((dec<BF>(hz[i][2]) > 0.0f) ? dz[2][i] : 0.0f);
+        o.w = enc<BF>((dec<BF>(hz[i][3]) > 0.0f) ? dz[3][i] : 0.0f);
+        *reinterpret_cast<float4*>(HLw + (4 * rg + i) * LDT + 16 * cg + 4 * x) = o;
+    }
+}
+
 // acc[32 rows x 32 cols] = dlogits[32 rows][KP] * Wout[KP][32 cols]   (backward through the head, K = KP)
 template <int KP>
 __device__ __forceinline__ void head_bwd_mfma(f32x16& acc, const float* ls_r0, const float* wts_c0) {
@@ -756,6 +874,8 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // hidden->hidden layer: 208 -> 219 registers for the actor pass of config 3); K > 8 heads (+ 24 .. 32 registers) and two-chunk / deep
     // instantiations sit at the 256-register limit of two workgroups per CU and would spill (config 4's actor: 4 -> 64 spilled registers)
     constexpr bool WP = (CM_HEAD_WP != 0) && KJ == 2 && NCH <= 1 && LCAP == 1;
+    constexpr bool WP44 = WP && TRAIN && (CM_HEAD_44 != 0);  // the three head products on the 4x4x1 MFMA (forward-only modes keep the 16x16x4 logits: their
+                                                              // samplers are held bit-identical to the fused rollouts')
     f32x4 accWoW[WP ? WR / 16 : 1][4];  // WP: dWout partial of THIS wave's rows, [k (16 per q)][16 hidden cols per ct]; summed over the waves at the end
     float dboW[KJ];                     // WP: head bias gradient from this lane's dlogits (k = 4 j + hq), summed over lanes and waves at the end
     f32x4 accWo[WR / 16];  // !WP: dWout[k (16 per tile) x 16 hidden cols]: wave w owns hidden columns 16w..16w+15
@@ -959,7 +1079,9 @@ _Pragma("unroll") \
         if (EARLY_NEXT && L >= 1) tile_load<(VEC != 0)>(pn, a.x, next_row0, a.rows, a.x_stride, 0, min(KC, din));
         // ================= head forward: 16x16x4 MFMA, wave w owns rows 16w..16w+15 (= the rows of its quad lanes) ====
         float* HL = smem + lds.Hs(L);
-        {
+        if constexpr (WP44) {
+            head_logits44<BF>(ls + 16 * wave * lstride, HL + 16 * wave * LDT, wouts, smem + lds.bout);
+        } else {
             const int n = lane & 15, g4 = lane >> 4;
 #pragma unroll
             for (int ct = 0; ct < WR / 16; ++ct) {
@@ -1041,11 +1163,11 @@ _Pragma("unroll") \
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     pj[j] = 0.0f;
-                    if (4 * j + hq < dout) { pj[j] = expf(zreg[j] - m); s += pj[j]; }
+                    if (4 * j + hq < dout) { pj[j] = head_exp(zreg[j] - m); s += pj[j]; }
                 }
                 s = quad_sum(s);
-                const float lse = m + logf(s);
-                const float rs = 1.0f / s;
+                const float lse = m + head_log(s);
+                const float rs = head_rcp(s);
                 float ent = 0.0f, lpa = 0.0f;
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
@@ -1060,7 +1182,7 @@ _Pragma("unroll") \
                 ent = quad_sum(ent);
                 lpa = quad_sum(lpa);
                 const float log_ratio = lpa - ri.lpo;
-                const float ratio = expf(log_ratio);
+                const float ratio = head_exp(log_ratio);
                 const float advv = ri.adv;
                 const float pg1 = advv * ratio;
                 const float pg2 = advv * fminf(fmaxf(ratio, a.clip_lo), a.clip_hi);
@@ -1086,6 +1208,7 @@ _Pragma("unroll") \
                         float d = invA * (-gr * ((k == ri.act ? 1.0f : 0.0f) - pj[j]) + a.ent_coef * pj[j] * (lp + ent));
                         if (!valid || zreg[j] <= -5e8f) d = 0.0f;  // padded rows; masked_fill blocks the gradient
                         ls[hrow * lstride + k] = d;
+                        if constexpr (WP) dboW[j] += d;  // head bias gradient straight from the register (no LDS read-back on the wave's critical path)
                     }
                 }
             } else if (MODE == M_COMA_ACTOR) {
@@ -1189,12 +1312,15 @@ _Pragma("unroll") \
             if constexpr (WP) {
             // head bias gradient from the dlogits this lane just wrote (k = 4 j + hq; M_CRITIC: only lane hq == 0 wrote, slot 0)
             __builtin_amdgcn_wave_barrier();
+            if constexpr (MODE != M_ACTOR) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j)
                 if (4 * j + hq < dout) dboW[j] += ls[hrow * lstride + 4 * j + hq];
+            }
             PH(4);
             // dWout, dZ_L and the in-place relu' write for this wave's 16 rows (same-wave LDS hand-off: DS ops of a wave execute in order)
-            head_bwd_wave<KP, (WP ? WR / 16 : 1), BF>(accWoW, ls + 16 * wave * KP, HL + 16 * wave * LDT, wouts);
+            if constexpr (WP44) head_bwd_wave44<BF>(accWoW[0], ls + 16 * wave * KP, HL + 16 * wave * LDT, wouts);
+            else head_bwd_wave<KP, (WP ? WR / 16 : 1), BF>(accWoW, ls + 16 * wave * KP, HL + 16 * wave * LDT, wouts);
             PH(5);
             __syncthreads();
             PH(6);
@@ -1352,6 +1478,22 @@ _Pragma("unroll") \
             // four waves in wave order through LDS (the tile buffers are dead), one 16-row block of k at a time
             const int n = lane & 15, g4 = lane >> 4;
             float* wsum = smem + lds.Xs;  // [4 waves][16 k][64 c] = 16 KB of the (dead) X | W0 tile buffers
+            if constexpr (WP44) {   // eight partials (wave, row half) of [8 k][64 c]: lane 4 b + x, b = 8 rh + 4 kg + cg, register i of accWoW[0][m] = k 4 kg + i, column 16 cg + 4 x + m
+                const int x = lane & 3, b = lane >> 2, cg = b & 3, kg = (b >> 2) & 1, rh = b >> 3;
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(wsum + ((2 * wave + rh) * 8 + 4 * kg + i) * HP + 16 * cg + 4 * x) =
+                        make_float4(accWoW[0][0][i], accWoW[0][1][i], accWoW[0][2][i], accWoW[0][3][i]);
+                __syncthreads();
+                for (int i = tid; i < 8 * HP; i += NTHREADS) {
+                    const int k = i / HP, c = i % HP;
+                    float sw = wsum[i];
+#pragma unroll
+                    for (int part = 1; part < 8; ++part) sw += wsum[part * 8 * HP + i];
+                    if (k < dout && c < H) out[off.Wout + k * H + c] = sw;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < WR / 16; ++q) {
                 __syncthreads();
