@@ -874,8 +874,12 @@ __global__ __launch_bounds__(NTHREADS, wgs_per_cu(NCH)) void k_mlp(const MlpArgs
     // hidden->hidden layer: 208 -> 219 registers for the actor pass of config 3); K > 8 heads (+ 24 .. 32 registers) and two-chunk / deep
     // instantiations sit at the 256-register limit of two workgroups per CU and would spill (config 4's actor: 4 -> 64 spilled registers)
     constexpr bool WP = (CM_HEAD_WP != 0) && KJ == 2 && NCH <= 1 && LCAP == 1;
-    constexpr bool WP44 = WP && TRAIN && (CM_HEAD_44 != 0);  // the three head products on the 4x4x1 MFMA (forward-only modes keep the 16x16x4 logits: their
-                                                              // samplers are held bit-identical to the fused rollouts')
+    // the three head products on the 4x4x1 MFMA: only in the hand-ordered instantiations, i.e. launches that have the GPU to themselves (launch_variant:
+    // >= 2^21 rows).  Its 14-deep operand pipelines cost 26 registers (221 -> 247): beside the critic's kernels the two actor workgroups of a CU then
+    // leave no register slot for the small launches of the other stream (fold + step, scan), which wait for a whole actor pass -- measured on the
+    // 512-env share: 1.34 -> 1.475 ms with the new head, although the pass alone is 2 % faster (profiles/r06_head_4x4_ab.txt).  Forward-only modes
+    // keep the 16x16x4 logits: their samplers are held bit-identical to the fused rollouts'.
+    constexpr bool WP44 = WP && TRAIN && HAND && (CM_HEAD_44 != 0);
     f32x4 accWoW[WP ? WR / 16 : 1][4];  // WP: dWout partial of THIS wave's rows, [k (16 per q)][16 hidden cols per ct]; summed over the waves at the end
     float dboW[KJ];                     // WP: head bias gradient from this lane's dlogits (k = 4 j + hq), summed over lanes and waves at the end
     f32x4 accWo[WR / 16];  // !WP: dWout[k (16 per tile) x 16 hidden cols]: wave w owns hidden columns 16w..16w+15
