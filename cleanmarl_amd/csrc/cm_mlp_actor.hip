@@ -114,7 +114,12 @@ extern "C" double cm_ppo_actor_issued_flop_per_row(int din, int hidden, int n_hi
         m32 += 32;                   // dW0, chunk c
     }
     m32 += (long)n_hidden_layers * (32 + 32 + 32);  // forward, weight gradient, data path of every hidden layer
-    m16 += 2 * 16 * (WR / 16);       // logits + dWout
-    m32 += 4 * (KP / 8);             // dZ_L
-    return (double)(4 * (m32 * 4096 + m16 * 2048)) / (double)TM;
+    long m4 = 0;
+    if (CM_HEAD_44 != 0 && nch == 1 && n_hidden_layers <= 1 && n_actions <= 8) {
+        m4 += 32 + 32 + 32;          // the hand-ordered instantiation (launches of >= 2^21 rows): logits, dWout, dZ_L on the 4x4x1 MFMA, 8 head columns
+    } else {
+        m16 += 2 * 16 * (WR / 16);   // logits + dWout on the 16x16x4 MFMA, 16 head columns per block
+        m32 += 4 * (KP / 8);         // dZ_L
+    }
+    return (double)(4 * (m32 * 4096 + m16 * 2048 + m4 * 512)) / (double)TM;
 }

@@ -388,7 +388,9 @@ int cm_policy_act_episode_ld(const float* x, int64_t x_ld, const uint8_t* avail,
                              int n_hidden_layers, int n_actions, const float* params, uint64_t seed, int64_t row_offset,
                              int32_t* action, float* logp, void* ws, size_t ws_bytes, cm_stream_t stream);
 /* MFMA work the fused actor pass issues per row (flop, tile padding included; 0 for shapes on the layered schedule): reported by
- * bench.py beside the algorithmic flop of SURVEY.md 8(d) so that the padding share of the matrix-pipe time is visible. */
+ * bench.py beside the algorithmic flop of SURVEY.md 8(d) so that the padding share of the matrix-pipe time is visible.  The figure is
+ * that of the instantiation a launch of >= 2^21 rows takes (single-chunk inputs, <= 8 actions: the head on the 4x4x1 MFMA, 8 padded
+ * head columns: 3 072 flop per row for the head); smaller launches of those shapes run the 16x16x4 head (16 padded columns: 5 120 flop per row). */
 double cm_ppo_actor_issued_flop_per_row(int din, int hidden, int n_hidden_layers, int n_actions);
 int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* avail, const int32_t* action,
                             const float* logp_old, const float* adv, const int32_t* ep_len,
