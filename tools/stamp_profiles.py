@@ -15,7 +15,7 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 manifest = open(os.path.join(src, "MANIFEST.txt")).read()
 stamp = manifest.splitlines()[0].strip()
 rename = {"bench.json": "bench.json", "gputests.txt": "gputests_log.txt", "parity_observed.txt": "gputests.txt"}
-skip = {"bench.err", "coma.err", "coma128.err", "pmc_dominant_kernel.json", "MANIFEST.txt"}
+skip = {"bench.err", "coma.err", "coma128.err", "pmc_dominant_kernel.json", "issue_counters.json", "MANIFEST.txt"}  # the two .json records are installed below
 copied = []
 for f in sorted(os.listdir(src)):
     p = os.path.join(src, f)
@@ -41,5 +41,8 @@ pmc = os.path.join(src, "pmc_dominant_kernel.json")
 if os.path.exists(pmc):
     shutil.copyfile(pmc, os.path.join(dst, "pmc_dominant_kernel.json"))
     shutil.copyfile(pmc, os.path.join(dst, f"{tag}_pmc_dominant_kernel.json"))
+issue = os.path.join(src, "issue_counters.json")  # tools/gpu/r06_issue_pmc.sh: the record bench.py reads for roofline.issue (carries its own source_hash)
+if os.path.exists(issue):
+    shutil.copyfile(issue, os.path.join(dst, "issue_counters.json"))
 print(stamp)
 print(f"{len(copied)} files -> profiles/{tag}_*")
