@@ -115,6 +115,35 @@ def test_coma_two_iterations_match_oracle(E, A, T, Do, Ds, K, Ha, Hc, La, Lc, td
         assert _err(L.target.cpu().numpy(), R.flat(tp).numpy()) <= TOL, it
 
 
+def test_coma_hand_ordered_passes_match_the_oracle(monkeypatch):
+    """COMA's actor pass (M_COMA_ACTOR) and Q-critic pass (M_QCRITIC) take the hand-ordered instantiation of k_mlp -- the one with the 4x4x1-MFMA head
+    (csrc/cm_mlp_kernel.h: head_logits44 / head_bwd_wave44) -- from 2^21 rows on; forced here at config-3 shapes (16-byte rows) with CM_MLP_FORMS=hand and held
+    to the same oracle bars as the compiler-scheduled run, which must differ from it in the low bits of the actor gradient (else the forced form was not taken)."""
+    from oracle import coma as C
+    from oracle import restatement as R
+    E, A, T, Do, Ds, K, Ha, Hc, La, Lc = 40, 8, 16, 56, 384, 5, 64, 64, 1, 1
+    hp = dict(gamma=0.99, td_lambda=0.8, normalize_reward=0.0, normalize_advantage=1.0, normalize_return=1.0,
+              target_network_update_freq=1.0, polyak=0.1, entropy_coef=0.01, use_tdlamda=1.0, nsteps=3.0, clip_gradients=0.5,
+              optimizer="Adam", learning_rate_actor=5e-4, learning_rate_critic=5e-4)
+    dev = torch.device("cuda:0")
+    grads = {}
+    for forms in ("hand", "loop"):
+        monkeypatch.setenv("CM_MLP_FORMS", forms)
+        batch, ap, cp, tp = _seeded(E * 7 + K, E, A, T, Do, Ds, K, Ha, Hc, La, Lc)
+        L, b = _learner(batch, ap, cp, hp, dev, target=tp)
+        oa, oc = R.AdamState(ap, 5e-4, "Adam"), R.AdamState(cp, 5e-4, "Adam")
+        chk_c, chk_a = StepChecker(R.flat(cp), "Adam", 5e-4, f"coma {forms} critic"), StepChecker(R.flat(ap), "Adam", 5e-4, f"coma {forms} actor")
+        rec = L.train_iteration(b, keep_grads=True)
+        ref = C.update(ap, cp, tp, batch, hp, oa, oc, 0)
+        assert _err(rec["critic_loss"], ref["critic_loss"]) <= TOL and _err(rec["actor_loss"], ref["actor_loss"]) <= TOL, forms
+        assert _err(rec["entropy"], ref["entropy"]) <= TOL, forms
+        chk_c.step(rec["critic_grads"], L.critic, ref["critic_grads"], R.flat(cp))
+        chk_a.step(rec["actor_grads"], L.actor, ref["actor_grads"], R.flat(ap))
+        grads[forms] = rec["actor_grads"].clone()
+    assert not torch.equal(grads["hand"], grads["loop"]), "the hand-ordered COMA actor pass did not take its own head"
+    assert grad_err(grads["hand"], grads["loop"], "coma hand vs loop forms, actor gradient") <= 1e-5
+
+
 @pytest.mark.parametrize("E,A,T,Do,Ds,K,Hc", [
     (33, 3, 16, 21, 54, 5, 64),     # the reference's default simple_spread shapes (3 agents): rows of 21 / 54 floats
     (33, 3, 16, 21, 54, 5, 128),    # ... with its default 128-wide critic (one-launch S + z0 GEMM on a padded state, fused 128-wide tiles)
