@@ -182,18 +182,27 @@ class Workload:
             ev.append((e0, e1))
         torch.cuda.synchronize()
         ms = [a.elapsed_time(c) for a, c in ev]
-        # the critic's pass the same way (phase_roofline.critic_fwd_bwd: beside the actor's kernels it only fills their tails)
+        # the critic's pass the same way (phase_roofline.critic_fwd_bwd: beside the actor's kernels it only fills their tails): the plain pass of
+        # epochs 2 .. n, and -- where the value pass hands its layer-0 activations over (learner._keeps_h0) -- the first epoch's pass without the W0 product
         L.wait_critic()
-        for _ in range(warm):
-            L.critic_pass(b, s)
-        torch.cuda.synchronize()
-        evc = []
-        for _ in range(launches):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); L.critic_pass(b, s); e1.record()
-            evc.append((e0, e1))
-        torch.cuda.synchronize()
-        self.solo_critic_ms = sum(a.elapsed_time(c) for a, c in evc) / len(evc)
+        h0_key = getattr(L, "_h0_key", None)
+
+        def critic_alone():
+            for _ in range(warm):
+                L.critic_pass(b, s)
+            torch.cuda.synchronize()
+            evc = []
+            for _ in range(launches):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); L.critic_pass(b, s); e1.record()
+                evc.append((e0, e1))
+            torch.cuda.synchronize()
+            return sum(a.elapsed_time(c) for a, c in evc) / len(evc)
+
+        self.solo_critic_first_ms = critic_alone() if h0_key is not None else None
+        L._h0_key = None
+        self.solo_critic_ms = critic_alone()
+        L._h0_key = h0_key
         return sum(ms) / len(ms), ms
 
     # ---- algorithmic work per launch (weights, MFMA-tile padding and recomputation are NOT counted)
@@ -497,6 +506,7 @@ def main():
             "phase_ms": r["phase_ms"],
             "phase_solo_ms": {"rollout": getattr(w, "solo_rollout_ms", None), "value_pass_scan": getattr(w, "solo_value_pass_ms", None),
                               "actor_fwd_bwd": solo[0] if solo else None, "critic_fwd_bwd": getattr(w, "solo_critic_ms", None),
+                              "critic_first_epoch": getattr(w, "solo_critic_first_ms", None),
                               "note": "each phase alone on the device (solo leg after the timed region); phase_ms / kernel_ms are event times inside the "
                                       "timed iterations, where the critic's epochs run beside the actor's passes and the next rollout"},
             "kernel_ms": {"actor_fwd_bwd": r["actor_ms"], "critic_fwd_bwd": r["critic_ms"]},

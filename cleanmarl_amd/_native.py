@@ -46,6 +46,8 @@ SIGNATURES = {
     "cm_policy_act_episode_ld": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _u64, _l, _p, _p, _p, _sz, _p]),
     "cm_ppo_actor_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _d, _d, _p, _p, _sz, _p]),
     "cm_critic_fwd_bwd_ld": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_critic_fwd_bwd_h0_ld": (_i, [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "cm_value_pass_keep_h0_ld": (_i, [_p, _l, _l, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "cm_rollout_spread_ld": (_i, [_p, _i, _i, _i, _i, _u64, _u64, _l, _l, _p, _i, _i, _d, _p, _l, _p, _l, _p, _p, _p, _p]),
     "cm_shape_env_fill_ld": (_i, [_i, _i, _i, _i, _i, _i, _i, _d, _u64, _l, _l, _p, _l, _p, _l, _p, _p]),
     "cm_stream_create_low_priority": (_p, []),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "cm_optimizer_step": (_i, [_p, _l, _po, _p]),
     "cm_ppo_actor_train_step_ld": (_i, [_p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _d, _p, _p, _sz, _po, _p]),
     "cm_critic_train_step_ld": (_i, [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _po, _p]),
+    "cm_critic_train_step_h0_ld": (_i, [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _po, _p]),
     "cm_gru_actor_chunk_train_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _d, _d, _p, _p, _sz, _po, _p]),
     "cm_peer_handle_bytes": (_sz, []),
     "cm_peer_mailbox_bytes": (_sz, [_i, _l]),

@@ -46,7 +46,11 @@ __device__ __forceinline__ float cf_row16_sum(float v) {
 #define CF_STEP(xr, base, s_, acc, w) do { CF_LD2(xr, base, (s_) + 1); cf_wait<2>((xr)[(s_) & 1][0], (xr)[(s_) & 1][1]); CF_MM8(xr, s_, acc, w); } while (0)
 #define CF_LAST(xr, acc, w) do { cf_wait<0>((xr)[1][0], (xr)[1][1]); CF_MM8(xr, 7, acc, w); } while (0)
 
-template <int NC>
+// SAVED (round 6): the layer-0 activations h0 = relu(x W0^T + b0) of every row come from memory (MlpArgs::dz0, [rows][HP]) instead of the NC-chunk
+// product -- the value pass at the head of the update computed them with the SAME parameters the first critic epoch uses (cm_value_pass_keep_h0_ld /
+// cm_critic_fwd_bwd_h0_ld).  The X tile still goes to LDS (the layer-0 weight gradient contracts it), W0 is not loaded at all.  At config 3 (384-wide
+// state) the layer-0 product is 39 % of the kernel's time (profiles/r06_phase_critic.txt) against 64 of 448 floats per row of extra traffic.
+template <int NC, bool SAVED = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XS = smem;                       // [NC][TM][LDT] the tile's input, chunk by chunk
@@ -61,7 +65,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
     const bool cok = col < H;
     const int lrow = tid >> 2, part = tid & 3;  // loss phase: four lanes per row
     // ---- weights of this wave's 16 hidden columns -> registers
-    float w0[NC][16], w1n[16], w1t[16];
+    float w0[SAVED ? 1 : NC][16], w1n[16], w1t[16];
+    if constexpr (!SAVED) {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
                 const int k = 64 * c + 16 * j + 4 * g + i;
                 w0[c][4 * j + i] = (cok && k < din) ? a.params[off.W0 + (long)col * din + k] : 0.0f;
             }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -81,10 +87,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
         }
     // park the layer-0 slice in accumulation registers (the MFMA B operand may come from either file): left to itself the allocator
     // keeps all 16 NC of them in the 256 architectural registers and spills the X prefetch sets to scratch
+    if constexpr (!SAVED) {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int k = 0; k < 16; ++k) asm volatile("" : "+a"(w0[c][k]));
+    }
     const float b0r = cok ? a.params[off.b0 + col] : 0.0f, b1r = cok ? a.params[off.bl(0) + col] : 0.0f;
     const float wo = cok ? a.params[off.Wout + col] : 0.0f, bout = a.params[off.bout];
     // ---- gradient accumulators (whole launch)
@@ -117,7 +125,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
         }
     };
     auto xstore = [&](float* dst, const Tile16& t) { tile_store<true>(dst, t); };
-    if ((long)blockIdx.x < ntiles) { xload(pa, blockIdx.x, 0); xload(pb, blockIdx.x, 1); }
+    // SAVED: the tile's h0 rows, requested a tile ahead like X (same clamped, branch-free 16-byte loads; leading dimension HP)
+    Tile16 ph;
+    auto hload = [&](Tile16& t, long tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + NTHREADS * i;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            const long row = min(tile * TM + r, a.rows - 1);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(a.dz0 + row * HP + c4);
+            t.v[i] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) { xload(pa, blockIdx.x, 0); xload(pb, blockIdx.x, 1); if constexpr (SAVED) hload(ph, blockIdx.x); }
 
     PH_DECL
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -131,11 +151,33 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
         // ================= forward, layer 0: chunk c + 1 is written to LDS BEFORE chunk c is multiplied, so the barrier after the
         // products finds every wave's stores long finished (one exposed store + barrier per tile instead of one per chunk)
         f32x4 z0[4] = {zero4, zero4, zero4, zero4};
+        f32x4 xr[2][2];
+        float h0[16];
+        if constexpr (SAVED) {
+            // no layer-0 product: the X chunks go to LDS in the order (and through the register sets) of the product loop below, h0 comes from memory
+            xstore(XS, pa);
+            if (NC > 2) xload(pa, tile, 2); else xload(pa, min(ntile, ntiles - 1), 0);
+#pragma unroll
+            for (int c = 0; c + 1 < NC; ++c) {
+                Tile16& set = ((c + 1) & 1) ? pb : pa;
+                xstore(XS + (c + 1) * TM * LDT, set);
+                if (c + 3 < NC) xload(set, tile, c + 3);
+                else xload(set, min(ntile, ntiles - 1), c + 3 - NC);
+            }
+            xstore(H0s, ph);
+            hload(ph, min(ntile, ntiles - 1));
+            PH(0);
+            if (NC & 1) { const Tile16 t = pa; pa = pb; pb = t; }
+            __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h0[4 * rb + q] = H0s[(16 * rb + 4 * g + q) * LDT + col];
+        } else {
         xstore(XS, pa);
         if (NC > 2) xload(pa, tile, 2); else xload(pa, min(ntile, ntiles - 1), 0);
         __syncthreads();
         const unsigned xa_f = cf_lds_addr(XS + n * LDT + 4 * g);  // forward A operand: rows 16 rb + n, columns 16 j + 4 g ..
-        f32x4 xr[2][2];
         CF_LD2(xr, xa_f, 0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -169,7 +211,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
         PH(0);
         if (NC & 1) { const Tile16 t = pa; pa = pb; pb = t; }  // odd chunk count: the next tile's chunk 0 was requested into pb
         // h0 = relu(z0 + b0): kept in registers (relu' mask), written to LDS for the other waves
-        float h0[16];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -178,6 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_critic_fused(const MlpArgs a) {
                 H0s[(16 * rb + 4 * g + q) * LDT + col] = h0[4 * rb + q];
             }
         __syncthreads();
+        }
         PH(1);
         // ================= hidden layer + value head =================
         f32x4 z1[4] = {zero4, zero4, zero4, zero4};
@@ -778,9 +820,14 @@ inline int run_critic_fused(MlpArgs a, float* grad_and_stats, void* ws, size_t w
     }
     const int grid = (int)(ntiles < 256 ? ntiles : 256);  // one workgroup per CU
     const size_t lds = critic_fused_lds_bytes(nc);
+    // a.dz0 != NULL: the rows' layer-0 activations for THESE parameters are in memory (cm_critic_fwd_bwd_h0_ld): the kernel without the layer-0 product
 #define CM_CF(NC_) do { \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_fused<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k_critic_fused<NC_>, dim3(grid), dim3(NTHREADS), lds, s, a); } while (0)
+        if (a.dz0) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_fused<NC_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_critic_fused<NC_, true>), dim3(grid), dim3(NTHREADS), lds, s, a); \
+        } else { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_fused<NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(k_critic_fused<NC_>, dim3(grid), dim3(NTHREADS), lds, s, a); } } while (0)
     switch (nc) {
         case 2: CM_CF(2); break; case 3: CM_CF(3); break; case 4: CM_CF(4); break; case 5: CM_CF(5); break;
         case 6: CM_CF(6); break; default: CM_CF(7); break;

@@ -9,13 +9,14 @@ extern unsigned long long* g_prof;
 
 static int mlp_forward_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                           const float* params, const uint8_t* avail, float* y, cm_stream_t stream, void* ws = nullptr, size_t ws_bytes = 0,
-                          bool solo = false) {
+                          bool solo = false, float* h0_out = nullptr) {
     if (int rc = check_shapes("cm_mlp_forward", din, hidden, n_hidden_layers, dout)) return rc;
     CM_REQUIRE(x_ld >= din, "cm_mlp_forward: leading dimension %lld < din %d", (long long)x_ld, din);
     if (rows <= 0) return 0;
     MlpArgs a = {};
     a.x = x; a.x_stride = x_ld; a.rows = rows; a.din = din; a.H = hidden; a.L = n_hidden_layers; a.dout = dout;
     a.params = params; a.avail = avail; a.avail_stride = dout; a.y = y;
+    a.dz0 = h0_out;  // forward kernels: optional [rows][64] copy of the layer-0 activations (cm_value_pass_keep_h0_ld)
     prep_w0_image(a, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);  // no workspace: W0 chunks on 4-byte loads where unaligned
     const size_t lds_bytes = (size_t)make_lds(a.L, a.dout, (a.din + KC - 1) / KC).total * sizeof(float);
     // forward kernels run two workgroups per CU as well (same two-group finish, cm_mlp_kernel.h): the unequal split pays for a launch that
@@ -57,6 +58,15 @@ extern "C" int cm_mlp_forward_solo_ld(const float* x, int64_t x_ld, int64_t rows
                                       const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {
     if (wide_shape(hidden, n_hidden_layers, dout)) return cm_mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, ws, ws_bytes, stream);
     return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, dout, params, avail, y, stream, ws, ws_bytes, true);
+}
+/* The value pass of an update (cm_mlp_forward_solo_ld with one output and no availability mask) that also leaves the layer-0 activations
+ * h0 = relu(x W0^T + b0) of every row in h0_out ([rows][64] floats, columns >= hidden are 0) for the first critic epoch of the same update
+ * (cm_critic_fwd_bwd_h0_ld: same parameters, same rows).  Shapes of the fused kernels only (hidden <= 64). */
+extern "C" int cm_value_pass_keep_h0_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers,
+                                        const float* params, float* y, float* h0_out, void* ws, size_t ws_bytes, cm_stream_t stream) {
+    CM_REQUIRE(!wide_shape(hidden, n_hidden_layers, 1), "cm_value_pass_keep_h0_ld: hidden %d / %d layers run on the layered schedule, which keeps no h0", hidden, n_hidden_layers);
+    CM_REQUIRE(h0_out != nullptr, "cm_value_pass_keep_h0_ld: h0_out is NULL");
+    return mlp_forward_ld(x, x_ld, rows, din, hidden, n_hidden_layers, 1, params, nullptr, y, stream, ws, ws_bytes, true, h0_out);
 }
 extern "C" int cm_mlp_forward_ws(const float* x, int64_t rows, int din, int hidden, int n_hidden_layers, int dout,
                                  const float* params, const uint8_t* avail, float* y, void* ws, size_t ws_bytes, cm_stream_t stream) {

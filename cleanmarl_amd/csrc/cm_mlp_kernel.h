@@ -1052,7 +1052,11 @@ _Pragma("unroll") \
                 const int row = 32 * wm + (g & 3) + 8 * (g >> 2) + 4 * h;
                 float z = acc[g] + bias;
                 if (ADD_OK) z += zadd[g];
-                H0[row * LDT + 32 * wn + lc] = enc<BF>(fmaxf(z, 0.0f));
+                const float hv = fmaxf(z, 0.0f);
+                H0[row * LDT + 32 * wn + lc] = enc<BF>(hv);
+                // forward passes may hand the layer-0 activations to a later pass with the same parameters (cm_value_pass_keep_h0_ld -> the first critic
+                // epoch, cm_critic_fused.h): [rows][HP] row-major through MlpArgs::dz0, which no forward kernel uses otherwise
+                if constexpr (MODE == M_FWD) { if (a.dz0 != nullptr && row0 + row < a.rows) a.dz0[(row0 + row) * HP + 32 * wn + lc] = hv; }
             }
         }
         __syncthreads();

@@ -6,6 +6,7 @@ Mirrors the inline learner of the reference script (cleanmarl/mappo_multienvs.py
 but every numeric step is a call into libcleanmarl_hip.so on the current HIP stream.  PyTorch only
 provides device memory, streams and (for env-sharded multi-GPU runs) torch.distributed.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -292,6 +293,7 @@ class PPOLearner:
         self._sched_rows = {}
         self.moments = torch.zeros(3, dtype=torch.float64, device=device)
         self.values = None
+        self._h0, self._h0_key = None, None  # layer-0 activations of the value pass for the first critic epoch (_keeps_h0)
         self.mom_ws = None
         self.stats_stream = None  # the stream the last update()'s statistics left on when it was NOT the launch stream (the critic's, overlapped schedules)
         self.events = None  # bench.py sets this to a list to collect per-launch (kind, start, end) HIP events
@@ -353,8 +355,18 @@ class PPOLearner:
         self.wait_critic()  # the critic epochs of the previous update ran on their own stream (under this batch's rollout)
         x_ld = b.state_ld if self.algo == "mappo" else b.obs_ld
         # "solo": this launch is ordered behind the critic stream (wait_critic above) and in front of the update -- it has the GPU to itself
-        N.check(lib.cm_mlp_forward_solo_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
-                                           N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_solo_ld")
+        if self._keeps_h0(rows, x_ld):
+            # the first critic epoch evaluates the critic on these rows with these parameters again: the value pass leaves its layer-0
+            # activations behind and that epoch's one-pass kernel skips the product with W0 (critic_pass; csrc/cm_critic_fused.h, SAVED)
+            if self._h0 is None or self._h0.numel() < rows * 64:
+                self._h0 = torch.empty(rows * 64, dtype=torch.float32, device=self.device)
+            N.check(lib.cm_value_pass_keep_h0_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, N.ptr(self.critic), N.ptr(self.values),
+                                                 N.ptr(self._h0), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_value_pass_keep_h0_ld")
+            self._h0_key = (self.opt_c.step, x.data_ptr(), rows)
+        else:
+            self._h0_key = None
+            N.check(lib.cm_mlp_forward_solo_ld(N.ptr(x), x_ld, rows, cs.din, cs.hidden, cs.n_layers, 1, N.ptr(self.critic), None,
+                                               N.ptr(self.values), N.ptr(self.ws_c), self.ws_c.numel(), s), "cm_mlp_forward_solo_ld")
         N.check(lib.cm_td_lambda_scan(N.ptr(b.reward), N.ptr(self.values), N.ptr(b.ep_len), E, A, Av, T,
                                       hp.gamma, hp.td_lambda, N.ptr(b.ret), N.ptr(b.adv), s), "cm_td_lambda_scan")
         if hp.normalize_advantage:
@@ -387,6 +399,24 @@ class PPOLearner:
         fn(*a)
         e1.record()
         self.events.append((kind, e0, e1))
+
+    def _keeps_h0(self, rows, x_ld):
+        """Does the value pass hand its layer-0 activations to the first critic epoch?  Only where that epoch runs the one-pass kernel
+        (csrc/cm_mlp_critic.hip: 65 .. 448 input columns on 16-byte rows, one hidden layer of <= 64 units, >= 131072 rows, exact fp32) AND the
+        input is wide enough for the 64 extra floats per row to pay (>= 192 columns: measured at config 3's 384, profiles/r06_critic_h0_ab.txt;
+        config 4's 115-wide observations would trade a 2-chunk product for 56 % more traffic).  CM_CRITIC_H0=0 / 1 forces it off / on wherever the
+        kernel exists (A/B runs, tests)."""
+        cs = self.critic_spec
+        force = os.environ.get("CM_CRITIC_H0", "auto")
+        if force == "0" or cs.kind != "mlp":
+            return False
+        sched = os.environ.get("CM_CRITIC_SCHEDULE", "auto")
+        shape = 65 <= cs.din <= 448 and cs.hidden <= 64 and cs.n_layers == 1 and x_ld % 4 == 0 and os.environ.get("CM_MFMA", "fp32") == "fp32"
+        if not shape or sched in ("split", "fused2"):
+            return False
+        if force == "1":
+            return sched == "fused" or rows >= 131072
+        return rows >= 131072 and cs.din >= 192
 
     def _ensure_ws(self, b):
         a, c = self.actor_spec, self.critic_spec
@@ -430,12 +460,27 @@ class PPOLearner:
         self._ensure_ws(b)
         cs = self.critic_spec
         x = b.state if self.algo == "mappo" else b.obs
+        # layer-0 activations left by the value pass: valid while neither the parameters (no optimiser step since) nor the rows have changed
+        rows = b.E * b.T * (1 if self.algo == "mappo" else b.A)
+        h0 = self._h0 if (self._h0_key is not None and self._h0_key == (self.opt_c.step, x.data_ptr(), rows)) else None
         if step is not None:
             o = self.opt_c.next_step(self.critic, step, self.hp.clip_gradients, stats_out=stats)
+            if h0 is not None:
+                N.check(self.lib.cm_critic_train_step_h0_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(h0), N.ptr(b.ret), N.ptr(b.ep_len),
+                                                            b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
+                                                            N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), o, s),
+                        "cm_critic_train_step_h0")
+                return
             N.check(self.lib.cm_critic_train_step_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len),
                                                      b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
                                                      N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), o, s),
                     "cm_critic_train_step")
+            return
+        if h0 is not None:
+            N.check(self.lib.cm_critic_fwd_bwd_h0_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(h0), N.ptr(b.ret), N.ptr(b.ep_len),
+                                                     b.E, b.A, b.T, 0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
+                                                     N.ptr(self.critic), N.ptr(self.g_critic if g is None else g), N.ptr(self.ws_c), self.ws_c.numel(), s),
+                    "cm_critic_fwd_bwd_h0")
             return
         N.check(self.lib.cm_critic_fwd_bwd_ld(N.ptr(x), b.state_ld if self.algo == "mappo" else b.obs_ld, N.ptr(b.ret), N.ptr(b.ep_len), b.E, b.A, b.T,
                                            0 if self.algo == "mappo" else 1, cs.din, cs.hidden, cs.n_layers,
@@ -710,5 +755,6 @@ class PPOLearner:
                 warnings.warn(f"resuming with different hyper-parameters than the checkpoint was written with: {diff}")
         self.wait_critic()
         self.actor.copy_(sd["actor"]); self.critic.copy_(sd["critic"])
+        self._h0_key = None
         for opt, o in ((self.opt_a, sd["opt_a"]), (self.opt_c, sd["opt_c"])):
             opt.m.copy_(o["m"]); opt.v.copy_(o["v"]); opt.step = int(o["step"])

@@ -405,6 +405,22 @@ int cm_ppo_actor_fwd_bwd_ld(const float* obs, int64_t obs_ld, const uint8_t* ava
 int cm_critic_fwd_bwd_ld(const float* x, int64_t x_ld, const float* ret, const int32_t* ep_len,
                          int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
                          const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+/* ---- the critic's first epoch without its layer-0 product (round 6) ----
+ * The value pass at the head of an update (cleanmarl/mappo_multienvs.py:484-504) and the first critic epoch (:554-558) evaluate the critic on the same
+ * rows with the same parameters.  cm_value_pass_keep_h0_ld = cm_mlp_forward_solo_ld with one output and no mask that ALSO leaves
+ * h0 = relu(x W0^T + b0) in h0_out ([rows][64] floats, caller-owned; columns >= hidden are 0; fused-kernel shapes only: hidden <= 64);
+ * cm_critic_fwd_bwd_h0_ld / cm_critic_train_step_h0_ld = cm_critic_fwd_bwd_ld / cm_critic_train_step_ld for THAT epoch: the one-pass schedule then
+ * reads h0 instead of multiplying x by W0 (39 % of its time at a 384-wide state), the other schedules ignore it.  The caller guarantees that params
+ * have not changed since the value pass; later epochs use the plain entry points.  Same sums (h0 comes from another product form: results agree to
+ * rounding). */
+int cm_value_pass_keep_h0_ld(const float* x, int64_t x_ld, int64_t rows, int din, int hidden, int n_hidden_layers,
+                             const float* params, float* y, float* h0_out, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_critic_fwd_bwd_h0_ld(const float* x, int64_t x_ld, const float* h0, const float* ret, const int32_t* ep_len,
+                            int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                            const float* params, float* grad_and_stats, void* ws, size_t ws_bytes, cm_stream_t stream);
+int cm_critic_train_step_h0_ld(const float* x, int64_t x_ld, const float* h0, const float* ret, const int32_t* ep_len,
+                               int E, int A, int T, int per_agent, int din, int hidden, int n_hidden_layers,
+                               float* grad_and_stats, void* ws, size_t ws_bytes, const cm_opt_step_t* opt, cm_stream_t stream);
 /* eps = 0: cm_rollout_spread; eps in (0, 1]: cm_rollout_spread_eps; eps < 0: greedy -- every agent takes the first maximal masked logit
  * (the evaluation rollouts of --greedy_eval: cleanmarl/mappo_multienvs.py:614-650 as ONE launch over num_eval_ep environments) */
 int cm_rollout_spread_ld(float* env_state, int E, int A, int T, int agent_ids, uint64_t seed, uint64_t act_seed,

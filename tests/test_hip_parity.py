@@ -1473,6 +1473,67 @@ def test_one_pass_critic_equals_the_two_kernel_schedule_on_random_shapes(monkeyp
             assert np.array_equal(out["fused"], out["fused2"])  # only two-chunk inputs have a two-tile form
 
 
+def test_first_critic_epoch_on_the_value_pass_activations_matches_the_plain_pass():
+    """cm_value_pass_keep_h0_ld + cm_critic_fwd_bwd_h0_ld straight through the C-ABI, 24 seeded random shapes of the one-pass critic (2 .. 7 input chunks,
+    H <= 64, central and per-agent targets, ragged episodes, partial tiles, more tiles than workgroups, padded leading dimensions): the values are the
+    bits of cm_mlp_forward_solo_ld, h0 is relu(x W0^T + b0) (1e-5 against torch), and the critic pass that reads h0 instead of multiplying by W0
+    (k_critic_fused<NC, true>) returns the gradient + statistics buffer of the plain one-pass kernel to 1e-5 of its scale (h0 comes from another
+    product form: not bit for bit), with identical row count."""
+    from cleanmarl_amd import _native as N
+    from cleanmarl_amd.learner import NetSpec, flatten_params, init_params_like_torch
+    lib, dev = N.load(), torch.device("cuda:0")
+    rng = np.random.default_rng(777)
+    N.set_option("critic_schedule", "fused")
+    try:
+        for case in range(24):
+            nc = int(rng.integers(2, 8))
+            din = int(rng.integers(64 * (nc - 1) + 1, 64 * nc + 1))
+            ld = (din + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))
+            H = int(rng.choice([16, 33, 48, 64]))
+            A, T = int(rng.integers(1, 12)), int(rng.integers(3, 40))
+            per_agent = int(rng.integers(0, 2))
+            E = int(rng.choice([1, 3, 17, 70, 700 if case % 6 == 0 else 40]))
+            torch.manual_seed(case)
+            spec = NetSpec(din, H, 1, 1)
+            params = init_params_like_torch(spec)
+            p = flatten_params(params, dev)
+            rows_shape = (E, A, T) if per_agent else (E, T)
+            rows = int(np.prod(rows_shape))
+            x = torch.zeros(*rows_shape, ld, device=dev)
+            x[..., :din] = torch.randn(*rows_shape, din, device=dev)
+            ret = torch.randn(E, A, T, device=dev)
+            ep_len = torch.from_numpy(rng.integers(1, T + 1, size=E).astype(np.int32)).to(dev)
+            ws = torch.empty(max(lib.cm_critic_workspace_bytes(E, A, T, per_agent, din, H, 1), lib.cm_mlp_forward_workspace_bytes(rows, din, H, 1, 1)),
+                             dtype=torch.uint8, device=dev)
+            v0, v1 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+            h0 = torch.full((rows, 64), float("nan"), device=dev)
+            N.check(lib.cm_mlp_forward_solo_ld(N.ptr(x), ld, rows, din, H, 1, 1, N.ptr(p), None, N.ptr(v0), N.ptr(ws), ws.numel(), N.stream_ptr()), "solo")
+            N.check(lib.cm_value_pass_keep_h0_ld(N.ptr(x), ld, rows, din, H, 1, N.ptr(p), N.ptr(v1), N.ptr(h0), N.ptr(ws), ws.numel(), N.stream_ptr()), "keep_h0")
+            torch.cuda.synchronize()
+            assert torch.equal(v0, v1), case
+            W0, b0 = params[0].to(dev), params[1].to(dev)
+            h_ref = torch.relu(x.reshape(rows, ld)[:, :din].double() @ W0.double().T + b0.double()).float()
+            assert _err(h0[:, :H].cpu().numpy(), h_ref.cpu().numpy(), "value pass h0") <= 1e-5, case
+            assert (h0[:, H:] == 0).all(), case
+            out = {}
+            for kind in ("plain", "h0"):
+                g = torch.full((spec.nparams + N.NUM_STATS,), float("nan"), device=dev)
+                if kind == "plain":
+                    N.check(lib.cm_critic_fwd_bwd_ld(N.ptr(x), ld, N.ptr(ret), N.ptr(ep_len), E, A, T, per_agent, din, H, 1, N.ptr(p), N.ptr(g),
+                                                     N.ptr(ws), ws.numel(), N.stream_ptr()), "cm_critic_fwd_bwd_ld")
+                else:
+                    N.check(lib.cm_critic_fwd_bwd_h0_ld(N.ptr(x), ld, N.ptr(h0), N.ptr(ret), N.ptr(ep_len), E, A, T, per_agent, din, H, 1, N.ptr(p), N.ptr(g),
+                                                        N.ptr(ws), ws.numel(), N.stream_ptr()), "cm_critic_fwd_bwd_h0_ld")
+                torch.cuda.synchronize()
+                out[kind] = g.cpu().numpy()
+            assert np.isfinite(out["h0"]).all(), (case, din, H, A, T, E, per_agent)
+            scale = 1.0 + np.abs(out["plain"]).max()
+            assert np.abs(out["h0"] - out["plain"]).max() <= 1e-5 * scale, (case, din, ld, H, A, T, E, per_agent, np.abs(out["h0"] - out["plain"]).max() / scale)
+            assert out["h0"][spec.nparams + N.STAT_COUNT] == out["plain"][spec.nparams + N.STAT_COUNT], case
+    finally:
+        N.set_option("critic_schedule", "auto")
+
+
 @pytest.mark.parametrize("per_agent", [0, 1])
 @pytest.mark.parametrize("rows_e,T", [(2, 64), (3, 64), (5, 40), (33, 31), (1030, 64), (2049, 33)])
 def test_two_tile_critic_equals_the_one_tile_kernel(rows_e, T, per_agent):
