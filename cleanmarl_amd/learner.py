@@ -402,10 +402,10 @@ class PPOLearner:
 
     def _keeps_h0(self, rows, x_ld):
         """Does the value pass hand its layer-0 activations to the first critic epoch?  Only where that epoch runs the one-pass kernel
-        (csrc/cm_mlp_critic.hip: 65 .. 448 input columns on 16-byte rows, one hidden layer of <= 64 units, >= 131072 rows, exact fp32) AND the
-        input is wide enough for the 64 extra floats per row to pay (>= 192 columns: measured at config 3's 384, profiles/r06_critic_h0_ab.txt;
-        config 4's 115-wide observations would trade a 2-chunk product for 56 % more traffic).  CM_CRITIC_H0=0 / 1 forces it off / on wherever the
-        kernel exists (A/B runs, tests)."""
+        (csrc/cm_mlp_critic.hip: 65 .. 448 input columns on 16-byte rows, one hidden layer of <= 64 units, >= 131072 rows, exact fp32).  The 64
+        extra floats per row pay at both ends of that range (profiles/r06_critic_h0_ab.txt: config 3's 384-wide state 7.76 -> 7.68 ms, config 4's
+        115-wide observations 23.26 -> 22.78 ms although h0 is more than half an input row there).  CM_CRITIC_H0=0 / 1 forces it off / on wherever
+        the kernel exists (A/B runs, tests)."""
         cs = self.critic_spec
         force = os.environ.get("CM_CRITIC_H0", "auto")
         if force == "0" or cs.kind != "mlp":
@@ -416,7 +416,7 @@ class PPOLearner:
             return False
         if force == "1":
             return sched == "fused" or rows >= 131072
-        return rows >= 131072 and cs.din >= 192
+        return rows >= 131072
 
     def _ensure_ws(self, b):
         a, c = self.actor_spec, self.critic_spec
